@@ -1,0 +1,72 @@
+// Common device helpers for the gfx950 kernels (wave64, MFMA).  gfx950 only: no portability macros.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dinounet_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DU_WAVE 64
+
+template <typename T> struct Elem;
+template <> struct Elem<float> { static constexpr int VEC = 4; static constexpr int DT = DU_F32; };
+template <> struct Elem<bf16_t> { static constexpr int VEC = 8; static constexpr int DT = DU_BF16; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// 16-byte vector <-> element arrays
+template <typename T> struct Vec16 {
+  static constexpr int N = 16 / sizeof(T);
+  T v[N];
+};
+template <typename T> __device__ __forceinline__ Vec16<T> as_vec(uint4 u) { return __builtin_bit_cast(Vec16<T>, u); }
+template <typename T> __device__ __forceinline__ uint4 as_u4(Vec16<T> v) { return __builtin_bit_cast(uint4, v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case DU_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case DU_ACT_RELU: return v > 0.f ? v : 0.f;
+    case DU_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
+    default: return v;
+  }
+}
+// d act(z) / dz evaluated at pre-activation z
+__device__ __forceinline__ float act_grad(float z, int act) {
+  switch (act) {
+    case DU_ACT_GELU: {
+      const float c = 0.70710678118654752440f, ip = 0.39894228040143267794f;  // 1/sqrt(2), 1/sqrt(2 pi)
+      return 0.5f * (1.0f + erff(z * c)) + z * ip * __expf(-0.5f * z * z);
+    }
+    case DU_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case DU_ACT_LEAKY: return z > 0.f ? 1.f : 0.01f;
+    default: return 1.f;
+  }
+}
+
+static inline int du_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DU_OK : DU_ERR_LAUNCH;
+}
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,408 @@
+// MFMA GEMM / implicit-convolution engine for gfx950.
+//
+//   C[m][n] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
+//
+// One kernel template serves every dense contraction of the Dino U-Net hot path: linear layers and 1x1 convs
+// (PLAIN_ROW x PLAIN_ROW), their data gradients (PLAIN_ROW x PLAIN_COL), weight gradients (PLAIN_COL x PLAIN_COL,
+// split-K + fp32 atomics), 3x3 / strided / transposed-stride convolutions as implicit GEMM (IM2COL_ROW gather of
+// an NHWC tensor, optionally from two tensors = fused channel concat), conv weight gradients (PLAIN_COL x
+// IM2COL_COL) and ConvTranspose2d k2s2 (GEMM + pixel-shuffle store).
+//
+// Tiling (wave64): 256 threads = WM x WN waves, each wave owns TM x TN MFMA tiles of 32x32
+// (v_mfma_f32_32x32x16_bf16 for bf16 inputs, v_mfma_f32_32x32x2_f32 for the fp32 parity mode), fp32 accumulate.
+// Operand tiles are staged global -> registers -> LDS as S[outer][k] (k contiguous, one 16-byte vector of
+// padding per row); the next tile's global loads are issued before the current tile's MFMAs so HBM/L2 latency
+// hides under the matrix pipe.
+#include "common.h"
+
+namespace {
+
+struct Operand {
+  const void* p; long ld; long bstride;
+  const void* p2; long ld2; int C1;
+  int Hi, Wi, C, KH, KW, stride, pad, Ho, Wo, transposed;
+  int logC;  // log2(C) if C is a power of two else -1
+};
+
+struct GemmParams {
+  Operand a, b;
+  void* C; long ldc; long cbs;
+  int M, N, K;
+  int split_k, k_per_split;
+  float alpha; const float* bias; int act; const float* gamma; const void* residual; long ldr;
+  int store_mode, ps_H, ps_W, ps_C;
+  int tiles_n;
+};
+
+__device__ __forceinline__ int div_small(int x, int d) {
+  if (d == 3) return (x * 11) >> 5;  // exact for x < 32
+  if (d == 2) return x >> 1;
+  if (d == 1) return x;
+  return x / d;
+}
+
+// address of element (pixel (b,yo,xo), column c=(tap,ci)) of the im2col matrix; returns nullptr if padding
+template <typename T>
+__device__ __forceinline__ const T* im2col_ptr(const Operand& op, int b, int yo, int xo, int c) {
+  int tap = op.logC >= 0 ? (c >> op.logC) : (c / op.C);
+  int ci = c - tap * op.C;
+  int dy = div_small(tap, op.KW);
+  int dx = tap - dy * op.KW;
+  int yi, xi;
+  bool ok;
+  if (!op.transposed) {
+    yi = yo * op.stride - op.pad + dy;
+    xi = xo * op.stride - op.pad + dx;
+    ok = (yi >= 0) & (yi < op.Hi) & (xi >= 0) & (xi < op.Wi);
+  } else {
+    int ty = yo + op.pad - dy, tx = xo + op.pad - dx;
+    if (op.stride == 1) { yi = ty; xi = tx; ok = true; }
+    else if (op.stride == 2) { yi = ty >> 1; xi = tx >> 1; ok = ((ty & 1) == 0) & ((tx & 1) == 0); }
+    else { yi = ty / op.stride; xi = tx / op.stride; ok = (yi * op.stride == ty) & (xi * op.stride == tx); }
+    ok = ok & (ty >= 0) & (tx >= 0) & (yi < op.Hi) & (xi < op.Wi);
+  }
+  if (!ok) return nullptr;
+  long sp = ((long)b * op.Hi + yi) * op.Wi + xi;
+  if (ci < op.C1) return (const T*)op.p + sp * op.ld + ci;
+  return (const T*)op.p2 + sp * op.ld2 + (ci - op.C1);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Tile loader: OUTER x BK tile of one operand -> registers -> LDS S[OUTER][BK + VEC]
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int MODE, int OUTER, int BK, int NT>
+struct TileLoader {
+  static constexpr int VEC = Elem<T>::VEC;
+  static constexpr int LDS_LD = BK + VEC;
+  static constexpr int TOTAL = OUTER * BK / VEC;
+  static constexpr int NV = (TOTAL + NT - 1) / NT;
+  static constexpr bool ROWMODE = (MODE == DU_PLAIN_ROW || MODE == DU_IM2COL_ROW);
+  static constexpr int KV = BK / VEC;      // vectors per row (ROW modes)
+  static constexpr int OV = OUTER / VEC;   // vectors per k-row (COL modes)
+
+  uint4 regs[NV];
+  // per-slot cached pixel coordinates for the IM2COL modes
+  int pb[NV], py[NV], px[NV];
+
+  __device__ __forceinline__ void init(const Operand& op, int tid, int o0, int outer_dim, int kbeg) {
+    if constexpr (MODE == DU_IM2COL_ROW) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        int v = tid + i * NT;
+        int o = o0 + v / KV;
+        if (o >= outer_dim) o = outer_dim - 1;
+        int xo = o % op.Wo; int t = o / op.Wo;
+        px[i] = xo; py[i] = t % op.Ho; pb[i] = t / op.Ho;
+      }
+    } else if constexpr (MODE == DU_IM2COL_COL) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        int v = tid + i * NT;
+        long pix = (long)kbeg + v / OV;
+        int xo = pix % op.Wo; long t = pix / op.Wo;
+        px[i] = xo; py[i] = (int)(t % op.Ho); pb[i] = (int)(t / op.Ho);
+      }
+    }
+  }
+
+  // advance cached pixel coordinates by BK pixels (IM2COL_COL: contraction runs over pixels)
+  __device__ __forceinline__ void advance(const Operand& op) {
+    if constexpr (MODE == DU_IM2COL_COL) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        px[i] += BK;
+        while (px[i] >= op.Wo) { px[i] -= op.Wo; py[i]++; }
+        while (py[i] >= op.Ho) { py[i] -= op.Ho; pb[i]++; }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void load(const Operand& op, int tid, int o0, int outer_dim, int k0, int kend) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      int v = tid + i * NT;
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (TOTAL % NT == 0 || v < TOTAL) {
+        if constexpr (MODE == DU_PLAIN_ROW) {
+          int o = o0 + v / KV, k = k0 + (v % KV) * VEC;
+          if (o < outer_dim && k < kend) r = *(const uint4*)((const T*)op.p + (long)o * op.ld + k);
+        } else if constexpr (MODE == DU_PLAIN_COL) {
+          int k = k0 + v / OV, o = o0 + (v % OV) * VEC;
+          if (o < outer_dim && k < kend) r = *(const uint4*)((const T*)op.p + (long)k * op.ld + o);
+        } else if constexpr (MODE == DU_IM2COL_ROW) {
+          int o = o0 + v / KV, k = k0 + (v % KV) * VEC;
+          if (o < outer_dim && k < kend) {
+            const T* q = im2col_ptr<T>(op, pb[i], py[i], px[i], k);
+            if (q) r = *(const uint4*)q;
+          }
+        } else {  // IM2COL_COL: row = pixel (contraction), column vector = (tap, ci..ci+VEC)
+          int k = k0 + v / OV, o = o0 + (v % OV) * VEC;
+          if (o < outer_dim && k < kend) {
+            const T* q = im2col_ptr<T>(op, pb[i], py[i], px[i], o);
+            if (q) r = *(const uint4*)q;
+          }
+        }
+      }
+      regs[i] = r;
+    }
+  }
+
+  __device__ __forceinline__ void store(T* S, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      int v = tid + i * NT;
+      if (TOTAL % NT == 0 || v < TOTAL) {
+        if constexpr (ROWMODE) {
+          int o = v / KV, kv = v % KV;
+          *(uint4*)(S + o * LDS_LD + kv * VEC) = regs[i];
+        } else {
+          int k = v / OV, ov = v % OV;
+          Vec16<T> e = as_vec<T>(regs[i]);
+#pragma unroll
+          for (int j = 0; j < VEC; j++) S[(ov * VEC + j) * LDS_LD + k] = e.v[j];
+        }
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// MFMA micro-kernels
+// ------------------------------------------------------------------------------------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int K = 16;  // contraction per instruction
+  typedef bf16x8 Frag;
+  // lane l supplies row (l&31), k-slice (l>>5)*8 .. +8
+  static __device__ __forceinline__ Frag load(const bf16_t* S, int ld, int row, int kk, int lane) {
+    return *(const bf16x8*)(S + row * ld + kk * 16 + (lane >> 5) * 8);
+  }
+  static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int K = 2;
+  typedef float Frag;
+  // lane l supplies row (l&31), k = (l>>5)
+  static __device__ __forceinline__ Frag load(const float* S, int ld, int row, int kk, int lane) {
+    return S[row * ld + kk * 2 + (lane >> 5)];
+  }
+  static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T> struct TileK;
+template <> struct TileK<bf16_t> { static constexpr int BK = 64; };
+template <> struct TileK<float> { static constexpr int BK = 16; };
+
+template <typename T, typename TC, int AMODE, int BMODE, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams P) {
+  constexpr int NT = 256;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = TileK<T>::BK;
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int LDS_LD = BK + VEC;
+  static_assert(WM * WN == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) T smem[(BM + BN) * LDS_LD];
+  T* As = smem;
+  T* Bs = smem + BM * LDS_LD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile = blockIdx.x;
+  const int tm_idx = tile / P.tiles_n, tn_idx = tile % P.tiles_n;
+  const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+  const int z = blockIdx.y;
+  const int batch = z / P.split_k, split = z % P.split_k;
+  const int kbeg = split * P.k_per_split;
+  const int kend = min(P.K, kbeg + P.k_per_split);
+
+  Operand opa = P.a, opb = P.b;
+  opa.p = (const T*)opa.p + (long)batch * opa.bstride;
+  opb.p = (const T*)opb.p + (long)batch * opb.bstride;
+
+  TileLoader<T, AMODE, BM, BK, NT> la;
+  TileLoader<T, BMODE, BN, BK, NT> lb;
+  la.init(opa, tid, m0, P.M, kbeg);
+  lb.init(opb, tid, n0, P.N, kbeg);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    la.load(opa, tid, m0, P.M, kbeg, kend);
+    lb.load(opb, tid, n0, P.N, kbeg, kend);
+    la.store(As, tid);
+    lb.store(Bs, tid);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      la.advance(opa); lb.advance(opb);
+      la.load(opa, tid, m0, P.M, kbeg + (kt + 1) * BK, kend);
+      lb.load(opb, tid, n0, P.N, kbeg + (kt + 1) * BK, kend);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / Mma<T>::K; kk++) {
+      typename Mma<T>::Frag fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) fa[i] = Mma<T>::load(As, LDS_LD, (wm * TM + i) * 32 + (lane & 31), kk, lane);
+#pragma unroll
+      for (int j = 0; j < TN; j++) fb[j] = Mma<T>::load(Bs, LDS_LD, (wn * TN + j) * 32 + (lane & 31), kk, lane);
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+    }
+    __syncthreads();
+    if (more) {
+      la.store(As, tid);
+      lb.store(Bs, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5) of each 32x32 tile ----
+  TC* Cb = (TC*)P.C + (long)batch * P.cbs;
+  const TC* Rb = (const TC*)P.residual;
+  if (Rb) Rb += (long)batch * P.cbs;
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+    if (n >= P.N) continue;
+    const float bias = P.bias ? P.bias[n] : 0.f;
+    const float gam = P.gamma ? P.gamma[n] : 1.f;
+    int ps_q = 0, ps_co = n;
+    if (P.store_mode == DU_STORE_PIXEL_SHUFFLE2) { ps_q = n / P.ps_C; ps_co = n - ps_q * P.ps_C; }
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= P.M) continue;
+        float v = acc[i][j][r] * P.alpha;
+        if (P.split_k > 1) { atomic_add_f32((float*)Cb + (long)m * P.ldc + n, v); continue; }
+        v += bias;
+        v = apply_act(v, P.act);
+        v *= gam;
+        long off;
+        if (P.store_mode == DU_STORE_PIXEL_SHUFFLE2) {
+          int x = m % P.ps_W; int t = m / P.ps_W; int y = t % P.ps_H; int b = t / P.ps_H;
+          off = (((long)b * 2 * P.ps_H + 2 * y + (ps_q >> 1)) * (2 * P.ps_W) + 2 * x + (ps_q & 1)) * P.ldc + ps_co;
+        } else {
+          off = (long)m * P.ldc + n;
+        }
+        if (Rb) v += to_f32(Rb[(long)m * P.ldr + n]);
+        Cb[off] = from_f32<TC>(v);
+      }
+    }
+  }
+}
+
+int ilog2_exact(int x) {
+  if (x <= 0 || (x & (x - 1))) return -1;
+  int l = 0; while ((1 << l) < x) l++;
+  return l;
+}
+
+Operand make_operand(const void* p, long ld, long bs, int mode, const du_conv_geom& g) {
+  Operand o{};
+  o.p = p; o.ld = ld; o.bstride = bs;
+  if (mode == DU_IM2COL_ROW || mode == DU_IM2COL_COL) {
+    o.p2 = g.p2; o.ld2 = g.ld2; o.C1 = g.p2 ? g.C1 : g.C;
+    o.Hi = g.Hi; o.Wi = g.Wi; o.C = g.C; o.KH = g.KH; o.KW = g.KW; o.stride = g.stride; o.pad = g.pad;
+    o.Ho = g.Ho; o.Wo = g.Wo; o.transposed = g.transposed; o.logC = ilog2_exact(g.C);
+  }
+  return o;
+}
+
+template <typename T, typename TC, int AMODE, int BMODE, int WM, int WN, int TM, int TN>
+int launch_cfg(const du_gemm_args& a, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = TileK<T>::BK;
+  GemmParams P{};
+  P.a = make_operand(a.A, a.lda, a.a_batch_stride, AMODE, a.geom);
+  P.b = make_operand(a.B, a.ldb, a.b_batch_stride, BMODE, a.geom);
+  P.C = a.C; P.ldc = a.ldc; P.cbs = a.c_batch_stride;
+  P.M = a.M; P.N = a.N; P.K = a.K;
+  P.split_k = a.split_k < 1 ? 1 : a.split_k;
+  int kps = (a.K + P.split_k - 1) / P.split_k;
+  kps = ((kps + BK - 1) / BK) * BK;
+  P.k_per_split = kps;
+  P.split_k = (a.K + kps - 1) / kps;  // drop empty splits
+  if (a.split_k > 1 && P.split_k == 1) P.split_k = 1;
+  P.alpha = a.alpha; P.bias = a.bias; P.act = a.act; P.gamma = a.gamma; P.residual = a.residual; P.ldr = a.ldr;
+  P.store_mode = a.store_mode; P.ps_H = a.ps_H; P.ps_W = a.ps_W; P.ps_C = a.ps_C;
+  int tiles_m = (a.M + BM - 1) / BM;
+  P.tiles_n = (a.N + BN - 1) / BN;
+  // when the caller asked for split-K but it collapsed to one split the epilogue must still accumulate
+  // (C was zero-filled, no epilogue ops) -- plain store of alpha*acc is equivalent.
+  dim3 grid(tiles_m * P.tiles_n, (a.batch < 1 ? 1 : a.batch) * P.split_k);
+  hipLaunchKernelGGL((gemm_kernel<T, TC, AMODE, BMODE, WM, WN, TM, TN>), grid, dim3(256), 0, st, P);
+  return du_check_launch();
+}
+
+template <typename T, typename TC, int AMODE, int BMODE>
+int launch_modes(const du_gemm_args& a, hipStream_t st) {
+  if (a.N <= 32) return launch_cfg<T, TC, AMODE, BMODE, 4, 1, 2, 1>(a, st);   // 256 x 32
+  if (a.N <= 64) return launch_cfg<T, TC, AMODE, BMODE, 2, 2, 2, 1>(a, st);   // 128 x 64
+  return launch_cfg<T, TC, AMODE, BMODE, 2, 2, 2, 2>(a, st);                   // 128 x 128
+}
+
+template <typename T, typename TC>
+int launch_dtype(const du_gemm_args& a, hipStream_t st) {
+  const int am = a.a_mode, bm = a.b_mode;
+  if (am == DU_PLAIN_ROW && bm == DU_PLAIN_ROW) return launch_modes<T, TC, DU_PLAIN_ROW, DU_PLAIN_ROW>(a, st);
+  if (am == DU_PLAIN_ROW && bm == DU_PLAIN_COL) return launch_modes<T, TC, DU_PLAIN_ROW, DU_PLAIN_COL>(a, st);
+  if (am == DU_PLAIN_COL && bm == DU_PLAIN_COL) return launch_modes<T, TC, DU_PLAIN_COL, DU_PLAIN_COL>(a, st);
+  if (am == DU_IM2COL_ROW && bm == DU_PLAIN_ROW) return launch_modes<T, TC, DU_IM2COL_ROW, DU_PLAIN_ROW>(a, st);
+  if (am == DU_PLAIN_COL && bm == DU_IM2COL_COL) return launch_modes<T, TC, DU_PLAIN_COL, DU_IM2COL_COL>(a, st);
+  return DU_ERR_UNSUPPORTED;
+}
+
+bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
+  if (!pa) return DU_ERR_BAD_ARG;
+  const du_gemm_args& a = *pa;
+  hipStream_t st = (hipStream_t)stream;
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return DU_ERR_BAD_ARG;
+  if (!a.A || !a.B || !a.C) return DU_ERR_BAD_ARG;
+  const int vec = a.dtype == DU_BF16 ? 8 : 4;
+  if (a.dtype != DU_BF16 && a.dtype != DU_F32) return DU_ERR_BAD_ARG;
+  if (a.out_dtype != DU_BF16 && a.out_dtype != DU_F32) return DU_ERR_BAD_ARG;
+  // 16-byte vector access requirements
+  if (!aligned16(a.A) || !aligned16(a.B)) return DU_ERR_BAD_ARG;
+  auto chk = [&](int mode, long ld, int outer, long bs) {
+    if (ld % vec || bs % vec) return false;
+    if (mode == DU_PLAIN_ROW) return a.K % vec == 0;
+    if (mode == DU_PLAIN_COL) return outer % vec == 0;
+    return true;
+  };
+  if (!chk(a.a_mode, a.lda, a.M, a.a_batch_stride) || !chk(a.b_mode, a.ldb, a.N, a.b_batch_stride)) return DU_ERR_BAD_ARG;
+  const bool a_i2c = (a.a_mode == DU_IM2COL_ROW), b_i2c = (a.b_mode == DU_IM2COL_COL);
+  if (a_i2c || b_i2c) {
+    const du_conv_geom& g = a.geom;
+    if (g.C % vec || g.KH <= 0 || g.KW <= 0 || g.stride <= 0) return DU_ERR_BAD_ARG;
+    if (g.p2 && (g.C1 % vec || g.ld2 % vec || !aligned16(g.p2))) return DU_ERR_BAD_ARG;
+    if (a_i2c && a.K != g.KH * g.KW * g.C) return DU_ERR_BAD_ARG;
+    if (b_i2c && a.N != g.KH * g.KW * g.C) return DU_ERR_BAD_ARG;
+  }
+  if (a.split_k > 1 && (a.out_dtype != DU_F32 || a.bias || a.act || a.gamma || a.residual || a.store_mode)) return DU_ERR_BAD_ARG;
+  if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && (a.ps_C <= 0 || a.N != 4 * a.ps_C || a.M % (a.ps_H * a.ps_W))) return DU_ERR_BAD_ARG;
+  if (a.dtype == DU_BF16) {
+    if (a.out_dtype == DU_BF16) return launch_dtype<bf16_t, bf16_t>(a, st);
+    return launch_dtype<bf16_t, float>(a, st);
+  }
+  if (a.out_dtype == DU_F32) return launch_dtype<float, float>(a, st);
+  return DU_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,378 @@
+// LayerNorm (token rows) and channel-statistics norms (InstanceNorm2d / BatchNorm2d on NHWC) for gfx950.
+// All are HBM-bound: 16-byte vector loads, fp32 statistics, wave64 shuffle reductions, one pass per tensor.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// LayerNorm forward: one wave per row, the row lives in registers (MAXV 16-byte vectors per lane).
+// ------------------------------------------------------------------------------------------------------
+template <typename TI, typename TO, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                            const float* __restrict__ b, TO* __restrict__ y, long ldy,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            long rows, int D, float eps) {
+  constexpr int VI = Elem<TI>::VEC;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = D / VI;
+  float v[MAXV][VI];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; i++) {
+    int vi = lane + i * 64;
+    if (vi < nvec) {
+      Vec16<TI> t = as_vec<TI>(*(const uint4*)(x + row * ldx + (long)vi * VI));
+#pragma unroll
+      for (int j = 0; j < VI; j++) { v[i][j] = to_f32(t.v[j]); s += v[i][j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VI; j++) v[i][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; i++) {
+    int vi = lane + i * 64;
+    if (vi < nvec) {
+#pragma unroll
+      for (int j = 0; j < VI; j++) { float d = v[i][j] - mean; s2 += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(s2) / (float)D + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; i++) {
+    int vi = lane + i * 64;
+    if (vi < nvec) {
+      const int c0 = vi * VI;
+#pragma unroll
+      for (int j = 0; j < VI; j++) y[row * ldy + c0 + j] = from_f32<TO>((v[i][j] - mean) * rstd * w[c0 + j] + b[c0 + j]);
+    }
+  }
+}
+
+// LayerNorm backward: each wave walks a strip of rows; lanes own fixed columns so dw/db partials stay in
+// registers until one atomic flush per block-strip.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            const float* __restrict__ w, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, T* __restrict__ dx,
+                                                            float* __restrict__ dw, float* __restrict__ db, long rows,
+                                                            int D, int rows_per_wave) {
+  constexpr int VI = Elem<T>::VEC;
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long r0 = wave_id * rows_per_wave;
+  const int nvec = D / VI;
+  float aw[MAXV][VI], ab[MAXV][VI], wv[MAXV][VI];
+#pragma unroll
+  for (int i = 0; i < MAXV; i++)
+#pragma unroll
+    for (int j = 0; j < VI; j++) {
+      aw[i][j] = 0.f; ab[i][j] = 0.f;
+      int vi = lane + i * 64;
+      wv[i][j] = vi < nvec ? w[vi * VI + j] : 0.f;
+    }
+  for (long row = r0; row < r0 + rows_per_wave && row < rows; row++) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[MAXV][VI], g[MAXV][VI];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+      int vi = lane + i * 64;
+      if (vi < nvec) {
+        Vec16<T> tx = as_vec<T>(*(const uint4*)(x + row * (long)D + (long)vi * VI));
+        Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + row * (long)D + (long)vi * VI));
+#pragma unroll
+        for (int j = 0; j < VI; j++) {
+          xh[i][j] = (to_f32(tx.v[j]) - mu) * rs;
+          float gy = to_f32(tg.v[j]);
+          aw[i][j] += gy * xh[i][j];
+          ab[i][j] += gy;
+          g[i][j] = gy * wv[i][j];
+          c1 += g[i][j];
+          c2 += g[i][j] * xh[i][j];
+        }
+      }
+    }
+    c1 = wave_sum(c1) / (float)D;
+    c2 = wave_sum(c2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+      int vi = lane + i * 64;
+      if (vi < nvec) {
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < VI; j++) o.v[j] = from_f32<T>(rs * (g[i][j] - c1 - xh[i][j] * c2));
+        *(uint4*)(dx + row * (long)D + (long)vi * VI) = as_u4(o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; i++) {
+    int vi = lane + i * 64;
+    if (vi < nvec) {
+#pragma unroll
+      for (int j = 0; j < VI; j++) {
+        atomic_add_f32(dw + vi * VI + j, aw[i][j]);
+        atomic_add_f32(db + vi * VI + j, ab[i][j]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Channel statistics over NHWC: thread = (pixel lane, channel vector); block = one strip of one group.
+// ------------------------------------------------------------------------------------------------------
+constexpr int STRIP = 2048;  // pixels per block
+
+template <typename T, int KIND>
+struct StatOp;
+
+// generic strip reducer: F(xvec, dyvec, g, c0) -> (a[VEC], b[VEC]) accumulated per channel, then written with atomics
+template <typename T, typename F>
+__device__ __forceinline__ void strip_reduce(int G, long P, int C, float* out /*[G][C][2]*/, F f) {
+  constexpr int V = Elem<T>::VEC;
+  __shared__ float red[2][256 * V];
+  const int cv_total = C / V;
+  const long strips = (P + STRIP - 1) / STRIP;
+  const int g = blockIdx.x / strips;
+  const long p0 = (long)(blockIdx.x % strips) * STRIP;
+  const long p1 = min(P, p0 + STRIP);
+  const int cvb = min(cv_total, 256);        // channel vectors handled per pass
+  const int tp = threadIdx.x / cvb;          // pixel lane
+  const int tcv = threadIdx.x % cvb;
+  const int np = 256 / cvb;                  // pixel lanes
+  for (int cv0 = 0; cv0 < cv_total; cv0 += cvb) {
+    const int cv = cv0 + tcv;
+    float a[V], b[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) { a[j] = 0.f; b[j] = 0.f; }
+    if (cv < cv_total && tp < np) {
+      for (long p = p0 + tp; p < p1; p += np) f((long)g * P + p, g, cv * V, a, b);
+    }
+#pragma unroll
+    for (int j = 0; j < V; j++) { red[0][threadIdx.x * V + j] = a[j]; red[1][threadIdx.x * V + j] = b[j]; }
+    __syncthreads();
+    if (tp == 0 && cv < cv_total) {
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        float sa = 0.f, sb = 0.f;
+        for (int q = 0; q < np; q++) { sa += red[0][(q * cvb + tcv) * V + j]; sb += red[1][(q * cvb + tcv) * V + j]; }
+        atomic_add_f32(out + ((long)g * C + cv * V + j) * 2 + 0, sa);
+        atomic_add_f32(out + ((long)g * C + cv * V + j) * 2 + 1, sb);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ x, long ldx, float* __restrict__ sums, int G,
+                                                         long P, int C) {
+  constexpr int V = Elem<T>::VEC;
+  strip_reduce<T>(G, P, C, sums, [&](long pix, int g, int c0, float* a, float* b) {
+    Vec16<T> t = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
+#pragma unroll
+    for (int j = 0; j < V; j++) { float v = to_f32(t.v[j]); a[j] += v; b[j] += v * v; }
+  });
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ w, const float* __restrict__ b, long P,
+                                                           int C, int act, long total_vec) {
+  constexpr int V = Elem<T>::VEC;
+  const int cvn = C / V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (long)gridDim.x * 256) {
+    const long pix = i / cvn;
+    const int c0 = (int)(i % cvn) * V;
+    const int g = (int)(pix / P);
+    Vec16<T> t = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      const int c = c0 + j;
+      float z = (to_f32(t.v[j]) - mean[(long)g * C + c]) * rstd[(long)g * C + c] * w[c] + b[c];
+      o.v[j] = from_f32<T>(apply_act(z, act));
+    }
+    *(uint4*)(y + pix * ldy + c0) = as_u4(o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_act_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
+                                                                 long lddy, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, float* __restrict__ bsums, int G,
+                                                                 long P, int C, int act) {
+  constexpr int V = Elem<T>::VEC;
+  strip_reduce<T>(G, P, C, bsums, [&](long pix, int g, int c0, float* a, float* bb) {
+    Vec16<T> tx = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
+    Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + pix * lddy + c0));
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      const int c = c0 + j;
+      float xh = (to_f32(tx.v[j]) - mean[(long)g * C + c]) * rstd[(long)g * C + c];
+      float z = xh * w[c] + b[c];
+      float dz = to_f32(tg.v[j]) * act_grad(z, act);
+      a[j] += dz;
+      bb[j] += dz * xh;
+    }
+  });
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_act_bwd_dx_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
+                                                              long lddy, T* __restrict__ dx, long lddx,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ w, const float* __restrict__ b,
+                                                              const float* __restrict__ bsums, long P, int C, int act,
+                                                              float inv_count, int use_batch_stats, long total_vec) {
+  constexpr int V = Elem<T>::VEC;
+  const int cvn = C / V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (long)gridDim.x * 256) {
+    const long pix = i / cvn;
+    const int c0 = (int)(i % cvn) * V;
+    const int g = (int)(pix / P);
+    Vec16<T> tx = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
+    Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + pix * lddy + c0));
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      const int c = c0 + j;
+      const float rs = rstd[(long)g * C + c];
+      float xh = (to_f32(tx.v[j]) - mean[(long)g * C + c]) * rs;
+      float z = xh * w[c] + b[c];
+      float dz = to_f32(tg.v[j]) * act_grad(z, act);
+      float r;
+      if (use_batch_stats) {
+        float s1 = bsums[((long)g * C + c) * 2 + 0], s2 = bsums[((long)g * C + c) * 2 + 1];
+        r = w[c] * rs * (dz - s1 * inv_count - xh * s2 * inv_count);
+      } else {
+        r = w[c] * rs * dz;
+      }
+      o.v[j] = from_f32<T>(r);
+    }
+    *(uint4*)(dx + pix * lddx + c0) = as_u4(o);
+  }
+}
+
+int grid_for(long total) { long g = (total + 255) / 256; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+
+template <typename TI, typename TO>
+int ln_fwd_dispatch(const void* x, long ldx, const float* w, const float* b, void* y, long ldy, float* m, float* r, long rows,
+                    int D, float eps, hipStream_t st) {
+  const int nvec = D / Elem<TI>::VEC;
+  const int maxv = (nvec + 63) / 64;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define LN_LAUNCH(MV) hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO, MV>), grid, block, 0, st, (const TI*)x, ldx, w, b, (TO*)y, ldy, m, r, rows, D, eps)
+  if (maxv <= 1) LN_LAUNCH(1); else if (maxv <= 2) LN_LAUNCH(2); else if (maxv <= 4) LN_LAUNCH(4);
+  else if (maxv <= 8) LN_LAUNCH(8); else if (maxv <= 16) LN_LAUNCH(16); else return DU_ERR_UNSUPPORTED;
+#undef LN_LAUNCH
+  return du_check_launch();
+}
+
+template <typename T>
+int ln_bwd_dispatch(const void* x, const void* dy, const float* w, const float* mean, const float* rstd, void* dx, float* dw,
+                    float* db, long rows, int D, hipStream_t st) {
+  const int nvec = D / Elem<T>::VEC;
+  const int maxv = (nvec + 63) / 64;
+  long waves = 2048;  // 512 blocks
+  int rpw = (int)((rows + waves - 1) / waves);
+  if (rpw < 1) rpw = 1;
+  long nwaves = (rows + rpw - 1) / rpw;
+  dim3 grid((unsigned)((nwaves + 3) / 4)), block(256);
+#define LNB_LAUNCH(MV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV>), grid, block, 0, st, (const T*)x, (const T*)dy, w, mean, rstd, (T*)dx, dw, db, rows, D, rpw)
+  if (maxv <= 1) LNB_LAUNCH(1); else if (maxv <= 2) LNB_LAUNCH(2); else if (maxv <= 4) LNB_LAUNCH(4);
+  else if (maxv <= 8) LNB_LAUNCH(8); else return DU_ERR_UNSUPPORTED;
+#undef LNB_LAUNCH
+  return du_check_launch();
+}
+
+}  // namespace
+
+extern "C" int du_layernorm_fwd(int in_dtype, int out_dtype, const void* x, int64_t ldx, const float* w, const float* b, void* y,
+                                int64_t ldy, float* mean_out, float* rstd_out, int64_t rows, int D, float eps, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (rows <= 0 || D <= 0 || !x || !y || !w || !b) return DU_ERR_BAD_ARG;
+  const int vi = in_dtype == DU_BF16 ? 8 : 4;
+  if (D % vi || ldx % vi) return DU_ERR_BAD_ARG;
+  if (in_dtype == DU_F32 && out_dtype == DU_F32) return ln_fwd_dispatch<float, float>(x, ldx, w, b, y, ldy, mean_out, rstd_out, rows, D, eps, st);
+  if (in_dtype == DU_F32 && out_dtype == DU_BF16) return ln_fwd_dispatch<float, bf16_t>(x, ldx, w, b, y, ldy, mean_out, rstd_out, rows, D, eps, st);
+  if (in_dtype == DU_BF16 && out_dtype == DU_BF16) return ln_fwd_dispatch<bf16_t, bf16_t>(x, ldx, w, b, y, ldy, mean_out, rstd_out, rows, D, eps, st);
+  if (in_dtype == DU_BF16 && out_dtype == DU_F32) return ln_fwd_dispatch<bf16_t, float>(x, ldx, w, b, y, ldy, mean_out, rstd_out, rows, D, eps, st);
+  return DU_ERR_BAD_ARG;
+}
+
+extern "C" int du_layernorm_bwd(int dtype, const void* x, const void* dy, const float* w, const float* mean, const float* rstd,
+                                void* dx, float* dw, float* db, int64_t rows, int D, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (rows <= 0 || D <= 0 || !x || !dy || !dx || !dw || !db) return DU_ERR_BAD_ARG;
+  const int vi = dtype == DU_BF16 ? 8 : 4;
+  if (D % vi) return DU_ERR_BAD_ARG;
+  if (dtype == DU_F32) return ln_bwd_dispatch<float>(x, dy, w, mean, rstd, dx, dw, db, rows, D, st);
+  if (dtype == DU_BF16) return ln_bwd_dispatch<bf16_t>(x, dy, w, mean, rstd, dx, dw, db, rows, D, st);
+  return DU_ERR_BAD_ARG;
+}
+
+extern "C" int du_chan_stats(int dtype, const void* x, int64_t ldx, float* sums, int G, int64_t P, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (G <= 0 || P <= 0 || C <= 0 || C % v || ldx % v || !x || !sums) return DU_ERR_BAD_ARG;
+  long strips = (P + STRIP - 1) / STRIP;
+  dim3 grid((unsigned)(G * strips)), block(256);
+  if (dtype == DU_BF16) hipLaunchKernelGGL(chan_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, sums, G, P, C);
+  else if (dtype == DU_F32) hipLaunchKernelGGL(chan_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, sums, G, P, C);
+  else return DU_ERR_BAD_ARG;
+  return du_check_launch();
+}
+
+extern "C" int du_norm_act_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* mean, const float* rstd,
+                               const float* w, const float* b, int G, int64_t P, int C, int act, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (G <= 0 || P <= 0 || C % v || ldx % v || ldy % v) return DU_ERR_BAD_ARG;
+  long total = (long)G * P * (C / v);
+  dim3 grid(grid_for(total)), block(256);
+  if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, mean, rstd, w, b, P, C, act, total);
+  else if (dtype == DU_F32) hipLaunchKernelGGL(norm_act_fwd_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (float*)y, ldy, mean, rstd, w, b, P, C, act, total);
+  else return DU_ERR_BAD_ARG;
+  return du_check_launch();
+}
+
+extern "C" int du_norm_act_bwd_stats(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* mean,
+                                     const float* rstd, const float* w, const float* b, float* bsums, int G, int64_t P, int C,
+                                     int act, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (G <= 0 || P <= 0 || C % v || ldx % v || lddy % v) return DU_ERR_BAD_ARG;
+  long strips = (P + STRIP - 1) / STRIP;
+  dim3 grid((unsigned)(G * strips)), block(256);
+  if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_bwd_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act);
+  else if (dtype == DU_F32) hipLaunchKernelGGL(norm_act_bwd_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act);
+  else return DU_ERR_BAD_ARG;
+  return du_check_launch();
+}
+
+extern "C" int du_norm_act_bwd_dx(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx,
+                                  const float* mean, const float* rstd, const float* w, const float* b, const float* bsums, int G,
+                                  int64_t P, int C, int act, float count, int use_batch_stats, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (G <= 0 || P <= 0 || C % v || ldx % v || lddy % v || lddx % v) return DU_ERR_BAD_ARG;
+  long total = (long)G * P * (C / v);
+  dim3 grid(grid_for(total)), block(256);
+  const float inv = count > 0 ? 1.0f / count : 0.f;
+  if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_bwd_dx_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, mean, rstd, w, b, bsums, P, C, act, inv, use_batch_stats, total);
+  else if (dtype == DU_F32) hipLaunchKernelGGL(norm_act_bwd_dx_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, (float*)dx, lddx, mean, rstd, w, b, bsums, P, C, act, inv, use_batch_stats, total);
+  else return DU_ERR_BAD_ARG;
+  return du_check_launch();
+}

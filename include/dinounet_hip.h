@@ -1,0 +1,181 @@
+/*
+ * dinounet_hip.h -- C ABI of libdinounet_hip.so: the MI355X (gfx950) kernels behind the Dino U-Net
+ * forward/backward hot path.  Plain pointers and sizes only (no torch types); every entry point
+ * enqueues on the caller's HIP stream, does not synchronise, keeps no global state and returns 0 on
+ * success or a negative DU_ERR_* code (the Python host turns that into RuntimeError, mirroring the
+ * AT_ASSERTM behaviour of the reference extension, ops/src/cuda/ms_deform_attn_cuda.cu:33-57).
+ *
+ * All pointers are DEVICE pointers unless stated otherwise.  Conv-side tensors are NHWC ("pixel-major",
+ * channel-contiguous); token tensors are (B, N, D) row-major -- the same memory as NHWC.  `ld*` are row
+ * (pixel) strides in ELEMENTS, so a channel slice of a wider NHWC tensor can be read/written in place.
+ *
+ * Reference interfaces replaced (paths relative to the reference root):
+ *   du_msda_forward / du_msda_backward
+ *       <- ms_deform_attn_forward / ms_deform_attn_backward, the two pybind names of the extension
+ *          `MultiScaleDeformableAttention` (ops/src/vision.cpp:18-21, ops/src/ms_deform_attn.h:25-66,
+ *          kernels ops/src/cuda/ms_deform_im2col_cuda.cuh:242-304 and :961-1332)
+ *   du_gemm (linear / 1x1 conv / implicit 3x3 conv / transposed conv, fwd + dgrad + wgrad)
+ *       <- torch F.linear / F.conv2d / F.conv_transpose2d call sites: layers/attention.py:88-90,
+ *          layers/ffn_layers.py:43-49, layers/patch_embed.py:70, ms_deform_attn.py:183-215,
+ *          dinov3_adapter.py:85-89,239-277,360,467, dinounet_training.py:423-438,253,613-619
+ *   du_attention_fwd, du_qkv_rope_split
+ *       <- SelfAttention.compute_attention / apply_rope (layers/attention.py:66-85,106-118)
+ *   du_layernorm_fwd / _bwd      <- nn.LayerNorm (layers/block.py:43,56; dinov3_adapter.py:128-137)
+ *   du_chan_stats / du_norm_act_* <- InstanceNorm2d+LeakyReLU (dinounet_training.py:401,238; decoder
+ *          StackedConvBlocks :581-592) and SyncBatchNorm(+ReLU) (dinov3_adapter.py:242-270,361-364)
+ *   du_dwconv3x3_*               <- DWConv (dinov3_adapter.py:94-109), DepthwiseSeparableConv.depthwise
+ *          (dinounet_training.py:235)
+ *   du_maxpool3x3s2_*            <- nn.MaxPool2d(3,2,1) (dinov3_adapter.py:250)
+ *   du_bilinear_add_*            <- F.interpolate(bilinear, align_corners=False)+add (dinov3_adapter.py:472-476)
+ *   du_softmax_lastdim4 / du_msda_locations <- ms_deform_attn.py:188-197
+ */
+#ifndef DINOUNET_HIP_H
+#define DINOUNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DU_OK 0
+#define DU_ERR_BAD_ARG (-1)
+#define DU_ERR_UNSUPPORTED (-2)
+#define DU_ERR_LAUNCH (-3)
+
+/* element types */
+#define DU_F32 0
+#define DU_BF16 1
+
+/* du_gemm operand addressing modes.  The logical product is C[m][n] = sum_k A(m,k) * B(n,k). */
+#define DU_PLAIN_ROW 0   /* element (outer o, contraction k) at p[o*ld + k]          (k contiguous) */
+#define DU_PLAIN_COL 1   /* element (outer o, contraction k) at p[k*ld + o]          (o contiguous) */
+#define DU_IM2COL_ROW 2  /* outer = output pixel, contraction = (tap, channel) gathered from an NHWC tensor */
+#define DU_IM2COL_COL 3  /* outer = (tap, channel), contraction = pixel (used by conv weight gradients) */
+
+/* du_gemm epilogue activations */
+#define DU_ACT_NONE 0
+#define DU_ACT_GELU 1    /* exact erf GELU (nn.GELU default) */
+#define DU_ACT_RELU 2
+#define DU_ACT_LEAKY 3   /* LeakyReLU(0.01) */
+
+/* du_gemm store modes */
+#define DU_STORE_PLAIN 0
+#define DU_STORE_PIXEL_SHUFFLE2 1 /* ConvTranspose2d k2 s2: column n=(dy*2+dx)*Cout+co of input pixel (b,y,x)
+                                     goes to output pixel (b,2y+dy,2x+dx), channel co */
+
+typedef struct {
+  /* source NHWC tensor(s): channels [0,C1) come from p (pixel stride ld), channels [C1,C) from p2 (ld2).
+     This is how the decoder's torch.cat (dinounet_training.py:614) is consumed without materialising it. */
+  const void* p2;
+  int64_t ld2;
+  int32_t C1;
+  int32_t Hi, Wi;      /* source spatial size */
+  int32_t C;           /* total gathered channels (C1 + C2) */
+  int32_t KH, KW, stride, pad;
+  int32_t Ho, Wo;      /* grid the "pixel" index runs over */
+  int32_t transposed;  /* 0: yi = yo*stride - pad + dy.  1: yi = (yo + pad - dy)/stride when divisible (dgrad) */
+} du_conv_geom;
+
+typedef struct {
+  int32_t dtype;      /* DU_F32 / DU_BF16: element type of A and B */
+  int32_t out_dtype;  /* element type of C and residual */
+  int32_t a_mode, b_mode;
+  int32_t M, N, K;
+  const void* A; int64_t lda; int64_t a_batch_stride;
+  const void* B; int64_t ldb; int64_t b_batch_stride;
+  void* C; int64_t ldc; int64_t c_batch_stride;
+  int32_t batch;      /* >= 1 */
+  int32_t split_k;    /* >= 1; > 1 requires out_dtype F32, a zero-initialised C and no epilogue ops */
+  float alpha;
+  const float* bias;  /* [N] fp32 or NULL */
+  int32_t act;
+  const float* gamma; /* [N] fp32 or NULL: per-column scale applied after act (LayerScale) */
+  const void* residual; int64_t ldr; /* added last, NULL for none; may alias C */
+  int32_t store_mode;
+  int32_t ps_H, ps_W, ps_C; /* pixel-shuffle geometry: input grid H x W, Cout */
+  du_conv_geom geom;  /* used by the IM2COL operand (at most one operand is IM2COL) */
+} du_gemm_args;
+
+int du_gemm(const du_gemm_args* args, void* stream);
+
+/* ---- ViT attention -------------------------------------------------------------------------- */
+/* qkv: (B, N, 3, H, Dh) as produced by the fused QKV GEMM.  Writes q (pre-scaled by `qscale`), k, v as
+   (B, H, N, Dh) contiguous; RoPE (rotate-half form, fp32 math) is applied to q and k for tokens >= prefix
+   using sin/cos tables (N - prefix, Dh) fp32. */
+int du_qkv_rope_split(int dtype, const void* qkv, void* q, void* k, void* v, const float* sin_t, const float* cos_t,
+                      int B, int N, int H, int Dh, int prefix, float qscale, void* stream);
+/* Non-causal softmax(q k^T) v per (b, head); q is expected pre-scaled (scores are used as-is).
+   q,k,v: (B, H, N, Dh) bf16; out: (B, N, H*Dh) bf16.  Dh in {64, 128}. */
+int du_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int N, int Dh, void* stream);
+/* row softmax over the last dim of a (rows, cols) fp32 matrix, in place (parity-mode attention). */
+int du_softmax_rows_f32(float* x, int64_t rows, int cols, int64_t ld, void* stream);
+
+/* ---- LayerNorm -------------------------------------------------------------------------------- */
+int du_layernorm_fwd(int in_dtype, int out_dtype, const void* x, int64_t ldx, const float* w, const float* b, void* y,
+                     int64_t ldy, float* mean_out, float* rstd_out, int64_t rows, int D, float eps, void* stream);
+/* dx (same dtype as x); dw/db accumulate with atomics into fp32 buffers the caller zero-fills. */
+int du_layernorm_bwd(int dtype, const void* x, const void* dy, const float* w, const float* mean, const float* rstd,
+                     void* dx, float* dw, float* db, int64_t rows, int D, void* stream);
+
+/* ---- channel-statistics norms (InstanceNorm2d / BatchNorm2d over NHWC) ---------------------------- */
+/* sums[g][c][0..1] += (sum x, sum x^2) over the pixels of group g (G groups of `pix_per_group` pixels). */
+int du_chan_stats(int dtype, const void* x, int64_t ldx, float* sums, int G, int64_t pix_per_group, int C, void* stream);
+/* y = act((x - mean[g,c]) * rstd[g,c] * w[c] + b[c]); mean/rstd: (G, C) fp32. */
+int du_norm_act_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* mean, const float* rstd,
+                    const float* w, const float* b, int G, int64_t pix_per_group, int C, int act, void* stream);
+/* backward pass 1: through the activation, accumulate per-(g,c) sum(dz) and sum(dz*xhat) into bsums (G,C,2). */
+int du_norm_act_bwd_stats(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* mean,
+                          const float* rstd, const float* w, const float* b, float* bsums, int G, int64_t pix_per_group,
+                          int C, int act, void* stream);
+/* backward pass 2: dx = w*rstd*(dz - s1/n - xhat*s2/n) with (s1,s2) from bsums and n = `count` (pixels the
+   statistics were taken over: pix_per_group for IN, all pixels x world for BN).  use_batch_stats=0 => dx = dz*w*rstd */
+int du_norm_act_bwd_dx(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx,
+                       const float* mean, const float* rstd, const float* w, const float* b, const float* bsums, int G,
+                       int64_t pix_per_group, int C, int act, float count, int use_batch_stats, void* stream);
+
+/* ---- multi-scale deformable attention ---------------------------------------------------------------- */
+/* value (N, S, M, D); spatial_shapes (L,2) int64 (H,W); level_start_index (L) int64; sampling_loc (N,Lq,M,L,P,2)
+   as (x,y) in [0,1]; attn_weight (N,Lq,M,L,P); out (N,Lq,M*D).  value/out dtype = `dtype`; loc/weights fp32 when
+   dtype is BF16, same as value when F32.  Semantics: ms_deform_im2col_cuda.cuh:242-304. */
+int du_msda_forward(int dtype, const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                    const float* sampling_loc, const float* attn_weight, void* out, int N, int S, int M, int D, int L,
+                    int Lq, int P, void* stream);
+/* grad_value (fp32, N,S,M,D), grad_sampling_loc, grad_attn_weight (fp32): zero-filled by the caller
+   (the reference allocates them with at::zeros, ms_deform_attn_cuda.cu:126-128). */
+int du_msda_backward(int dtype, const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                     const float* sampling_loc, const float* attn_weight, const void* grad_out, float* grad_value,
+                     float* grad_sampling_loc, float* grad_attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
+                     void* stream);
+
+/* ---- small conv-side ops (NHWC) ------------------------------------------------------------------- */
+int du_dwconv3x3_fwd(int dtype, const void* x, int64_t ldx, const float* w /*(C,3,3)*/, const float* bias, void* y,
+                     int64_t ldy, int B, int H, int W, int C, void* stream);
+int du_dwconv3x3_bwd_data(int dtype, const void* dy, int64_t lddy, const float* w, void* dx, int64_t lddx, int B, int H,
+                          int W, int C, void* stream);
+int du_dwconv3x3_bwd_weight(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, float* dw /*(C,9)*/,
+                            float* db, int B, int H, int W, int C, void* stream);
+int du_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream);
+int du_maxpool3x3s2_bwd(int dtype, const void* x, const void* y, const void* dy, void* dx /* zero-filled fp32? no: same dtype */,
+                        int B, int H, int W, int C, void* stream);
+/* out[b,y,x,:] = base[b,y,x,:] + bilinear(src)[b,y,x,:]  (align_corners=False), src (B,Hs,Ws,C), out/base (B,Ho,Wo,C) */
+int du_bilinear_add_fwd(int dtype, const void* src, const void* base, void* out, int B, int Hs, int Ws, int Ho, int Wo,
+                        int C, void* stream);
+
+/* ---- elementwise helpers --------------------------------------------------------------------------- */
+int du_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
+/* NCHW fp32 image -> NHWC `dtype` with channels zero-padded to Cpad */
+int du_nchw_to_nhwc_pad(int dst_dtype, const float* src, void* dst, int B, int C, int H, int W, int Cpad, void* stream);
+/* NHWC `dtype` (pixel stride ld) -> NCHW fp32 */
+int du_nhwc_to_nchw_f32(int src_dtype, const void* src, int64_t ld, float* dst, int B, int C, int H, int W, void* stream);
+/* 16x16/s16 patch gather: NCHW fp32 image -> (B*h*w, C*256) rows ordered (c, dy, dx) like Conv2d weight.flatten(1) */
+int du_patchify16(int dst_dtype, const float* src, void* dst, int B, int C, int H, int W, void* stream);
+
+/* library self-description */
+const char* du_version(void);
+int du_device_ok(void); /* 1 if the current device is gfx950 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
