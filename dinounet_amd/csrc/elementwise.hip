@@ -1,0 +1,539 @@
+// HBM-bound NHWC helpers for gfx950: depthwise 3x3, max-pool 3x3/s2, bilinear upsample+add, layout conversion,
+// MSDeformAttn sampling-location / softmax preparation.  All use 16-byte channel vectors per thread.
+#include "common.h"
+
+namespace {
+
+__host__ int grid_1d(long total) {
+  long g = (total + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 65535L * 8) g = 65535L * 8;
+  return (int)g;
+}
+
+#define GRID_STRIDE(i, total) for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (total); i += (long)gridDim.x * 256)
+
+// ---------------- depthwise 3x3, stride 1, pad 1 (dinov3_adapter.py:94-109, dinounet_training.py:235) ----------------
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x, long ldx, long xbs, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, T* __restrict__ y, long ldy, long ybs,
+                                                         T* __restrict__ z, int B, int H, int W, int C, int act, long total) {
+  constexpr int V = Elem<T>::VEC;
+  const int cvn = C / V;
+  GRID_STRIDE(i, total) {
+    const int c0 = (int)(i % cvn) * V;
+    long t = i / cvn;
+    const int xo = (int)(t % W); t /= W;
+    const int yo = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) acc[j] = bias ? bias[c0 + j] : 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+      const int yi = yo + dy - 1;
+      if (yi < 0 || yi >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; dx++) {
+        const int xi = xo + dx - 1;
+        if (xi < 0 || xi >= W) continue;
+        Vec16<T> v = as_vec<T>(*(const uint4*)(x + (long)b * xbs + ((long)yi * W + xi) * ldx + c0));
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[j] += to_f32(v.v[j]) * w[(c0 + j) * 9 + dy * 3 + dx];
+      }
+    }
+    const long off = (long)b * ybs + ((long)yo * W + xo) * ldy + c0;
+    Vec16<T> o;
+    if (z) {
+#pragma unroll
+      for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(acc[j]);
+      *(uint4*)(z + off) = as_u4(o);
+    }
+#pragma unroll
+    for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(apply_act(acc[j], act));
+    *(uint4*)(y + off) = as_u4(o);
+  }
+}
+
+// dx = correlation of dy with the flipped kernel
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const T* __restrict__ dy, long lddy, long dybs,
+                                                              const float* __restrict__ w, T* __restrict__ dx, long lddx,
+                                                              long dxbs, int B, int H, int W, int C, long total) {
+  constexpr int V = Elem<T>::VEC;
+  const int cvn = C / V;
+  GRID_STRIDE(i, total) {
+    const int c0 = (int)(i % cvn) * V;
+    long t = i / cvn;
+    const int xi = (int)(t % W); t /= W;
+    const int yi = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) acc[j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+      const int yo = yi - ky + 1;
+      if (yo < 0 || yo >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const int xo = xi - kx + 1;
+        if (xo < 0 || xo >= W) continue;
+        Vec16<T> v = as_vec<T>(*(const uint4*)(dy + (long)b * dybs + ((long)yo * W + xo) * lddy + c0));
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[j] += to_f32(v.v[j]) * w[(c0 + j) * 9 + ky * 3 + kx];
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(acc[j]);
+    *(uint4*)(dx + (long)b * dxbs + ((long)yi * W + xi) * lddx + c0) = as_u4(o);
+  }
+}
+
+// dw[c][tap] += sum_pix x[pix+tap][c] * dy[pix][c]; db[c] += sum dy.  Block = strip of pixels, thread = (pixel lane, cvec).
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, long ldx, long xbs,
+                                                                const T* __restrict__ dy, long lddy, long dybs,
+                                                                float* __restrict__ dw, float* __restrict__ db, int B, int H,
+                                                                int W, int C, int strip) {
+  constexpr int V = Elem<T>::VEC;
+  const int cvn = C / V;
+  const int cvb = min(cvn, 256);
+  const int np = 256 / cvb;
+  const int tp = threadIdx.x / cvb, tcv = threadIdx.x % cvb;
+  const long npix = (long)B * H * W;
+  const long p0 = (long)blockIdx.x * strip, p1 = min(npix, p0 + strip);
+  for (int cv0 = 0; cv0 < cvn; cv0 += cvb) {
+    const int cv = cv0 + tcv;
+    if (cv >= cvn || tp >= np) continue;
+    const int c0 = cv * V;
+    float aw[9][V], ab[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      ab[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; k++) aw[k][j] = 0.f;
+    }
+    for (long p = p0 + tp; p < p1; p += np) {
+      const int xo = (int)(p % W); long t = p / W;
+      const int yo = (int)(t % H); const int b = (int)(t / H);
+      Vec16<T> g = as_vec<T>(*(const uint4*)(dy + (long)b * dybs + ((long)yo * W + xo) * lddy + c0));
+      float gf[V];
+#pragma unroll
+      for (int j = 0; j < V; j++) { gf[j] = to_f32(g.v[j]); ab[j] += gf[j]; }
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+        const int yi = yo + ky - 1;
+        if (yi < 0 || yi >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+          const int xi = xo + kx - 1;
+          if (xi < 0 || xi >= W) continue;
+          Vec16<T> v = as_vec<T>(*(const uint4*)(x + (long)b * xbs + ((long)yi * W + xi) * ldx + c0));
+#pragma unroll
+          for (int j = 0; j < V; j++) aw[ky * 3 + kx][j] += to_f32(v.v[j]) * gf[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      if (db) atomic_add_f32(db + c0 + j, ab[j]);
+#pragma unroll
+      for (int k = 0; k < 9; k++) atomic_add_f32(dw + (c0 + j) * 9 + k, aw[k][j]);
+    }
+  }
+}
+
+// ---------------- max-pool 3x3 stride 2 pad 1 (dinov3_adapter.py:250); idx = winning tap (first max in scan order) -----------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
+                                                          int B, int H, int W, int C, int Ho, int Wo, long total) {
+  constexpr int V = Elem<T>::VEC;
+  const int cvn = C / V;
+  GRID_STRIDE(i, total) {
+    const int c0 = (int)(i % cvn) * V;
+    long t = i / cvn;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float best[V]; int bi[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) { best[j] = -INFINITY; bi[j] = 0; }
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+      const int yi = yo * 2 - 1 + dy;
+      if (yi < 0 || yi >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; dx++) {
+        const int xi = xo * 2 - 1 + dx;
+        if (xi < 0 || xi >= W) continue;
+        Vec16<T> v = as_vec<T>(*(const uint4*)(x + (((long)b * H + yi) * W + xi) * C + c0));
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+          float f = to_f32(v.v[j]);
+          if (f > best[j]) { best[j] = f; bi[j] = dy * 3 + dx; }
+        }
+      }
+    }
+    const long off = (((long)b * Ho + yo) * Wo + xo) * C + c0;
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(best[j]);
+    *(uint4*)(y + off) = as_u4(o);
+    if (idx) {
+#pragma unroll
+      for (int j = 0; j < V; j++) idx[off + j] = (uint8_t)bi[j];
+    }
+  }
+}
+
+// gather form: each input pixel sums dy of the (<= 4) windows that selected it
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const T* __restrict__ dy,
+                                                          T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo,
+                                                          long total) {
+  constexpr int V = Elem<T>::VEC;
+  const int cvn = C / V;
+  GRID_STRIDE(i, total) {
+    const int c0 = (int)(i % cvn) * V;
+    long t = i / cvn;
+    const int xi = (int)(t % W); t /= W;
+    const int yi = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) acc[j] = 0.f;
+    // windows yo with yo*2-1+dy == yi, dy in 0..2
+#pragma unroll
+    for (int dy_ = 0; dy_ < 3; dy_++) {
+      const int ty = yi + 1 - dy_;
+      if (ty < 0 || (ty & 1)) continue;
+      const int yo = ty >> 1;
+      if (yo >= Ho) continue;
+#pragma unroll
+      for (int dx_ = 0; dx_ < 3; dx_++) {
+        const int tx = xi + 1 - dx_;
+        if (tx < 0 || (tx & 1)) continue;
+        const int xo = tx >> 1;
+        if (xo >= Wo) continue;
+        const long off = (((long)b * Ho + yo) * Wo + xo) * C + c0;
+        Vec16<T> g = as_vec<T>(*(const uint4*)(dy + off));
+#pragma unroll
+        for (int j = 0; j < V; j++)
+          if (idx[off + j] == dy_ * 3 + dx_) acc[j] += to_f32(g.v[j]);
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(acc[j]);
+    *(uint4*)(dx + (((long)b * H + yi) * W + xi) * C + c0) = as_u4(o);
+  }
+}
+
+// ---------------- bilinear (align_corners=False) upsample + add (dinov3_adapter.py:472-476) ----------------
+template <typename TS, typename T>
+__global__ __launch_bounds__(256) void bilinear_add_kernel(const TS* __restrict__ src, long lds_, const T* __restrict__ base,
+                                                           long ldb, T* __restrict__ out, long ldo, int B, int Hs, int Ws, int Ho,
+                                                           int Wo, int C, long total) {
+  constexpr int V = 4;
+  const int cvn = C / V;
+  const float sh = (float)Hs / (float)Ho, sw = (float)Ws / (float)Wo;
+  GRID_STRIDE(i, total) {
+    const int c0 = (int)(i % cvn) * V;
+    long t = i / cvn;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    // PyTorch area_pixel_compute_source_index: max(0, scale*(dst+0.5)-0.5)
+    float fy = fmaxf(0.f, sh * (yo + 0.5f) - 0.5f), fx = fmaxf(0.f, sw * (xo + 0.5f) - 0.5f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const TS* s00 = src + (((long)b * Hs + y0) * Ws + x0) * lds_ + c0;
+    const TS* s01 = src + (((long)b * Hs + y0) * Ws + x1) * lds_ + c0;
+    const TS* s10 = src + (((long)b * Hs + y1) * Ws + x0) * lds_ + c0;
+    const TS* s11 = src + (((long)b * Hs + y1) * Ws + x1) * lds_ + c0;
+    const long po = ((long)b * Ho + yo) * Wo + xo;
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      float v = hy * (hx * to_f32(s00[j]) + lx * to_f32(s01[j])) + ly * (hx * to_f32(s10[j]) + lx * to_f32(s11[j]));
+      out[po * ldo + c0 + j] = from_f32<T>(to_f32(base[po * ldb + c0 + j]) + v);
+    }
+  }
+}
+
+// ---------------- casts / layout ----------------
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, long n) {
+  GRID_STRIDE(i, n) d[i] = from_f32<TD>(to_f32(s[i]));
+}
+
+template <typename TD>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ s, TD* __restrict__ d, int B, int C, int H,
+                                                               int W, int Cpad, long total) {
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % Cpad);
+    long p = i / Cpad;
+    const long hw = (long)H * W;
+    const int b = (int)(p / hw);
+    const long r = p % hw;
+    d[i] = from_f32<TD>(c < C ? s[((long)b * C + c) * hw + r] : 0.f);
+  }
+}
+
+template <typename TS>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const TS* __restrict__ s, long ld, float* __restrict__ d, int B, int C,
+                                                           int H, int W, long total) {
+  GRID_STRIDE(i, total) {
+    const long hw = (long)H * W;
+    const long r = i % hw;
+    long t = i / hw;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    d[i] = to_f32(s[((long)b * hw + r) * ld + c]);
+  }
+}
+
+// rows = (b, py, px), columns = (c, dy, dx): matches Conv2d(k16,s16).weight.flatten(1) (layers/patch_embed.py:61)
+template <typename TD>
+__global__ __launch_bounds__(256) void patchify16_kernel(const float* __restrict__ s, TD* __restrict__ d, int B, int C, int H,
+                                                         int W, long total) {
+  const int ph = H / 16, pw = W / 16;
+  const int K = C * 256;
+  GRID_STRIDE(i, total) {
+    const int k = (int)(i % K);
+    long r = i / K;
+    const int px = (int)(r % pw); r /= pw;
+    const int py = (int)(r % ph);
+    const int b = (int)(r / ph);
+    const int c = k >> 8, dy = (k >> 4) & 15, dx = k & 15;
+    d[i] = from_f32<TD>(s[(((long)b * C + c) * H + py * 16 + dy) * W + px * 16 + dx]);
+  }
+}
+
+// ---------------- MSDeformAttn: sampling locations + softmax of the attention logits (ms_deform_attn.py:188-197) --------------
+// raw: (rows, M*P*2 + M*P) fp32/bf16 = [offsets | logits]; ref: (Lq, 2) reference points (x, y) shared by the batch;
+// loc (rows, M, P, 2) = ref + off / (W, H); attn (rows, M, P) = softmax over P.   (single level)
+template <typename T>
+__global__ __launch_bounds__(256) void msda_prep_kernel(const T* __restrict__ raw, long ldr, const float* __restrict__ ref,
+                                                        float* __restrict__ loc, float* __restrict__ attn, long rows, int Lq, int M,
+                                                        int P, float invW, float invH, long total) {
+  GRID_STRIDE(i, total) {
+    const int m = (int)(i % M);
+    const long row = i / M;
+    const int q = (int)(row % Lq);
+    const float rx = ref[q * 2], ry = ref[q * 2 + 1];
+    const T* po = raw + row * ldr + (long)m * P * 2;
+    const T* pl = raw + row * ldr + (long)M * P * 2 + (long)m * P;
+    float* lo = loc + (row * M + m) * (long)P * 2;
+    float* ao = attn + (row * M + m) * (long)P;
+    float mx = -1e30f;
+    for (int p = 0; p < P; p++) mx = fmaxf(mx, to_f32(pl[p]));
+    float s = 0.f;
+    for (int p = 0; p < P; p++) s += expf(to_f32(pl[p]) - mx);
+    const float inv = 1.f / s;
+    for (int p = 0; p < P; p++) {
+      lo[p * 2] = rx + to_f32(po[p * 2]) * invW;
+      lo[p * 2 + 1] = ry + to_f32(po[p * 2 + 1]) * invH;
+      ao[p] = expf(to_f32(pl[p]) - mx) * inv;
+    }
+  }
+}
+
+// backward of the above: d_raw[off] = d_loc * (1/W, 1/H); d_raw[logit] = p * (g - sum_p p g)
+template <typename T>
+__global__ __launch_bounds__(256) void msda_prep_bwd_kernel(const float* __restrict__ attn, const float* __restrict__ gloc,
+                                                            const float* __restrict__ gattn, T* __restrict__ graw, long ldr,
+                                                            long rows, int M, int P, float invW, float invH, long total) {
+  GRID_STRIDE(i, total) {
+    const int m = (int)(i % M);
+    const long row = i / M;
+    const float* gl = gloc + (row * M + m) * (long)P * 2;
+    const float* ga = gattn + (row * M + m) * (long)P;
+    const float* pa = attn + (row * M + m) * (long)P;
+    T* go = graw + row * ldr + (long)m * P * 2;
+    T* gg = graw + row * ldr + (long)M * P * 2 + (long)m * P;
+    float dot = 0.f;
+    for (int p = 0; p < P; p++) dot += pa[p] * ga[p];
+    for (int p = 0; p < P; p++) {
+      go[p * 2] = from_f32<T>(gl[p * 2] * invW);
+      go[p * 2 + 1] = from_f32<T>(gl[p * 2 + 1] * invH);
+      gg[p] = from_f32<T>(pa[p] * (ga[p] - dot));
+    }
+  }
+}
+
+// dz = dy * act'(z)
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ dz, long n,
+                                                      int act) {
+  GRID_STRIDE(i, n) dz[i] = from_f32<T>(to_f32(dy[i]) * act_grad(to_f32(z[i]), act));
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
+  if ((dtype) == DU_BF16) { CALL_BF16; } else if ((dtype) == DU_F32) { CALL_F32; } else return DU_ERR_BAD_ARG;
+
+extern "C" int du_dwconv3x3_fwd(int dtype, const void* x, int64_t ldx, int64_t xbs, const float* w, const float* bias, void* y,
+                                int64_t ldy, int64_t ybs, void* z, int B, int H, int W, int C, int act, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C % v || ldx % v || ldy % v || xbs % v || ybs % v) return DU_ERR_BAD_ARG;
+  long total = (long)B * H * W * (C / v);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(dwconv_fwd_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, (const bf16_t*)x, ldx, xbs, w, bias, (bf16_t*)y, ldy, ybs, (bf16_t*)z, B, H, W, C, act, total),
+             hipLaunchKernelGGL(dwconv_fwd_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, (const float*)x, ldx, xbs, w, bias, (float*)y, ldy, ybs, (float*)z, B, H, W, C, act, total));
+  return du_check_launch();
+}
+
+extern "C" int du_dwconv3x3_bwd_data(int dtype, const void* dy, int64_t lddy, int64_t dybs, const float* w, void* dx, int64_t lddx,
+                                     int64_t dxbs, int B, int H, int W, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (!dy || !w || !dx || B <= 0 || C % v || lddy % v || lddx % v || dybs % v || dxbs % v) return DU_ERR_BAD_ARG;
+  long total = (long)B * H * W * (C / v);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(dwconv_bwd_data_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, (const bf16_t*)dy, lddy, dybs, w, (bf16_t*)dx, lddx, dxbs, B, H, W, C, total),
+             hipLaunchKernelGGL(dwconv_bwd_data_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, (const float*)dy, lddy, dybs, w, (float*)dx, lddx, dxbs, B, H, W, C, total));
+  return du_check_launch();
+}
+
+extern "C" int du_dwconv3x3_bwd_weight(int dtype, const void* x, int64_t ldx, int64_t xbs, const void* dy, int64_t lddy, int64_t dybs,
+                                       float* dw, float* db, int B, int H, int W, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (!x || !dy || !dw || B <= 0 || C % v || ldx % v || lddy % v || xbs % v || dybs % v) return DU_ERR_BAD_ARG;
+  const long npix = (long)B * H * W;
+  int strip = 512;
+  long blocks = (npix + strip - 1) / strip;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, xbs, (const bf16_t*)dy, lddy, dybs, dw, db, B, H, W, C, strip),
+             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, ldx, xbs, (const float*)dy, lddy, dybs, dw, db, B, H, W, C, strip));
+  return du_check_launch();
+}
+
+extern "C" int du_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (!x || !y || B <= 0 || C % v) return DU_ERR_BAD_ARG;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  long total = (long)B * Ho * Wo * (C / v);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, idx, B, H, W, C, Ho, Wo, total),
+             hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, (const float*)x, (float*)y, idx, B, H, W, C, Ho, Wo, total));
+  return du_check_launch();
+}
+
+extern "C" int du_maxpool3x3s2_bwd(int dtype, const uint8_t* idx, const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (!idx || !dy || !dx || B <= 0 || C % v) return DU_ERR_BAD_ARG;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  long total = (long)B * H * W * (C / v);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, idx, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C, Ho, Wo, total),
+             hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, idx, (const float*)dy, (float*)dx, B, H, W, C, Ho, Wo, total));
+  return du_check_launch();
+}
+
+extern "C" int du_bilinear_add_fwd(int src_dtype, int dtype, const void* src, int64_t lds_, const void* base, int64_t ldb, void* out,
+                                   int64_t ldo, int B, int Hs, int Ws, int Ho, int Wo, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!src || !base || !out || B <= 0 || C % 4) return DU_ERR_BAD_ARG;
+  long total = (long)B * Ho * Wo * (C / 4);
+  dim3 g(grid_1d(total)), b(256);
+  if (src_dtype == DU_F32 && dtype == DU_F32)
+    hipLaunchKernelGGL((bilinear_add_kernel<float, float>), g, b, 0, st, (const float*)src, lds_, (const float*)base, ldb, (float*)out, ldo, B, Hs, Ws, Ho, Wo, C, total);
+  else if (src_dtype == DU_F32 && dtype == DU_BF16)
+    hipLaunchKernelGGL((bilinear_add_kernel<float, bf16_t>), g, b, 0, st, (const float*)src, lds_, (const bf16_t*)base, ldb, (bf16_t*)out, ldo, B, Hs, Ws, Ho, Wo, C, total);
+  else if (src_dtype == DU_BF16 && dtype == DU_BF16)
+    hipLaunchKernelGGL((bilinear_add_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)src, lds_, (const bf16_t*)base, ldb, (bf16_t*)out, ldo, B, Hs, Ws, Ho, Wo, C, total);
+  else return DU_ERR_BAD_ARG;
+  return du_check_launch();
+}
+
+extern "C" int du_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!src || !dst || n <= 0) return DU_ERR_BAD_ARG;
+  dim3 g(grid_1d(n)), b(256);
+  if (src_dtype == DU_F32 && dst_dtype == DU_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, st, (const float*)src, (bf16_t*)dst, (long)n);
+  else if (src_dtype == DU_BF16 && dst_dtype == DU_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)src, (float*)dst, (long)n);
+  else if (src_dtype == DU_F32 && dst_dtype == DU_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, (long)n);
+  else if (src_dtype == DU_BF16 && dst_dtype == DU_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)src, (bf16_t*)dst, (long)n);
+  else return DU_ERR_BAD_ARG;
+  return du_check_launch();
+}
+
+extern "C" int du_nchw_to_nhwc_pad(int dst_dtype, const float* src, void* dst, int B, int C, int H, int W, int Cpad, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!src || !dst || B <= 0 || Cpad < C) return DU_ERR_BAD_ARG;
+  long total = (long)B * H * W * Cpad;
+  DISPATCH_T(dst_dtype,
+             hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, src, (bf16_t*)dst, B, C, H, W, Cpad, total),
+             hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, src, (float*)dst, B, C, H, W, Cpad, total));
+  return du_check_launch();
+}
+
+extern "C" int du_nhwc_to_nchw_f32(int src_dtype, const void* src, int64_t ld, float* dst, int B, int C, int H, int W, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!src || !dst || B <= 0) return DU_ERR_BAD_ARG;
+  long total = (long)B * C * H * W;
+  DISPATCH_T(src_dtype,
+             hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, (const bf16_t*)src, ld, dst, B, C, H, W, total),
+             hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, (const float*)src, ld, dst, B, C, H, W, total));
+  return du_check_launch();
+}
+
+extern "C" int du_patchify16(int dst_dtype, const float* src, void* dst, int B, int C, int H, int W, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!src || !dst || B <= 0 || H % 16 || W % 16) return DU_ERR_BAD_ARG;
+  long total = (long)B * (H / 16) * (W / 16) * C * 256;
+  DISPATCH_T(dst_dtype,
+             hipLaunchKernelGGL(patchify16_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, src, (bf16_t*)dst, B, C, H, W, total),
+             hipLaunchKernelGGL(patchify16_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, src, (float*)dst, B, C, H, W, total));
+  return du_check_launch();
+}
+
+extern "C" int du_msda_prep(int dtype, const void* raw, int64_t ldr, const float* ref, float* loc, float* attn, int64_t rows, int Lq,
+                            int M, int P, int Hs, int Ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!raw || !ref || !loc || !attn || rows <= 0 || Lq <= 0 || rows % Lq || M <= 0 || P <= 0 || P > 16) return DU_ERR_BAD_ARG;
+  long total = rows * M;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(msda_prep_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, (const bf16_t*)raw, ldr, ref, loc, attn, (long)rows, Lq, M, P, 1.f / Ws, 1.f / Hs, total),
+             hipLaunchKernelGGL(msda_prep_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, (const float*)raw, ldr, ref, loc, attn, (long)rows, Lq, M, P, 1.f / Ws, 1.f / Hs, total));
+  return du_check_launch();
+}
+
+extern "C" int du_msda_prep_bwd(int dtype, const float* attn, const float* gloc, const float* gattn, void* graw, int64_t ldr, int64_t rows,
+                                int M, int P, int Hs, int Ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!attn || !gloc || !gattn || !graw || rows <= 0 || M <= 0 || P <= 0) return DU_ERR_BAD_ARG;
+  long total = rows * M;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(msda_prep_bwd_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, attn, gloc, gattn, (bf16_t*)graw, ldr, (long)rows, M, P, 1.f / Ws, 1.f / Hs, total),
+             hipLaunchKernelGGL(msda_prep_bwd_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, attn, gloc, gattn, (float*)graw, ldr, (long)rows, M, P, 1.f / Ws, 1.f / Hs, total));
+  return du_check_launch();
+}
+
+extern "C" int du_act_bwd(int dtype, const void* z, const void* dy, void* dz, int64_t n, int act, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!z || !dy || !dz || n <= 0) return DU_ERR_BAD_ARG;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(grid_1d(n)), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)dy, (bf16_t*)dz, (long)n, act),
+             hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid_1d(n)), dim3(256), 0, st, (const float*)z, (const float*)dy, (float*)dz, (long)n, act));
+  return du_check_launch();
+}
+
+extern "C" const char* du_version(void) { return "dinounet_hip 0.1 (gfx950)"; }
+
+extern "C" int du_device_ok(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+  const char* a = p.gcnArchName;
+  return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
+}

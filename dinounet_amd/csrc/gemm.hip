@@ -29,7 +29,8 @@ struct GemmParams {
   void* C; long ldc; long cbs;
   int M, N, K;
   int split_k, k_per_split;
-  float alpha; const float* bias; int act; const float* gamma; const void* residual; long ldr;
+  float alpha; const float* bias; int act; const float* gamma; const float* row_scale; int rs_rows;
+  const void* residual; long ldr;
   int store_mode, ps_H, ps_W, ps_C;
   int tiles_n;
 };
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams P) {
         v += bias;
         v = apply_act(v, P.act);
         v *= gam;
+        if (P.row_scale) v *= P.row_scale[m / P.rs_rows];
         long off;
         if (P.store_mode == DU_STORE_PIXEL_SHUFFLE2) {
           int x = m % P.ps_W; int t = m / P.ps_W; int y = t % P.ps_H; int b = t / P.ps_H;
@@ -338,7 +340,7 @@ int launch_cfg(const du_gemm_args& a, hipStream_t st) {
   P.k_per_split = kps;
   P.split_k = (a.K + kps - 1) / kps;  // drop empty splits
   if (a.split_k > 1 && P.split_k == 1) P.split_k = 1;
-  P.alpha = a.alpha; P.bias = a.bias; P.act = a.act; P.gamma = a.gamma; P.residual = a.residual; P.ldr = a.ldr;
+  P.alpha = a.alpha; P.bias = a.bias; P.act = a.act; P.gamma = a.gamma; P.row_scale = a.row_scale; P.rs_rows = a.rs_rows > 0 ? a.rs_rows : 1; P.residual = a.residual; P.ldr = a.ldr;
   P.store_mode = a.store_mode; P.ps_H = a.ps_H; P.ps_W = a.ps_W; P.ps_C = a.ps_C;
   int tiles_m = (a.M + BM - 1) / BM;
   P.tiles_n = (a.N + BN - 1) / BN;
@@ -397,7 +399,7 @@ extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
     if (a_i2c && a.K != g.KH * g.KW * g.C) return DU_ERR_BAD_ARG;
     if (b_i2c && a.N != g.KH * g.KW * g.C) return DU_ERR_BAD_ARG;
   }
-  if (a.split_k > 1 && (a.out_dtype != DU_F32 || a.bias || a.act || a.gamma || a.residual || a.store_mode)) return DU_ERR_BAD_ARG;
+  if (a.split_k > 1 && (a.out_dtype != DU_F32 || a.bias || a.act || a.gamma || a.row_scale || a.residual || a.store_mode)) return DU_ERR_BAD_ARG;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && (a.ps_C <= 0 || a.N != 4 * a.ps_C || a.M % (a.ps_H * a.ps_W))) return DU_ERR_BAD_ARG;
   if (a.dtype == DU_BF16) {
     if (a.out_dtype == DU_BF16) return launch_dtype<bf16_t, bf16_t>(a, st);

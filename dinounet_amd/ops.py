@@ -1,0 +1,775 @@
+"""Host-side operator layer: thin Python wrappers that hand raw device pointers to libdinounet_hip.so
+(include/dinounet_hip.h) on the current HIP stream, plus the torch.autograd.Function classes that give the
+trainable part of Dino U-Net its backward pass.  PyTorch is used for device memory, streams and autograd
+bookkeeping only; there is no CPU path -- a CPU tensor raises.
+
+Layouts: conv-side activations are NHWC tensors (B, H, W, C) (channel-contiguous; a channel slice of a wider
+buffer is allowed), token tensors are (B, N, D).  `dt` is the activation dtype (bf16 throughput mode, fp32
+parity mode); statistics, MSDA locations/weights, weight gradients and the ViT residual stream are fp32.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, DU_BF16, DU_F32, IM2COL_COL, IM2COL_ROW, PLAIN_COL,
+                   PLAIN_ROW, STORE_PIXEL_SHUFFLE2, ConvGeom, GemmArgs)
+
+__all__ = ["mm", "linear", "conv2d", "conv_transpose2x2", "norm_act", "layer_norm", "msda", "dwconv3x3",
+           "maxpool3x3s2", "bilinear_add"]
+
+
+# ----------------------------------------------------------------------------------------------------
+# plumbing
+# ----------------------------------------------------------------------------------------------------
+def _code(dt):
+    if dt == torch.bfloat16:
+        return DU_BF16
+    if dt == torch.float32:
+        return DU_F32
+    raise RuntimeError(f"dinounet_amd: unsupported dtype {dt} (bf16 / fp32 only)")
+
+
+def _req(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("dinounet_amd ops run on the GPU through libdinounet_hip.so only (no CPU fallback); "
+                               "got a CPU tensor")
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t):
+    if t is None:
+        return None
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _rows2d(t):
+    """(rows, cols) view info of a matrix whose last dim is contiguous: returns (rows, cols, ld)."""
+    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def _nhwc(t):
+    """NHWC tensor (B,H,W,C) with dense pixels -> (B,H,W,C,ld)."""
+    assert t.dim() == 4 and t.stride(3) == 1, (t.shape, t.stride())
+    B, H, W, Cc = t.shape
+    ld = t.stride(2)
+    assert (W == 1 or True) and t.stride(1) == W * ld and (B == 1 or t.stride(0) == H * W * ld), (t.shape, t.stride())
+    return B, H, W, Cc, ld
+
+
+def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat, ldc, batch=1, abs_=0, bbs=0, cbs=0,
+             split_k=1, alpha=1.0, bias=None, act=ACT_NONE, gamma=None, row_scale=None, rs_rows=0, residual=None, ldr=0,
+             store_mode=0, ps=(0, 0, 0), geom=None):
+    a = GemmArgs()
+    a.dtype, a.out_dtype, a.a_mode, a.b_mode = dtype, out_dtype, a_mode, b_mode
+    a.M, a.N, a.K = M, N, K
+    a.A, a.lda, a.a_batch_stride = A, lda, abs_
+    a.B, a.ldb, a.b_batch_stride = B, ldb, bbs
+    a.C, a.ldc, a.c_batch_stride = Cmat, ldc, cbs
+    a.batch, a.split_k, a.alpha = batch, split_k, alpha
+    a.bias = bias
+    a.act = act
+    a.gamma = gamma
+    a.row_scale, a.rs_rows = row_scale, rs_rows
+    a.residual, a.ldr = residual, ldr
+    a.store_mode = store_mode
+    a.ps_H, a.ps_W, a.ps_C = ps
+    if geom is not None:
+        a.geom = geom
+    _lib.check(_lib.lib().du_gemm(C.byref(a), _st()), "du_gemm")
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+# ----------------------------------------------------------------------------------------------------
+# dense products
+# ----------------------------------------------------------------------------------------------------
+def mm(x, w, *, out=None, out_dtype=None, bias=None, act=ACT_NONE, gamma=None, residual=None, row_scale=None,
+       rs_rows=0, alpha=1.0):
+    """out[m][n] = epi(sum_k x[m][k] * w[n][k]).  x (M,K), w (N,K) same dtype; bias/gamma/row_scale fp32."""
+    _req(x, w)
+    M, K, lda = _rows2d(x)
+    N, K2, ldb = _rows2d(w)
+    assert K == K2 and x.dtype == w.dtype, (x.shape, w.shape, x.dtype, w.dtype)
+    od = out_dtype or (out.dtype if out is not None else x.dtype)
+    if out is None:
+        out = torch.empty((M, N), dtype=od, device=x.device)
+    _, _, ldc = _rows2d(out)
+    ldr = 0
+    if residual is not None:
+        assert residual.dtype == out.dtype
+        ldr = residual.stride(0)
+    gemm_raw(dtype=_code(x.dtype), out_dtype=_code(out.dtype), a_mode=PLAIN_ROW, b_mode=PLAIN_ROW, M=M, N=N, K=K,
+             A=x.data_ptr(), lda=lda, B=w.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=ldc, alpha=alpha,
+             bias=_dp(bias), act=act, gamma=_dp(gamma), row_scale=_dp(row_scale), rs_rows=rs_rows,
+             residual=_dp(residual), ldr=ldr)
+    return out
+
+
+def mm_dgrad(dy, w, out=None):
+    """dx[m][k] = sum_n dy[m][n] * w[n][k]   (w (N,K) read column-wise, no transposed copy)."""
+    _req(dy, w)
+    M, N, lda = _rows2d(dy)
+    N2, K, ldb = _rows2d(w)
+    assert N == N2 and dy.dtype == w.dtype
+    if out is None:
+        out = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+    gemm_raw(dtype=_code(dy.dtype), out_dtype=_code(out.dtype), a_mode=PLAIN_ROW, b_mode=PLAIN_COL, M=M, N=K, K=N,
+             A=dy.data_ptr(), lda=lda, B=w.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=out.stride(0))
+    return out
+
+
+def _split_for(tiles, kdim):
+    s = max(1, min(1024 // max(tiles, 1), kdim // 256))
+    return max(1, s)
+
+
+def mm_wgrad(dy, x):
+    """dw[n][k] = sum_m dy[m][n] * x[m][k]  -> fp32 (N,K); split-K over the rows with fp32 atomics."""
+    _req(dy, x)
+    Mr, N, lda = _rows2d(dy)
+    Mr2, K, ldb = _rows2d(x)
+    assert Mr == Mr2 and dy.dtype == x.dtype
+    out = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    gemm_raw(dtype=_code(dy.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=PLAIN_COL, M=N, N=K, K=Mr,
+             A=dy.data_ptr(), lda=lda, B=x.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=K,
+             split_k=_split_for(tiles, Mr))
+    return out
+
+
+def colsum(x2d):
+    """sum over rows of a (rows, C) matrix -> fp32 (C,)   (bias gradients)."""
+    rows, Cc, ld = _rows2d(x2d)
+    sums = torch.zeros((1, Cc, 2), dtype=torch.float32, device=x2d.device)
+    _lib.check(_lib.lib().du_chan_stats(_code(x2d.dtype), _p(x2d), ld, _p(sums), 1, rows, Cc, _st()), "du_chan_stats")
+    return sums[0, :, 0].contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------
+# convolution as implicit GEMM
+# ----------------------------------------------------------------------------------------------------
+def _geom(src, KH, KW, stride, pad, Ho, Wo, transposed, src2=None):
+    B, Hi, Wi, C1, ld = _nhwc(src)
+    g = ConvGeom()
+    Ct = C1
+    if src2 is not None:
+        B2, H2, W2, C2, ld2 = _nhwc(src2)
+        assert (B2, H2, W2) == (B, Hi, Wi) and src2.dtype == src.dtype
+        g.p2, g.ld2 = src2.data_ptr(), ld2
+        Ct = C1 + C2
+    g.C1 = C1
+    g.Hi, g.Wi, g.C = Hi, Wi, Ct
+    g.KH, g.KW, g.stride, g.pad = KH, KW, stride, pad
+    g.Ho, g.Wo, g.transposed = Ho, Wo, transposed
+    return g, B, ld, Ct
+
+
+def pack_conv_weight(w, dt):
+    """(Cout,Cin,KH,KW) -> (Cout, KH*KW*Cin) in the activation dtype, (tap, ci) column order."""
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()
+
+
+def pack_conv_weight_dgrad(w, dt):
+    """(Cout,Cin,KH,KW) -> (Cin, KH*KW*Cout): [ci][(dy,dx,co)]."""
+    return w.permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(dt).contiguous()
+
+
+def conv_fwd(x, wp, bias, KH, KW, stride, pad, x2=None, out=None, act=ACT_NONE):
+    _req(x, wp)
+    B, Hi, Wi, _, _ = _nhwc(x)
+    Ho = (Hi + 2 * pad - KH) // stride + 1
+    Wo = (Wi + 2 * pad - KW) // stride + 1
+    g, B, ld, Ct = _geom(x, KH, KW, stride, pad, Ho, Wo, 0, x2)
+    Cout, Kc, ldb = _rows2d(wp)
+    assert Kc == KH * KW * Ct and wp.dtype == x.dtype, (wp.shape, KH, KW, Ct)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    _, _, _, _, ldc = _nhwc(out)
+    gemm_raw(dtype=_code(x.dtype), out_dtype=_code(out.dtype), a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * Ho * Wo, N=Cout,
+             K=Kc, A=x.data_ptr(), lda=ld, B=wp.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=ldc, bias=_dp(bias), act=act,
+             geom=g)
+    return out
+
+
+def conv_dgrad(dy, wd, KH, KW, stride, pad, Hin, Win, out=None):
+    """dX (B,Hin,Win,Cin) from dY (B,Ho,Wo,Cout) and wd = pack_conv_weight_dgrad(w)."""
+    _req(dy, wd)
+    g, B, ld, Cout = _geom(dy, KH, KW, stride, pad, Hin, Win, 1)
+    Cin, Kc, ldb = _rows2d(wd)
+    assert Kc == KH * KW * Cout
+    if out is None:
+        out = torch.empty((B, Hin, Win, Cin), dtype=dy.dtype, device=dy.device)
+    _, _, _, _, ldc = _nhwc(out)
+    gemm_raw(dtype=_code(dy.dtype), out_dtype=_code(out.dtype), a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * Hin * Win, N=Cin,
+             K=Kc, A=dy.data_ptr(), lda=ld, B=wd.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=ldc, geom=g)
+    return out
+
+
+def conv_wgrad(x, dy, KH, KW, stride, pad, x2=None):
+    """-> fp32 (Cout, KH*KW*C) in (tap, ci) column order."""
+    _req(x, dy)
+    Bo, Ho, Wo, Cout, lddy = _nhwc(dy)
+    g, B, ld, Ct = _geom(x, KH, KW, stride, pad, Ho, Wo, 0, x2)
+    Ncol = KH * KW * Ct
+    out = torch.zeros((Cout, Ncol), dtype=torch.float32, device=x.device)
+    npix = B * Ho * Wo
+    tiles = ((Cout + 127) // 128) * ((Ncol + 127) // 128)
+    gemm_raw(dtype=_code(x.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=IM2COL_COL, M=Cout, N=Ncol, K=npix,
+             A=dy.data_ptr(), lda=lddy, B=x.data_ptr(), ldb=ld, Cmat=out.data_ptr(), ldc=Ncol,
+             split_k=_split_for(tiles, npix), geom=g)
+    return out
+
+
+class _Conv2d(torch.autograd.Function):
+    """Conv2d on NHWC, optional second input = fused channel concat (dinounet_training.py:614)."""
+
+    @staticmethod
+    def forward(ctx, x, x2, w, bias, stride, pad):
+        KH, KW = w.shape[2], w.shape[3]
+        wp = pack_conv_weight(w, x.dtype)
+        y = conv_fwd(x, wp, _f32(bias), KH, KW, stride, pad, x2)
+        ctx.save_for_backward(x, x2, w)
+        ctx.conf = (KH, KW, stride, pad, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, w = ctx.saved_tensors
+        KH, KW, stride, pad, has_bias = ctx.conf
+        dy = dy.contiguous()
+        B, Hi, Wi, C1, _ = _nhwc(x)
+        dx = dx2 = dw = db = None
+        need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
+        if need_dx:
+            wd = pack_conv_weight_dgrad(w, dy.dtype)
+            dfull = conv_dgrad(dy, wd, KH, KW, stride, pad, Hi, Wi)
+            if x2 is None:
+                dx = dfull
+            else:
+                dx, dx2 = dfull[..., :C1], dfull[..., C1:]
+        if ctx.needs_input_grad[2]:
+            g = conv_wgrad(x, dy, KH, KW, stride, pad, x2)
+            dw = g.view(w.shape[0], KH, KW, w.shape[1]).permute(0, 3, 1, 2).contiguous()
+        if has_bias and ctx.needs_input_grad[3]:
+            db = colsum(dy.view(-1, dy.shape[-1]))
+        return dx, dx2, dw, db, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=1, x2=None):
+    return _Conv2d.apply(x, x2, w, bias, stride, pad)
+
+
+class _Linear(torch.autograd.Function):
+    """y = x w^T + b [* row_scale per sample] [+ residual]   on (rows, K) matrices."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, row_scale, rs_rows, out_dtype):
+        wq = w.to(x.dtype) if w.dtype != x.dtype else w
+        y = mm(x, wq, bias=_f32(bias), residual=residual, row_scale=row_scale, rs_rows=rs_rows, out_dtype=out_dtype)
+        ctx.save_for_backward(x, wq, row_scale)
+        ctx.rs_rows = rs_rows
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq, row_scale = ctx.saved_tensors
+        dres = dy if ctx.has_res else None
+        dyc = dy if dy.stride(1) == 1 else dy.contiguous()
+        if dyc.dtype != x.dtype:
+            dyc = cast(dyc, x.dtype)
+        if row_scale is not None:
+            dyc = (dyc.view(row_scale.numel(), ctx.rs_rows, -1) * row_scale.view(-1, 1, 1).to(dyc.dtype)).view(dyc.shape)
+        dx = mm_dgrad(dyc, wq) if ctx.needs_input_grad[0] else None
+        dw = mm_wgrad(dyc, x) if ctx.needs_input_grad[1] else None
+        db = colsum(dyc) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, dres, None, None, None
+
+
+def linear(x, w, bias=None, residual=None, row_scale=None, rs_rows=0, out_dtype=None):
+    """x (..., K) -> (..., N); leading dims are flattened (last dim contiguous, uniform row stride)."""
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    r2 = residual.reshape(-1, residual.shape[-1]) if residual is not None else None
+    y = _Linear.apply(x2, w, bias, r2, row_scale, rs_rows, out_dtype)
+    return y.view(*shp[:-1], w.shape[0])
+
+
+def conv1x1(x, w, bias=None, out_dtype=None):
+    """1x1 conv on NHWC = linear over pixels.  w (Cout, Cin, 1, 1)."""
+    B, H, W, Cc, ld = _nhwc(x)
+    xm = x.as_strided((B * H * W, Cc), (ld, 1), x.storage_offset())
+    y = _Linear.apply(xm, w.view(w.shape[0], -1), bias, None, None, 0, out_dtype)
+    return y.view(B, H, W, w.shape[0])
+
+
+class _ConvT2x2(torch.autograd.Function):
+    """ConvTranspose2d(k=2, s=2) on NHWC as GEMM [pixels x Cin] . [Cin x 4 Cout] + pixel-shuffle store."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        B, H, W, Cin, ld = _nhwc(x)
+        Cout = w.shape[1]
+        wp = w.permute(2, 3, 1, 0).reshape(4 * Cout, Cin).to(x.dtype).contiguous()
+        out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
+        _, _, _, _, ldc = _nhwc(out)
+        b4 = _f32(bias).repeat(4) if bias is not None else None
+        gemm_raw(dtype=_code(x.dtype), out_dtype=_code(out.dtype), a_mode=PLAIN_ROW, b_mode=PLAIN_ROW, M=B * H * W,
+                 N=4 * Cout, K=Cin, A=x.data_ptr(), lda=ld, B=wp.data_ptr(), ldb=Cin, Cmat=out.data_ptr(), ldc=ldc,
+                 bias=_dp(b4), store_mode=STORE_PIXEL_SHUFFLE2, ps=(H, W, Cout))
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, H, W, Cin, ld = _nhwc(x)
+        Cout = w.shape[1]
+        if not (dy.stride(3) == 1 and dy.stride(1) == dy.shape[2] * dy.stride(2)):
+            dy = dy.contiguous()
+        dx = dw = db = None
+        g, _, lddy, _ = _geom(dy, 2, 2, 2, 0, H, W, 0)
+        if ctx.needs_input_grad[0]:
+            wd = w.permute(0, 2, 3, 1).reshape(Cin, 4 * Cout).to(dy.dtype).contiguous()
+            dx = torch.empty((B, H, W, Cin), dtype=dy.dtype, device=dy.device)
+            gemm_raw(dtype=_code(dy.dtype), out_dtype=_code(dx.dtype), a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * H * W,
+                     N=Cin, K=4 * Cout, A=dy.data_ptr(), lda=lddy, B=wd.data_ptr(), ldb=4 * Cout, Cmat=dx.data_ptr(),
+                     ldc=Cin, geom=g)
+        if ctx.needs_input_grad[1]:
+            gw = torch.zeros((Cin, 4 * Cout), dtype=torch.float32, device=dy.device)
+            npix = B * H * W
+            tiles = ((Cin + 127) // 128) * ((4 * Cout + 127) // 128)
+            gemm_raw(dtype=_code(dy.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=IM2COL_COL, M=Cin, N=4 * Cout,
+                     K=npix, A=x.data_ptr(), lda=ld, B=dy.data_ptr(), ldb=lddy, Cmat=gw.data_ptr(), ldc=4 * Cout,
+                     split_k=_split_for(tiles, npix), geom=g)
+            dw = gw.view(Cin, 2, 2, Cout).permute(0, 3, 1, 2).contiguous()
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            Bo, Ho, Wo, Co, ldo = _nhwc(dy)
+            db = colsum(dy.as_strided((Bo * Ho * Wo, Co), (ldo, 1), dy.storage_offset()))
+        return dx, dw, db
+
+
+def conv_transpose2x2(x, w, bias=None):
+    return _ConvT2x2.apply(x, w, bias)
+
+
+# ----------------------------------------------------------------------------------------------------
+# norms
+# ----------------------------------------------------------------------------------------------------
+def chan_stats(x, G):
+    """NHWC x -> (G, C, 2) fp32 sums (sum, sum of squares) over each group's pixels (G=B: InstanceNorm, G=1: BatchNorm)."""
+    B, H, W, Cc, ld = _nhwc(x)
+    P = (B // G) * H * W
+    sums = torch.zeros((G, Cc, 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().du_chan_stats(_code(x.dtype), _p(x), ld, _p(sums), G, P, Cc, _st()), "du_chan_stats")
+    return sums, P
+
+
+def _norm_fwd(x, mean, rstd, w, b, G, P, act):
+    B, H, W, Cc, ld = _nhwc(x)
+    y = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().du_norm_act_fwd(_code(x.dtype), _p(x), ld, _p(y), Cc, _p(mean), _p(rstd), _p(w), _p(b), G, P, Cc, act,
+                                          _st()), "du_norm_act_fwd")
+    return y
+
+
+class _NormAct(torch.autograd.Function):
+    """InstanceNorm2d / (Sync)BatchNorm2d + activation on NHWC.
+
+    kind 'in': statistics per (sample, channel) (torch InstanceNorm2d, biased var, eps).
+    kind 'bn': training -> batch statistics (all-reduced over the process group when one is given = SyncBatchNorm,
+               dinov3_adapter.py:242,361) and running-stat update (momentum 0.1, unbiased var); eval -> running stats."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, kind, act, eps, training, running_mean, running_var, momentum, group):
+        B, H, W, Cc, ld = _nhwc(x)
+        wf, bf = _f32(w), _f32(b)
+        use_batch = (kind == "in") or training
+        count = None
+        if use_batch:
+            G = B if kind == "in" else 1
+            sums, P = chan_stats(x, G)
+            count = float(P)
+            if kind == "bn" and group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+                sums = sums.clone()
+                torch.distributed.all_reduce(sums, group=group)   # equal per-rank batch (TRN:322-327 splits evenly)
+                count = count * torch.distributed.get_world_size(group)
+            mean = sums[..., 0] / count
+            var = (sums[..., 1] / count - mean * mean).clamp_min_(0.0)
+            rstd = torch.rsqrt(var + eps)
+            if kind == "bn" and running_mean is not None:
+                with torch.no_grad():
+                    running_mean.mul_(1 - momentum).add_(mean[0], alpha=momentum)
+                    running_var.mul_(1 - momentum).add_(var[0] * (count / max(count - 1.0, 1.0)), alpha=momentum)
+        else:
+            G, P = 1, B * H * W
+            mean = running_mean.float().view(1, Cc)
+            rstd = torch.rsqrt(running_var.float() + eps).view(1, Cc)
+        mean, rstd = mean.contiguous(), rstd.contiguous()
+        y = _norm_fwd(x, mean, rstd, wf, bf, G, P, act)
+        ctx.save_for_backward(x, mean, rstd, wf, bf)
+        ctx.conf = (G, P, act, use_batch, count, kind, group)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, wf, bf = ctx.saved_tensors
+        G, P, act, use_batch, count, kind, group = ctx.conf
+        B, H, W, Cc, ld = _nhwc(x)
+        dy = dy.contiguous()
+        L = _lib.lib()
+        bs = torch.zeros((G, Cc, 2), dtype=torch.float32, device=x.device)
+        _lib.check(L.du_norm_act_bwd_stats(_code(x.dtype), _p(x), ld, _p(dy), Cc, _p(mean), _p(rstd), _p(wf), _p(bf), _p(bs), G, P,
+                                           Cc, act, _st()), "du_norm_act_bwd_stats")
+        dw = bs[..., 1].sum(0)
+        db = bs[..., 0].sum(0)
+        bsr = bs
+        if kind == "bn" and use_batch and group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+            bsr = bs.clone()
+            torch.distributed.all_reduce(bsr, group=group)
+        dx = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device)
+        _lib.check(L.du_norm_act_bwd_dx(_code(x.dtype), _p(x), ld, _p(dy), Cc, _p(dx), Cc, _p(mean), _p(rstd), _p(wf), _p(bf),
+                                        _p(bsr), G, P, Cc, act, float(count or 0.0), 1 if use_batch else 0, _st()),
+                   "du_norm_act_bwd_dx")
+        return dx, dw, db, None, None, None, None, None, None, None, None
+
+
+def norm_act(x, w, b, kind, act=ACT_NONE, eps=1e-5, training=True, running_mean=None, running_var=None, momentum=0.1,
+             group=None):
+    return _NormAct.apply(x, w, b, kind, act, eps, training, running_mean, running_var, momentum, group)
+
+
+def layernorm_raw(x2d, w, b, eps, out_dtype, want_stats=False):
+    rows, D, ld = _rows2d(x2d)
+    y = torch.empty((rows, D), dtype=out_dtype, device=x2d.device)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    _lib.check(_lib.lib().du_layernorm_fwd(_code(x2d.dtype), _code(out_dtype), _p(x2d), ld, _p(w), _p(b), _p(y), D, _p(mean),
+                                           _p(rstd), rows, D, eps, _st()), "du_layernorm_fwd")
+    return y, mean, rstd
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        xc = x.contiguous()
+        wf, bf = _f32(w), _f32(b)
+        y, mean, rstd = layernorm_raw(xc.view(-1, xc.shape[-1]), wf, bf, eps, xc.dtype, True)
+        ctx.save_for_backward(xc, wf, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wf, mean, rstd = ctx.saved_tensors
+        D = xc.shape[-1]
+        dyc = dy.contiguous()
+        dx = torch.empty_like(xc)
+        dw = torch.zeros(D, dtype=torch.float32, device=xc.device)
+        db = torch.zeros(D, dtype=torch.float32, device=xc.device)
+        _lib.check(_lib.lib().du_layernorm_bwd(_code(xc.dtype), _p(xc), _p(dyc), _p(wf), _p(mean), _p(rstd), _p(dx), _p(dw), _p(db),
+                                               xc.numel() // D, D, _st()), "du_layernorm_bwd")
+        return dx, dw, db, None
+
+
+def layer_norm(x, w, b, eps):
+    return _LayerNorm.apply(x, w, b, eps)
+
+
+# ----------------------------------------------------------------------------------------------------
+# multi-scale deformable attention
+# ----------------------------------------------------------------------------------------------------
+def msda_forward_raw(value, shapes, lsi, loc, attn):
+    _req(value, shapes, lsi, loc, attn)
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    _lib.check(_lib.lib().du_msda_forward(_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(attn), _p(out), N, S, M, D,
+                                          L, Lq, P, _st()), "du_msda_forward")
+    return out
+
+
+def msda_backward_raw(value, shapes, lsi, loc, attn, grad_out):
+    _req(value, shapes, lsi, loc, attn, grad_out)
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    gv = torch.zeros((N, S, M, D), dtype=torch.float32, device=value.device)
+    gl = torch.zeros(loc.shape, dtype=torch.float32, device=value.device)
+    ga = torch.zeros(attn.shape, dtype=torch.float32, device=value.device)
+    _lib.check(_lib.lib().du_msda_backward(_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(attn), _p(grad_out), _p(gv),
+                                           _p(gl), _p(ga), N, S, M, D, L, Lq, P, _st()), "du_msda_backward")
+    return gv, gl, ga
+
+
+class _MSDA(torch.autograd.Function):
+    """MSDeformAttnFunction (ms_deform_attn.py:28-68): value (N,S,M,D) in the activation dtype, sampling locations
+    and attention weights fp32 (the reference casts everything to fp32, :30)."""
+
+    @staticmethod
+    def forward(ctx, value, shapes, lsi, loc, attn):
+        value, loc, attn = value.contiguous(), loc.contiguous(), attn.contiguous()
+        out = msda_forward_raw(value, shapes, lsi, loc, attn)
+        ctx.save_for_backward(value, shapes, lsi, loc, attn)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        value, shapes, lsi, loc, attn = ctx.saved_tensors
+        gv, gl, ga = msda_backward_raw(value, shapes, lsi, loc, attn, go.contiguous())
+        return gv.to(value.dtype), None, None, gl, ga
+
+
+def msda(value, shapes, lsi, loc, attn):
+    return _MSDA.apply(value, shapes, lsi, loc, attn)
+
+
+class _MSDAPrep(torch.autograd.Function):
+    """offsets|logits (rows, M*P*3) -> sampling locations (rows,M,P,2) and softmaxed weights (rows,M,P), fp32."""
+
+    @staticmethod
+    def forward(ctx, raw, ref, Lq, M, P, Hs, Ws):
+        rows, ncol, ld = _rows2d(raw)
+        assert ncol == M * P * 3
+        loc = torch.empty((rows, M, P, 2), dtype=torch.float32, device=raw.device)
+        attn = torch.empty((rows, M, P), dtype=torch.float32, device=raw.device)
+        _lib.check(_lib.lib().du_msda_prep(_code(raw.dtype), _p(raw), ld, _p(ref), _p(loc), _p(attn), rows, Lq, M, P, Hs, Ws, _st()),
+                   "du_msda_prep")
+        ctx.save_for_backward(attn)
+        ctx.conf = (M, P, Hs, Ws, raw.dtype, ncol)
+        return loc, attn
+
+    @staticmethod
+    def backward(ctx, gloc, gattn):
+        (attn,) = ctx.saved_tensors
+        M, P, Hs, Ws, dt, ncol = ctx.conf
+        rows = attn.shape[0]
+        graw = torch.empty((rows, ncol), dtype=dt, device=attn.device)
+        _lib.check(_lib.lib().du_msda_prep_bwd(_code(dt), _p(attn), _p(gloc.contiguous()), _p(gattn.contiguous()), _p(graw), ncol, rows,
+                                               M, P, Hs, Ws, _st()), "du_msda_prep_bwd")
+        return graw, None, None, None, None, None, None
+
+
+def msda_prep(raw, ref, Lq, M, P, Hs, Ws):
+    return _MSDAPrep.apply(raw, ref, Lq, M, P, Hs, Ws)
+
+
+# ----------------------------------------------------------------------------------------------------
+# small NHWC ops
+# ----------------------------------------------------------------------------------------------------
+class _DWConvSegs(torch.autograd.Function):
+    """Depthwise 3x3 (+bias, +activation) over one or more image segments of a flat channel-last tensor.
+    seg = (element offset, B, H, W, pixel stride ld, per-image stride bs).  Serves plain NHWC tensors
+    (dinounet_training.py:235) and ConvFFN's DWConv (dinov3_adapter.py:99-109): one depthwise kernel applied to the
+    three token ranges of a (B, N, C) tensor viewed as (2H x 2W), (H x W), (H/2 x W/2) grids, then GELU (:87)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, segs, act):
+        x = x.contiguous()
+        Cc = w.shape[0]
+        wf = _f32(w).view(Cc, 9)
+        bf = _f32(bias)
+        y = torch.empty_like(x)
+        z = torch.empty_like(x) if act != ACT_NONE else None
+        es = x.element_size()
+        L = _lib.lib()
+        for (off, B, h, ww, ld, bs) in segs:
+            _lib.check(L.du_dwconv3x3_fwd(_code(x.dtype), C.c_void_p(x.data_ptr() + off * es), ld, bs, _p(wf), _p(bf),
+                                          C.c_void_p(y.data_ptr() + off * es), ld, bs,
+                                          None if z is None else C.c_void_p(z.data_ptr() + off * es), B, h, ww, Cc, act, _st()),
+                       "du_dwconv3x3_fwd")
+        ctx.save_for_backward(x, wf, z)
+        ctx.conf = (segs, act, bias is not None, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wf, z = ctx.saved_tensors
+        segs, act, has_bias, Cc = ctx.conf
+        L = _lib.lib()
+        es = x.element_size()
+        code = _code(x.dtype)
+        dy = dy.contiguous()
+        if act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            _lib.check(L.du_act_bwd(code, _p(z), _p(dy), _p(dz), dy.numel(), act, _st()), "du_act_bwd")
+        else:
+            dz = dy
+        dx = torch.empty_like(x)
+        dw = torch.zeros((Cc, 9), dtype=torch.float32, device=x.device)
+        db = torch.zeros(Cc, dtype=torch.float32, device=x.device) if has_bias else None
+        for (off, B, h, ww, ld, bs) in segs:
+            _lib.check(L.du_dwconv3x3_bwd_data(code, C.c_void_p(dz.data_ptr() + off * es), ld, bs, _p(wf),
+                                               C.c_void_p(dx.data_ptr() + off * es), ld, bs, B, h, ww, Cc, _st()),
+                       "du_dwconv3x3_bwd_data")
+            _lib.check(L.du_dwconv3x3_bwd_weight(code, C.c_void_p(x.data_ptr() + off * es), ld, bs,
+                                                 C.c_void_p(dz.data_ptr() + off * es), ld, bs, _p(dw), _p(db), B, h, ww, Cc,
+                                                 _st()), "du_dwconv3x3_bwd_weight")
+        return dx, dw.view(Cc, 1, 3, 3), db, None, None
+
+
+def dwconv3x3(x, w, bias=None, act=ACT_NONE):
+    """x NHWC (B,H,W,C)."""
+    x = x.contiguous()
+    B, H, W, Cc = x.shape
+    return _DWConvSegs.apply(x, w, bias, ((0, B, H, W, Cc, H * W * Cc),), act)
+
+
+def dwconv_tokens(x, w, bias, H, W, act=ACT_GELU):
+    """x (B, N, C) with N = 21 * (H*W/4) tokens (ConvFFN)."""
+    B, N, Cc = x.shape
+    n = N // 21
+    segs = ((0, B, 2 * H, 2 * W, Cc, N * Cc), (16 * n * Cc, B, H, W, Cc, N * Cc), (20 * n * Cc, B, H // 2, W // 2, Cc, N * Cc))
+    return _DWConvSegs.apply(x, w, bias, segs, act)
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+        idx = torch.empty((B, Ho, Wo, Cc), dtype=torch.uint8, device=x.device)
+        _lib.check(_lib.lib().du_maxpool3x3s2_fwd(_code(x.dtype), _p(x), _p(y), _p(idx), B, H, W, Cc, _st()), "du_maxpool3x3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, H, W, Cc, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, H, W, Cc, dt = ctx.shape
+        dx = torch.empty((B, H, W, Cc), dtype=dt, device=dy.device)
+        _lib.check(_lib.lib().du_maxpool3x3s2_bwd(_code(dt), _p(idx), _p(dy.contiguous()), _p(dx), B, H, W, Cc, _st()),
+                   "du_maxpool3x3s2_bwd")
+        return dx
+
+
+def maxpool3x3s2(x):
+    return _MaxPool.apply(x)
+
+
+class _BilinearAdd(torch.autograd.Function):
+    """out = base + bilinear_upsample(src), src carries no gradient (frozen ViT features, dinov3_adapter.py:472-476)."""
+
+    @staticmethod
+    def forward(ctx, src, base):
+        B, Hs, Ws, Cc, lds = _nhwc(src)
+        Bo, Ho, Wo, Co, ldb = _nhwc(base)
+        out = torch.empty((Bo, Ho, Wo, Co), dtype=base.dtype, device=base.device)
+        _lib.check(_lib.lib().du_bilinear_add_fwd(_code(src.dtype), _code(base.dtype), _p(src), lds, _p(base), ldb, _p(out), Co, B, Hs,
+                                                  Ws, Ho, Wo, Cc, _st()), "du_bilinear_add_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return None, dy
+
+
+def bilinear_add(src, base):
+    return _BilinearAdd.apply(src, base)
+
+
+# ----------------------------------------------------------------------------------------------------
+# layout helpers
+# ----------------------------------------------------------------------------------------------------
+def nchw_to_nhwc(x, dt, cpad=None):
+    """fp32 NCHW image -> NHWC `dt` with channels zero-padded to cpad (>= C, multiple of 8)."""
+    _req(x)
+    x = x.float().contiguous()
+    B, Cc, H, W = x.shape
+    cp = cpad or Cc
+    y = torch.empty((B, H, W, cp), dtype=dt, device=x.device)
+    _lib.check(_lib.lib().du_nchw_to_nhwc_pad(_code(dt), _p(x), _p(y), B, Cc, H, W, cp, _st()), "du_nchw_to_nhwc_pad")
+    return y
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, Cc, ld = _nhwc(x)
+        y = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().du_nhwc_to_nchw_f32(_code(x.dtype), _p(x), ld, _p(y), B, Cc, H, W, _st()), "du_nhwc_to_nchw_f32")
+        ctx.dt = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.float().contiguous()
+        B, Cc, H, W = dy.shape
+        return nchw_to_nhwc(dy, ctx.dt)
+
+
+def nhwc_to_nchw_f32(x):
+    return _ToNCHW.apply(x)
+
+
+def patchify16(x, dt):
+    _req(x)
+    x = x.float().contiguous()
+    B, Cc, H, W = x.shape
+    y = torch.empty((B * (H // 16) * (W // 16), Cc * 256), dtype=dt, device=x.device)
+    _lib.check(_lib.lib().du_patchify16(_code(dt), _p(x), _p(y), B, Cc, H, W, _st()), "du_patchify16")
+    return y
+
+
+def cast(x, dt):
+    _req(x)
+    if x.dtype == dt:
+        return x
+    xc = x.contiguous()
+    y = torch.empty(xc.shape, dtype=dt, device=x.device)
+    _lib.check(_lib.lib().du_cast(_code(xc.dtype), _code(dt), _p(xc), _p(y), xc.numel(), _st()), "du_cast")
+    return y
+
+
+# ----------------------------------------------------------------------------------------------------
+# ViT attention (forward only: the backbone is frozen, dinov3_adapter.py:326,423)
+# ----------------------------------------------------------------------------------------------------
+def attention(qkv, sin, cos, B, N, H, Dh, prefix, workspace):
+    """qkv (B*N, 3*H*Dh) -> (B*N, H*Dh).  bf16: fused flash kernel; fp32 (parity mode): QK^T / softmax / PV as batched
+    MFMA GEMMs with materialised scores."""
+    dt = qkv.dtype
+    Npad = (N + 7) // 8 * 8
+    key = ("qkv", dt, B, H, Npad, Dh)
+    if key not in workspace:
+        workspace[key] = torch.zeros((3, B, H, Npad, Dh), dtype=dt, device=qkv.device)
+    q, k, v = workspace[key]
+    L = _lib.lib()
+    scale = Dh ** -0.5
+    qscale = scale * math.log2(math.e) if dt == torch.bfloat16 else scale
+    _lib.check(L.du_qkv_rope_split(_code(dt), _p(qkv), _p(q), _p(k), _p(v), _p(sin), _p(cos), B, N, Npad, H, Dh, prefix, qscale, _st()),
+               "du_qkv_rope_split")
+    out = torch.empty((B * N, H * Dh), dtype=dt, device=qkv.device)
+    if dt == torch.bfloat16:
+        _lib.check(L.du_attention_fwd(_p(q), _p(k), _p(v), _p(out), B, H, N, Npad, Dh, _st()), "du_attention_fwd")
+        return out
+    skey = ("scores", B, H, Npad)
+    if skey not in workspace:
+        workspace[skey] = torch.empty((B * H, Npad, Npad), dtype=torch.float32, device=qkv.device)
+    S = workspace[skey]
+    gemm_raw(dtype=DU_F32, out_dtype=DU_F32, a_mode=PLAIN_ROW, b_mode=PLAIN_ROW, M=N, N=N, K=Dh, A=q.data_ptr(), lda=Dh,
+             B=k.data_ptr(), ldb=Dh, Cmat=S.data_ptr(), ldc=Npad, batch=B * H, abs_=Npad * Dh, bbs=Npad * Dh, cbs=Npad * Npad)
+    _lib.check(L.du_softmax_rows_f32(_p(S), B * H * Npad, N, Npad, _st()), "du_softmax_rows_f32")
+    # O[b,n,h,:] = P[b,h] V[b,h]: one batched GEMM per batch element so the (B,N,H,Dh) output strides are expressible
+    for b in range(B):
+        gemm_raw(dtype=DU_F32, out_dtype=DU_F32, a_mode=PLAIN_ROW, b_mode=PLAIN_COL, M=N, N=Dh, K=Npad,
+                 A=S[b * H].data_ptr(), lda=Npad, B=v[b].data_ptr(), ldb=Dh, Cmat=out[b * N].data_ptr(), ldc=H * Dh,
+                 batch=H, abs_=Npad * Npad, bbs=Npad * Dh, cbs=Dh)
+    return out

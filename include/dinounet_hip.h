@@ -91,6 +91,7 @@ typedef struct {
   const float* bias;  /* [N] fp32 or NULL */
   int32_t act;
   const float* gamma; /* [N] fp32 or NULL: per-column scale applied after act (LayerScale) */
+  const float* row_scale; int32_t rs_rows; /* optional per-row-block scale v *= row_scale[m / rs_rows] (DropPath) */
   const void* residual; int64_t ldr; /* added last, NULL for none; may alias C */
   int32_t store_mode;
   int32_t ps_H, ps_W, ps_C; /* pixel-shuffle geometry: input grid H x W, Cout */
@@ -100,15 +101,17 @@ typedef struct {
 int du_gemm(const du_gemm_args* args, void* stream);
 
 /* ---- ViT attention -------------------------------------------------------------------------- */
-/* qkv: (B, N, 3, H, Dh) as produced by the fused QKV GEMM.  Writes q (pre-scaled by `qscale`), k, v as
-   (B, H, N, Dh) contiguous; RoPE (rotate-half form, fp32 math) is applied to q and k for tokens >= prefix
-   using sin/cos tables (N - prefix, Dh) fp32. */
+/* qkv: (B, N, 3, H, Dh) as produced by the fused QKV GEMM.  Writes q (scaled by `qscale`), k, v as
+   (B, H, Npad, Dh) (rows >= N untouched: the caller zero-fills once); RoPE (rotate-half form, fp32 math) is
+   applied to q and k for tokens >= prefix using sin/cos tables (N - prefix, Dh) fp32. */
 int du_qkv_rope_split(int dtype, const void* qkv, void* q, void* k, void* v, const float* sin_t, const float* cos_t,
-                      int B, int N, int H, int Dh, int prefix, float qscale, void* stream);
-/* Non-causal softmax(q k^T) v per (b, head); q is expected pre-scaled (scores are used as-is).
-   q,k,v: (B, H, N, Dh) bf16; out: (B, N, H*Dh) bf16.  Dh in {64, 128}. */
-int du_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int N, int Dh, void* stream);
-/* row softmax over the last dim of a (rows, cols) fp32 matrix, in place (parity-mode attention). */
+                      int B, int N, int Npad, int H, int Dh, int prefix, float qscale, void* stream);
+/* Non-causal softmax2(q k^T) v per (b, head) with base-2 exponentials: q must be pre-scaled by
+   Dh^-0.5 * log2(e).  q,k,v: (B, H, Npad, Dh) bf16; out: (B, N, H*Dh) bf16.  Dh in {64, 128}. */
+int du_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int N, int Npad, int Dh,
+                     void* stream);
+/* row softmax over the first `cols` entries of each row of a (rows, ld) fp32 matrix, in place; entries
+   [cols, ld) are zeroed (parity-mode attention with materialised scores). */
 int du_softmax_rows_f32(float* x, int64_t rows, int cols, int64_t ld, void* stream);
 
 /* ---- LayerNorm -------------------------------------------------------------------------------- */
@@ -128,7 +131,7 @@ int du_norm_act_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy,
 int du_norm_act_bwd_stats(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* mean,
                           const float* rstd, const float* w, const float* b, float* bsums, int G, int64_t pix_per_group,
                           int C, int act, void* stream);
-/* backward pass 2: dx = w*rstd*(dz - s1/n - xhat*s2/n) with (s1,s2) from bsums and n = `count` (pixels the
+/* backward pass 2: dx = w*rstd*(dz - s1/n - xhat*s2/n) with (s1,s2) from bsums (G,C,2) and n = `count` (pixels the
    statistics were taken over: pix_per_group for IN, all pixels x world for BN).  use_batch_stats=0 => dx = dz*w*rstd */
 int du_norm_act_bwd_dx(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx,
                        const float* mean, const float* rstd, const float* w, const float* b, const float* bsums, int G,
@@ -148,19 +151,31 @@ int du_msda_backward(int dtype, const void* value, const int64_t* spatial_shapes
                      float* grad_sampling_loc, float* grad_attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
                      void* stream);
 
-/* ---- small conv-side ops (NHWC) ------------------------------------------------------------------- */
-int du_dwconv3x3_fwd(int dtype, const void* x, int64_t ldx, const float* w /*(C,3,3)*/, const float* bias, void* y,
-                     int64_t ldy, int B, int H, int W, int C, void* stream);
-int du_dwconv3x3_bwd_data(int dtype, const void* dy, int64_t lddy, const float* w, void* dx, int64_t lddx, int B, int H,
-                          int W, int C, void* stream);
-int du_dwconv3x3_bwd_weight(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, float* dw /*(C,9)*/,
-                            float* db, int B, int H, int W, int C, void* stream);
-int du_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream);
-int du_maxpool3x3s2_bwd(int dtype, const void* x, const void* y, const void* dy, void* dx /* zero-filled fp32? no: same dtype */,
-                        int B, int H, int W, int C, void* stream);
-/* out[b,y,x,:] = base[b,y,x,:] + bilinear(src)[b,y,x,:]  (align_corners=False), src (B,Hs,Ws,C), out/base (B,Ho,Wo,C) */
-int du_bilinear_add_fwd(int dtype, const void* src, const void* base, void* out, int B, int Hs, int Ws, int Ho, int Wo,
-                        int C, void* stream);
+/* MSDeformAttn glue (ms_deform_attn.py:188-197, single level): raw (rows, M*P*2 + M*P) = [offsets | logits] from the
+   fused sampling_offsets/attention_weights GEMM; ref (Lq, 2) reference points (x, y);
+   loc (rows, M, P, 2) = ref + off / (Ws, Hs); attn (rows, M, P) = softmax over P. */
+int du_msda_prep(int dtype, const void* raw, int64_t ldr, const float* ref, float* loc, float* attn, int64_t rows, int Lq,
+                 int M, int P, int Hs, int Ws, void* stream);
+int du_msda_prep_bwd(int dtype, const float* attn, const float* gloc, const float* gattn, void* graw, int64_t ldr,
+                     int64_t rows, int M, int P, int Hs, int Ws, void* stream);
+
+/* ---- small conv-side ops (NHWC; `*bs` = per-image stride in elements so token ranges can be viewed as images) ---- */
+/* y = act(dwconv3x3(x) + bias); z (nullable) receives the pre-activation. w: (C,3,3) fp32. */
+int du_dwconv3x3_fwd(int dtype, const void* x, int64_t ldx, int64_t xbs, const float* w, const float* bias, void* y,
+                     int64_t ldy, int64_t ybs, void* z, int B, int H, int W, int C, int act, void* stream);
+int du_dwconv3x3_bwd_data(int dtype, const void* dy, int64_t lddy, int64_t dybs, const float* w, void* dx, int64_t lddx,
+                          int64_t dxbs, int B, int H, int W, int C, void* stream);
+/* dw (C,9) and db (C, nullable) accumulate with atomics into zero-filled fp32 buffers */
+int du_dwconv3x3_bwd_weight(int dtype, const void* x, int64_t ldx, int64_t xbs, const void* dy, int64_t lddy, int64_t dybs,
+                            float* dw, float* db, int B, int H, int W, int C, void* stream);
+/* MaxPool2d(3, 2, 1) on contiguous NHWC; idx (nullable, same shape as y, uint8) records the winning tap */
+int du_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
+int du_maxpool3x3s2_bwd(int dtype, const uint8_t* idx, const void* dy, void* dx, int B, int H, int W, int C, void* stream);
+/* out = base + bilinear_upsample(src) (align_corners=False); src (B,Hs,Ws,C) of src_dtype, base/out (B,Ho,Wo,C) */
+int du_bilinear_add_fwd(int src_dtype, int dtype, const void* src, int64_t lds_, const void* base, int64_t ldb, void* out,
+                        int64_t ldo, int B, int Hs, int Ws, int Ho, int Wo, int C, void* stream);
+/* dz = dy * act'(z) */
+int du_act_bwd(int dtype, const void* z, const void* dy, void* dz, int64_t n, int act, void* stream);
 
 /* ---- elementwise helpers --------------------------------------------------------------------------- */
 int du_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

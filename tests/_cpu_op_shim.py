@@ -1,0 +1,170 @@
+"""TEST INFRASTRUCTURE: torch-CPU stand-ins for every function of `dinounet_amd.ops`, with the same signatures and
+layouts (NHWC / token-major).  Monkey-patched in by the `-m "not gpu"` host-logic tests so the product's Python glue
+(views, strides, weight packing order, module wiring, autograd plumbing) can be checked against the golden fixtures
+without a GPU.  The product never imports this file; on a GPU box the real ops call libdinounet_hip.so.
+"""
+import contextlib
+import math
+
+import torch
+import torch.nn.functional as F
+
+from dinounet_amd import ops
+from dinounet_amd._lib import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU
+
+
+def _act(x, act):
+    return {ACT_NONE: lambda t: t, ACT_GELU: F.gelu, ACT_RELU: F.relu, ACT_LEAKY: lambda t: F.leaky_relu(t, 0.01)}[act](x)
+
+
+def mm(x, w, *, out=None, out_dtype=None, bias=None, act=ACT_NONE, gamma=None, residual=None, row_scale=None, rs_rows=0, alpha=1.0):
+    y = (x.float() @ w.float().t()) * alpha
+    if bias is not None:
+        y = y + bias
+    y = _act(y, act)
+    if gamma is not None:
+        y = y * gamma
+    if row_scale is not None:
+        y = (y.view(row_scale.numel(), rs_rows, -1) * row_scale.view(-1, 1, 1)).view(y.shape)
+    if residual is not None:
+        y = y + residual.float()
+    od = out_dtype or (out.dtype if out is not None else x.dtype)
+    if out is not None:
+        out.copy_(y.to(od))
+        return out
+    return y.to(od)
+
+
+def linear(x, w, bias=None, residual=None, row_scale=None, rs_rows=0, out_dtype=None):
+    y = F.linear(x, w.to(x.dtype), None if bias is None else bias.to(x.dtype))
+    if row_scale is not None:
+        y = y * row_scale.view(-1, *([1] * (y.dim() - 1))).to(y.dtype)
+    if residual is not None:
+        y = y + residual
+    return y.to(out_dtype) if out_dtype is not None else y
+
+
+def conv1x1(x, w, bias=None, out_dtype=None):
+    return linear(x, w.view(w.shape[0], -1), bias, out_dtype=out_dtype)
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def conv2d(x, w, bias=None, stride=1, pad=1, x2=None):
+    xin = x if x2 is None else torch.cat([x, x2], -1)
+    return _nhwc(F.conv2d(_nchw(xin), w.to(x.dtype), None if bias is None else bias.to(x.dtype), stride, pad))
+
+
+def conv_transpose2x2(x, w, bias=None):
+    return _nhwc(F.conv_transpose2d(_nchw(x), w.to(x.dtype), None if bias is None else bias.to(x.dtype), stride=2))
+
+
+def norm_act(x, w, b, kind, act=ACT_NONE, eps=1e-5, training=True, running_mean=None, running_var=None, momentum=0.1, group=None):
+    xc = _nchw(x).float()
+    if kind == "in":
+        y = F.instance_norm(xc, None, None, w, b, True, 0.0, eps)
+    elif training:
+        y = F.batch_norm(xc, running_mean, running_var, w, b, True, momentum, eps)
+    else:
+        y = F.batch_norm(xc, running_mean, running_var, w, b, False, 0.0, eps)
+    return _act(_nhwc(y), act).to(x.dtype)
+
+
+def layer_norm(x, w, b, eps):
+    return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps).to(x.dtype)
+
+
+def layernorm_raw(x2d, w, b, eps, out_dtype, want_stats=False):
+    return F.layer_norm(x2d.float(), (x2d.shape[-1],), w, b, eps).to(out_dtype), None, None
+
+
+def msda_prep(raw, ref, Lq, M, P, Hs, Ws):
+    rows = raw.shape[0]
+    off = raw[:, :M * P * 2].float().view(rows, M, P, 2)
+    logit = raw[:, M * P * 2:].float().view(rows, M, P)
+    r = ref.repeat(rows // Lq, 1).view(rows, 1, 1, 2)
+    loc = r + off / torch.tensor([float(Ws), float(Hs)])
+    return loc, F.softmax(logit, -1)
+
+
+def msda(value, shapes, lsi, loc, attn):
+    from oracle.dinounet_oracle import msda_core
+    return msda_core(value.float(), shapes.tolist(), loc.float(), attn.float()).to(value.dtype)
+
+
+def dwconv3x3(x, w, bias=None, act=ACT_NONE):
+    C = x.shape[-1]
+    return _act(_nhwc(F.conv2d(_nchw(x), w.to(x.dtype), None if bias is None else bias.to(x.dtype), 1, 1, groups=C)), act)
+
+
+def dwconv_tokens(x, w, bias, H, W, act=ACT_GELU):
+    B, N, C = x.shape
+    n = N // 21
+    outs = []
+    for (lo, hi, h, ww) in ((0, 16 * n, 2 * H, 2 * W), (16 * n, 20 * n, H, W), (20 * n, N, H // 2, W // 2)):
+        outs.append(dwconv3x3(x[:, lo:hi].reshape(B, h, ww, C), w, bias, act).reshape(B, -1, C))
+    return torch.cat(outs, 1)
+
+
+def maxpool3x3s2(x):
+    return _nhwc(F.max_pool2d(_nchw(x), 3, 2, 1))
+
+
+def bilinear_add(src, base):
+    up = F.interpolate(_nchw(src).float(), size=(base.shape[1], base.shape[2]), mode="bilinear", align_corners=False)
+    return base + _nhwc(up).to(base.dtype)
+
+
+def nchw_to_nhwc(x, dt, cpad=None):
+    y = x.float().permute(0, 2, 3, 1)
+    if cpad and cpad > y.shape[-1]:
+        y = F.pad(y, (0, cpad - y.shape[-1]))
+    return y.contiguous().to(dt)
+
+
+def nhwc_to_nchw_f32(x):
+    return x.permute(0, 3, 1, 2).float().contiguous()
+
+
+def patchify16(x, dt):
+    B, C, H, W = x.shape
+    return F.unfold(x.float(), 16, stride=16).transpose(1, 2).reshape(-1, C * 256).to(dt)
+
+
+def cast(x, dt):
+    return x.to(dt)
+
+
+def attention(qkv, sin, cos, B, N, H, Dh, prefix, workspace):
+    q, k, v = [t.transpose(1, 2) for t in qkv.float().view(B, N, 3, H, Dh).unbind(2)]
+
+    def rope(t):
+        a = t[:, :, prefix:]
+        x1, x2 = a.chunk(2, -1)
+        return torch.cat([t[:, :, :prefix], a * cos + torch.cat([-x2, x1], -1) * sin], 2)
+
+    o = F.scaled_dot_product_attention(rope(q), rope(k), v)
+    return o.transpose(1, 2).reshape(B * N, H * Dh).to(qkv.dtype)
+
+
+_NAMES = ["mm", "linear", "conv1x1", "conv2d", "conv_transpose2x2", "norm_act", "layer_norm", "layernorm_raw", "msda_prep", "msda",
+          "dwconv3x3", "dwconv_tokens", "maxpool3x3s2", "bilinear_add", "nchw_to_nhwc", "nhwc_to_nchw_f32", "patchify16", "cast",
+          "attention"]
+
+
+@contextlib.contextmanager
+def patched_ops():
+    saved = {n: getattr(ops, n) for n in _NAMES}
+    try:
+        for n in _NAMES:
+            setattr(ops, n, globals()[n])
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(ops, n, f)
