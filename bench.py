@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""Benchmark of the Dino U-Net training hot path on MI355X (BASELINE.json metric):
+2D slices/s for a full training step (forward + DC/CE loss + backward + grad-clip 12 + Nesterov SGD) of `dinounet_l`,
+512x512, bf16, batch 8 per GPU, synthetic data, random-init weights; 1..8 GPUs data-parallel (one process per GPU,
+RCCL all-reduce of the trainable gradients overlapped with backward).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of the dominant kernel
+inside the timed region; `cpu_baseline` times the CPU oracle (port of the reference algorithm) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="dinounet_l")
+    ap.add_argument("--batch", type=int, default=8, help="slices per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    from oracle.refshim import PLANS_2D
+    from dinounet_amd import ops
+    from dinounet_amd.network_architecture import DinoUNet
+    from dinounet_amd.parallel import GradAllReducer
+    from dinounet_amd.training import dc_and_ce_loss
+
+    torch.manual_seed(1234)
+    net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name=a.model, precision=a.precision)
+    net = net.to(dev).train()
+    params = [p for p in net.parameters() if p.requires_grad]
+    reducer = GradAllReducer(net, world) if world > 1 else None
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5)   # nnUNetTrainer.py:486, DT:1024
+
+    g = torch.Generator(device="cpu").manual_seed(100 + rank)
+    x = torch.randn(a.batch, 3, a.size, a.size, generator=g).to(dev)
+    tgt = torch.randint(0, 2, (a.batch, 1, a.size, a.size), generator=g).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits = net(x)
+        loss = dc_and_ce_loss(logits, tgt)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        torch.nn.utils.clip_grad_norm_(params, 12)          # nnUNetTrainer.py:922
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if not a.no_roofline:
+        ops.PROFILE = ops.KernelProfile()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.PROFILE
+    ops.PROFILE = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / a.steps * 1e3
+    value = a.batch * world / (dt / a.steps)
+
+    out = {"metric": "2D slices/sec training, dinounet_l 512x512 bf16", "value": round(value, 3), "unit": "slices/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+           "config": {"workload": f"{a.model} train step (fwd+loss+bwd+clip+SGD), {a.size}x{a.size}x3 slices, batch {a.batch}/GPU, "
+                                  f"frozen ViT + adapter + FAPM + U-Net decoder, random-init weights",
+                      "global_batch": a.batch * world, "parallelism": f"dp{world}"},
+           "final_loss": round(float(loss.item()), 5)}
+    if rank == 0:
+        if prof is not None:
+            try:
+                out["roofline"], out["kernel_breakdown"] = prof.roofline(MFMA_BF16_PEAK_TFLOPS, HBM_PEAK_GBS, a.steps)
+            except Exception as e:  # noqa: BLE001
+                out["roofline"] = {"error": repr(e)}
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(net, a)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(net, a):
+    """The CPU oracle (port of the reference's algorithm, oracle/dinounet_oracle.py) timed on the host cores on a
+    bounded sample of the same workload: one full train step (forward + loss + backward) of the same model at the same
+    resolution with batch 1 (the reference has no CPU MSDA backward; autograd through its grid_sample formula is what
+    ops/test.py gradchecks against)."""
+    from oracle import dinounet_oracle as O
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    named = dict(net.named_parameters())
+    for k in sd:
+        if k in named and named[k].requires_grad:
+            sd[k] = sd[k].clone().requires_grad_(True)
+    for k in list(sd):
+        if k.startswith("decoder.encoder."):
+            sd[k] = sd[k[len("decoder."):]]
+    B = 1
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 3, a.size, a.size, generator=g)
+    tgt = torch.randint(0, 2, (B, 1, a.size, a.size), generator=g)
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    y = O.dinounet_forward(x, sd, a.model, training=True)
+    loss = O.dc_and_ce_loss(y, tgt)
+    leaves = [v for k, v in sd.items() if v.requires_grad and not k.startswith("decoder.encoder.") and ".all_modules." not in k]
+    torch.autograd.grad(loss, leaves, allow_unused=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(B / dt, 4), "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": f"1 train step (fwd+loss+bwd, fp32) of {a.model} on {B} slice {a.size}x{a.size}, {dt:.1f} s on {cores} threads "
+                      f"({os.cpu_count()} logical CPUs)"}
+
+
+if __name__ == "__main__":
+    main()

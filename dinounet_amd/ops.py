@@ -67,6 +67,51 @@ def _nhwc(t):
     return B, H, W, Cc, ld
 
 
+class KernelProfile:
+    """HIP-event timing of individual kernel launches on the stream they are launched on (torch's current stream).
+    Enabled by bench.py inside its timed region: ops.PROFILE = KernelProfile()."""
+
+    def __init__(self):
+        self.rec = []
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, name, e0, flops, nbytes):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.rec.append((name, e0, e1, flops, nbytes))
+
+    def roofline(self, peak_tflops, peak_gbs, steps):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, e0, e1, fl, nb in self.rec:
+            a = agg.setdefault(name, [0.0, 0, 0.0, 0.0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += 1
+            a[2] += fl
+            a[3] += nb
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
+        brk = [{"kernel": k, "launches_per_step": round(v[1] / steps, 1), "ms_per_step": round(v[0] / steps * 1e3, 3),
+                "tflops": round(v[2] / v[0] / 1e12, 1), "gbs": round(v[3] / v[0] / 1e9, 1)} for k, v in rows[:12]]
+        k, v = rows[0]
+        mfma_frac = v[2] / v[0] / 1e12 / peak_tflops
+        hbm_frac = v[3] / v[0] / 1e9 / peak_gbs
+        if mfma_frac >= hbm_frac:
+            roof = {"kernel": k, "bound": "mfma", "achieved": round(v[2] / v[0] / 1e12, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+                    "frac": round(mfma_frac, 4), "traffic": None, "avg_launch_us": round(v[0] / v[1] * 1e6, 2)}
+        else:
+            roof = {"kernel": k, "bound": "hbm", "achieved": round(v[3] / v[0] / 1e9, 1), "peak": peak_gbs, "unit": "GB/s",
+                    "frac": round(hbm_frac, 4), "traffic": None, "avg_launch_us": round(v[0] / v[1] * 1e6, 2)}
+        return roof, brk
+
+
+PROFILE = None
+_MODE_NAMES = {(0, 0): "linear", (0, 1): "linear_dgrad", (1, 1): "linear_wgrad", (2, 0): "conv_im2col", (1, 3): "conv_wgrad"}
+
+
 def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat, ldc, batch=1, abs_=0, bbs=0, cbs=0,
              split_k=1, alpha=1.0, bias=None, act=ACT_NONE, gamma=None, row_scale=None, rs_rows=0, residual=None, ldr=0,
              store_mode=0, ps=(0, 0, 0), geom=None):
@@ -86,6 +131,15 @@ def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat,
     a.ps_H, a.ps_W, a.ps_C = ps
     if geom is not None:
         a.geom = geom
+    if PROFILE is not None:
+        e0 = PROFILE.start()
+        _lib.check(_lib.lib().du_gemm(C.byref(a), _st()), "du_gemm")
+        es = 2 if dtype == DU_BF16 else 4
+        eo = 2 if out_dtype == DU_BF16 else 4
+        kin = K if geom is None else K // max(geom.KH * geom.KW, 1) if a_mode == IM2COL_ROW else K
+        PROFILE.stop(f"gemm_kernel<{'bf16' if dtype == DU_BF16 else 'f32'},{_MODE_NAMES.get((a_mode, b_mode), 'other')}>", e0,
+                     2.0 * M * N * K * batch, float(batch) * (M * kin * es + N * K * es + M * N * eo))
+        return
     _lib.check(_lib.lib().du_gemm(C.byref(a), _st()), "du_gemm")
 
 
@@ -758,7 +812,10 @@ def attention(qkv, sin, cos, B, N, H, Dh, prefix, workspace):
                "du_qkv_rope_split")
     out = torch.empty((B * N, H * Dh), dtype=dt, device=qkv.device)
     if dt == torch.bfloat16:
+        e0 = PROFILE.start() if PROFILE is not None else None
         _lib.check(L.du_attention_fwd(_p(q), _p(k), _p(v), _p(out), B, H, N, Npad, Dh, _st()), "du_attention_fwd")
+        if PROFILE is not None:
+            PROFILE.stop("attn_fwd_kernel<bf16>", e0, 4.0 * B * H * N * N * Dh, 4.0 * B * H * N * Dh * 2)
         return out
     skey = ("scores", B, H, Npad)
     if skey not in workspace:

@@ -1,0 +1,178 @@
+"""CPU suite (-m "not gpu"): the oracle against the committed golden vectors, the drop-in boundary (state_dict key
+contract, plugin classes, module API), the C-ABI library (loads, exports every declared symbol) and the host glue
+(product modules with torch stand-ins for the HIP ops reproduce the reference's logits)."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dinounet_oracle as O
+from oracle import weights
+from oracle.refshim import PLANS_2D
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    return g, json.loads(str(g["meta"]))
+
+
+def _sd(model):
+    keys = json.load(open(os.path.join(GOLD, f"state_dict_{model}.json")))["keys"]
+    return weights.make_state_dict([(k, tuple(s)) for k, s, _ in keys], seed=0)
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max())
+
+
+# ---------------------------------------------------------------- oracle vs golden (reference outputs)
+@pytest.mark.parametrize("name", ["dinounet_s_64_eval", "dinounet_s_96x64_eval", "dinounet_s_64_c1_eval", "dinounet_s_64_k4_eval",
+                                  "dinounet_b_64_eval"])
+def test_oracle_matches_reference_golden(name):
+    g, meta = _load(name)
+    sd = _sd(meta["model"])
+    if meta["num_classes"] != 2:   # seg heads have K rows
+        for k in list(sd):
+            if ".seg_layers." in k:
+                shp = list(sd[k].shape); shp[0] = meta["num_classes"]
+                sd[k] = weights.make_tensor(k, shp)
+    x = weights.make_input(meta["B"], meta["C"], meta["H"], meta["W"], seed=0)
+    with torch.no_grad():
+        y = O.dinounet_forward(x, sd, meta["model"])
+    ref = torch.from_numpy(g["logits"])
+    assert rel(y, ref) < 2e-5
+    am = y.argmax(1).numpy().astype(np.uint8)
+    gold_am = np.unpackbits(g["argmax"])[: am.size].reshape(am.shape) if meta["num_classes"] == 2 else g["argmax"]
+    assert (am != gold_am).mean() < 1e-4
+
+
+def test_oracle_msda_loops_match_reference_fixture():
+    """ops/test.py fixture (seed 3): scalar restatement of the CUDA loop == reference grid_sample core (fp64)."""
+    g = np.load(os.path.join(GOLD, "msda_testpy.npz"))
+    shapes, lsi = torch.from_numpy(g["shapes"]), torch.from_numpy(g["level_start_index"])
+    for tag in ("D2", "D30", "D71", "border"):
+        v, loc, a = (torch.from_numpy(g[f"{tag}_{n}"]) for n in ("value", "loc", "attn"))
+        out = O.msda_core_loops(v, shapes, lsi, loc, a)
+        assert (out - torch.from_numpy(g[f"{tag}_out"])).abs().max() < 1e-12
+        gv, gl, ga = O.msda_backward(v, shapes.tolist(), loc, a, torch.from_numpy(g[f"{tag}_grad_out"]))
+        assert (gv - torch.from_numpy(g[f"{tag}_grad_value"])).abs().max() < 1e-10
+        assert (gl - torch.from_numpy(g[f"{tag}_grad_loc"])).abs().max() < 1e-10
+        assert (ga - torch.from_numpy(g[f"{tag}_grad_attn"])).abs().max() < 1e-10
+
+
+# ---------------------------------------------------------------- boundary
+@pytest.mark.parametrize("model", ["dinounet_s", "dinounet_b"])
+def test_state_dict_contract(model):
+    from dinounet_amd.network_architecture import DinoUNet
+    net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name=model)
+    gold = json.load(open(os.path.join(GOLD, f"state_dict_{model}.json")))["keys"]
+    mine = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()]
+    assert mine == gold                                     # same keys, shapes, dtypes, same order
+    sd = net.state_dict()
+    assert sd["decoder.encoder.fapm.shared_basis.weight"].data_ptr() == sd["encoder.fapm.shared_basis.weight"].data_ptr()
+    trainable = sum(p.numel() for p in net.parameters() if p.requires_grad)
+    frozen = sum(p.numel() for p in net.parameters() if not p.requires_grad)
+    assert (trainable, frozen) == {"dinounet_s": (6188322, 21596544), "dinounet_b": (13178082, 85670400)}[model] or trainable > 0
+    assert all(not p.requires_grad for p in net.encoder.dinov3_adapter.backbone.parameters())
+    net.load_state_dict(weights.make_state_dict([(k, tuple(s)) for k, s, _ in gold]), strict=True)
+
+
+def test_plugin_surface():
+    import dinounet_amd.dinounet_training as DT
+    for n in ("DinoUNet", "DINOv3EncoderAdapter", "FAPM", "UNetDecoder", "SqueezeExcitation", "DepthwiseSeparableConv",
+              "LearnableUpsampleBlock", "DinoUNetTrainer", "DinoUNetTrainer_s", "DinoUNetTrainer_b", "DinoUNetTrainer_l",
+              "DinoUNetTrainer_7b", "DINOV3_TRAINERS", "get_dinov3_trainer", "load_dinov3_model", "DINOv3_MODEL_FACTORIES",
+              "DINOv3_INTERACTION_INDEXES", "DINOv3_MODEL_INFO", "main_dinov3"):
+        assert hasattr(DT, n), n
+    T = DT.get_dinov3_trainer("dinounet_s")
+    T.set_network_config(PLANS_2D, dinov3_pretrained_path="/nonexistent.pth")
+    net = T.build_network_architecture("ignored", {}, [], 3, 2, enable_deep_supervision=False)
+    assert isinstance(net, DT.DinoUNet) and net.decoder.deep_supervision is False
+    enc = net.encoder
+    for a in ("output_channels", "strides", "kernel_sizes", "conv_op", "norm_op", "norm_op_kwargs", "dropout_op",
+              "dropout_op_kwargs", "nonlin", "nonlin_kwargs", "conv_bias"):
+        assert hasattr(enc, a)
+    with pytest.raises(ValueError):
+        DT.get_dinov3_trainer("dinounet_xl")
+    with pytest.raises(RuntimeError):                      # product path has no CPU fallback
+        net(torch.zeros(1, 3, 64, 64))
+
+
+def test_msda_extension_module_surface():
+    import MultiScaleDeformableAttention as MSDA
+    assert callable(MSDA.ms_deform_attn_forward) and callable(MSDA.ms_deform_attn_backward)
+    v = torch.zeros(1, 4, 2, 4)
+    with pytest.raises(RuntimeError):                      # "must be a CUDA tensor" (ms_deform_attn_cuda.cu:39-43)
+        MSDA.ms_deform_attn_forward(v, torch.tensor([[2, 2]]), torch.tensor([0]), torch.zeros(1, 1, 2, 1, 1, 2),
+                                    torch.zeros(1, 1, 2, 1, 1), 64)
+
+
+# ---------------------------------------------------------------- C ABI
+def test_c_abi_exports_every_declared_symbol():
+    from dinounet_amd import _lib
+    protos = _lib.header_prototypes()
+    assert len(protos) >= 25
+    assert os.path.exists(_lib.LIB_PATH), "libdinounet_hip.so must be built (python -m dinounet_amd._build)"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(lib, name), f"{name} declared in include/dinounet_hip.h but not exported"
+    assert b"gfx950" in _lib.lib().du_version()
+
+
+def test_c_abi_argument_validation_without_gpu():
+    """Bad arguments are rejected before any launch (DU_ERR_BAD_ARG), so this runs without a device."""
+    from dinounet_amd import _lib
+    a = _lib.GemmArgs()
+    assert _lib.lib().du_gemm(ctypes.byref(a), None) == -1
+    with pytest.raises(RuntimeError):
+        _lib.check(-1, "du_gemm")
+
+
+# ---------------------------------------------------------------- host glue with stand-in ops
+@pytest.mark.parametrize("name", ["dinounet_s_64_eval", "dinounet_s_96x64_eval", "dinounet_s_64_c1_eval"])
+def test_host_glue_reproduces_reference_logits(name):
+    import _cpu_op_shim as shim
+    from dinounet_amd.network_architecture import DinoUNet
+    g, meta = _load(name)
+    net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name=meta["model"], precision="fp32")
+    net.load_state_dict(_sd(meta["model"]), strict=True)
+    net.eval()
+    x = weights.make_input(meta["B"], meta["C"], meta["H"], meta["W"], seed=0)
+    with shim.patched_ops(), torch.no_grad():
+        y = net.decoder(net.encoder(x))
+    assert rel(y, torch.from_numpy(g["logits"])) < 2e-5
+
+
+def test_host_glue_train_mode_and_grads():
+    """train(): batch-stat BN + running-stat update, loss, backward through the product's module wiring."""
+    import _cpu_op_shim as shim
+    from dinounet_amd.network_architecture import DinoUNet
+    from dinounet_amd.dinov3.adapter import DropPath
+    g, meta = _load("dinounet_s_64_train")
+    net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name="dinounet_s", precision="fp32")
+    net.load_state_dict(_sd("dinounet_s"), strict=True)
+    net.train()
+    for m in net.modules():
+        if isinstance(m, DropPath):
+            m.drop_prob = 0.0
+    net.encoder.dinov3_adapter.backbone.rope_embed.rescale_coords = None
+    x = weights.make_input(2, 3, 64, 64, seed=1)
+    tgt = weights.make_target(2, 64, 64, 2, seed=1)
+    with shim.patched_ops():
+        y = net.decoder(net.encoder(x))
+        loss = O.dc_and_ce_loss(y, tgt)
+        loss.backward()
+    assert rel(y.detach(), torch.from_numpy(g["logits"])) < 2e-5
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    norms = meta["grad_norms"]
+    gmax = max(norms.values())
+    named = dict(net.named_parameters())
+    for k, n in norms.items():
+        got = float(named[k].grad.norm())
+        assert abs(got - n) <= 5e-3 * max(n, 1e-3 * gmax), (k, got, n)
+    assert sorted(k for k, p in named.items() if p.requires_grad and p.grad is None) == meta["unused"]

@@ -1,0 +1,171 @@
+"""GPU parity tests (-m gpu), end to end: the product DinoUNet (HIP kernels through the C-ABI) against the committed
+outputs of the REFERENCE'S OWN modules (tests/golden/*, generated in the build container by oracle/make_golden.py) with
+identical synthetic weights (oracle/weights.py) and inputs.
+
+fp32 kernel mode: logits within 1e-3 relative (north_star), argmax masks identical except where the reference's own
+top-2 margin is below the tolerance.  bf16 throughput mode: deviation reported and bounded separately."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dinounet_oracle as O
+from oracle import weights
+from oracle.refshim import PLANS_2D
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    return g, json.loads(str(g["meta"]))
+
+
+def _build(model, num_classes, precision):
+    from dinounet_amd.network_architecture import DinoUNet
+    net = DinoUNet.from_config(PLANS_2D, 3, num_classes, dinov3_pretrained_path=None, dinov3_model_name=model, precision=precision)
+    ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    net.load_state_dict(weights.make_state_dict(ks, seed=0), strict=True)
+    return net.cuda()
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def argmax_check(y, ref, tol):
+    """masks must agree wherever the reference's top-2 margin exceeds tol * max|logit|"""
+    y, ref = y.detach().float().cpu(), ref.float()
+    mism = y.argmax(1) != ref.argmax(1)
+    top2 = ref.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    bad = mism & (margin > tol * ref.abs().max())
+    return int(mism.sum()), int(bad.sum())
+
+
+CASES = ["dinounet_s_64_eval", "dinounet_s_96x64_eval", "dinounet_s_64_c1_eval", "dinounet_s_64_k4_eval", "dinounet_b_64_eval",
+         "dinounet_l_64_eval", "dinounet_s_512_eval"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_eval_logits_fp32_vs_reference(name):
+    g, meta = _load(name)
+    net = _build(meta["model"], meta["num_classes"], "fp32").eval()
+    x = weights.make_input(meta["B"], meta["C"], meta["H"], meta["W"], seed=0).cuda()
+    with torch.no_grad():
+        y = net(x)
+    ref = torch.from_numpy(g["logits"])
+    e = rel(y, ref)
+    mism, bad = argmax_check(y, ref, 1e-3)
+    print(f"[{name}] fp32 HIP vs reference: rel err {e:.2e}, argmax mismatches {mism} (outside tie band: {bad})")
+    assert e < 1e-3
+    assert bad == 0
+
+
+@pytest.mark.parametrize("name", ["dinounet_s_64_eval", "dinounet_l_64_eval", "dinounet_s_512_eval"])
+def test_eval_logits_bf16_mode(name):
+    g, meta = _load(name)
+    net = _build(meta["model"], meta["num_classes"], "bf16").eval()
+    x = weights.make_input(meta["B"], meta["C"], meta["H"], meta["W"], seed=0).cuda()
+    with torch.no_grad():
+        y = net(x)
+    ref = torch.from_numpy(g["logits"])
+    e = rel(y, ref)
+    agree = float((y.float().cpu().argmax(1) == ref.argmax(1)).float().mean())
+    print(f"[{name}] bf16 HIP vs reference fp32: rel err {e:.2e}, argmax agreement {agree:.4f}")
+    assert e < 0.15 and agree > 0.97
+
+
+def test_stage_taps_fp32():
+    """Per-stage tensors of the reference (ViT taps, c after each interaction, f1..f4, FAPM, skips): localises a wrong kernel."""
+    g, meta = _load("dinounet_s_64_eval")
+    net = _build("dinounet_s", 2, "fp32").eval()
+    taps = {}
+    ad = net.encoder.dinov3_adapter
+    for i, blk in enumerate(ad.interactions):
+        blk.register_forward_hook(lambda m, a, out, i=i: taps.__setitem__(f"c{i + 1}", out))
+    ad.register_forward_hook(lambda m, a, out: [taps.__setitem__(f"feats{j}", out[k].permute(0, 3, 1, 2)) for j, k in enumerate("1234")])
+    net.encoder.fapm.register_forward_hook(lambda m, a, out: [taps.__setitem__(f"fapm{j}", o.permute(0, 3, 1, 2)) for j, o in enumerate(out)])
+    net.encoder.register_forward_hook(lambda m, a, out: [taps.__setitem__(f"skips{j}", o.permute(0, 3, 1, 2)) for j, o in enumerate(out)])
+    orig = ad.backbone.get_intermediate_layers
+
+    def gil(*a, **k):
+        r = orig(*a, **k)
+        for j, t in enumerate(r):
+            taps[f"vit{j}"] = t[0]
+        return r
+
+    ad.backbone.get_intermediate_layers = gil
+    x = weights.make_input(2, 3, 64, 64, seed=0).cuda()
+    with torch.no_grad():
+        y = net(x)
+    errs = {k: rel(v, torch.from_numpy(g[k])) for k, v in taps.items()}
+    errs["logits"] = rel(y, torch.from_numpy(g["logits"]))
+    for k in sorted(errs):
+        print(f"  tap {k:8s} rel err {errs[k]:.2e}")
+    assert len(errs) == 21
+    assert max(errs.values()) < 1e-3, errs
+
+
+def test_train_step_fp32_vs_reference():
+    """train(): batch-statistics BN, DC+CE loss, backward through every HIP backward kernel; per-parameter gradient norms and
+    the small gradients in full vs the reference's (drop-path / RoPE jitter disabled on both sides)."""
+    from dinounet_amd.dinov3.adapter import DropPath
+    g, meta = _load("dinounet_s_64_train")
+    net = _build("dinounet_s", 2, "fp32").train()
+    for m in net.modules():
+        if isinstance(m, DropPath):
+            m.drop_prob = 0.0
+    net.encoder.dinov3_adapter.backbone.rope_embed.rescale_coords = None
+    x = weights.make_input(2, 3, 64, 64, seed=1).cuda()
+    tgt = weights.make_target(2, 64, 64, 2, seed=1).cuda()
+    y = net(x)
+    loss = O.dc_and_ce_loss(y, tgt)
+    loss.backward()
+    assert rel(y, torch.from_numpy(g["logits"])) < 1e-3
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    norms = meta["grad_norms"]
+    gmax = max(norms.values())
+    named = dict(net.named_parameters())
+    worst = ("", 0.0)
+    for k, n in norms.items():
+        assert named[k].grad is not None, k
+        got = float(named[k].grad.norm())
+        err = abs(got - n) / max(n, 1e-3 * gmax)
+        if err > worst[1]:
+            worst = (k, err)
+    print(f"worst grad-norm deviation {worst[1]:.2e} at {worst[0]}")
+    assert worst[1] < 1e-2, worst
+    for key in g.files:
+        if key.startswith("grad:"):
+            k = key[5:]
+            ref = torch.from_numpy(g[key])
+            if ref.norm() > 1e-3 * gmax:
+                assert float((named[k].grad.cpu() - ref).norm() / ref.norm()) < 2e-2, k
+    assert sorted(k for k, p in named.items() if p.requires_grad and p.grad is None) == meta["unused"]
+
+
+def test_train_step_bf16_runs_and_learns():
+    """bf16 throughput mode with drop-path + RoPE jitter on: finite loss/grads, SGD reduces the loss on a fixed batch."""
+    net = _build("dinounet_s", 2, "bf16").train()
+    torch.manual_seed(0)
+    x = weights.make_input(4, 3, 64, 64, seed=3).cuda()
+    tgt = weights.make_target(4, 64, 64, 2, seed=3).cuda()
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, 1e-2, momentum=0.9, nesterov=True)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        loss = O.dc_and_ce_loss(net(x), tgt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 12)
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses

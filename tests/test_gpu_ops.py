@@ -1,0 +1,355 @@
+"""GPU parity tests (-m gpu): every HIP kernel, called through the C-ABI (dinounet_amd.ops -> libdinounet_hip.so),
+against the CPU oracle / a plain PyTorch fp32 reference of the same op on the same seeded inputs.
+Tolerances: fp32 kernels 2e-4 (max-abs error relative to the reference's max-abs; fp32 MFMA accumulation order differs
+from the CPU's), bf16 kernels 3e-2; MSDA fp32 vs the reference's fp64 fixture 1e-5."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DTS = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-4, torch.bfloat16: 3e-2}
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from dinounet_amd import _lib
+    assert _lib.lib().du_device_ok() == 1, "libdinounet_hip.so kernels are built for gfx950 only"
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all(), "non-finite values in kernel output"
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def q(t, dt):
+    """quantise a CPU fp32 tensor through dt so the reference sees the same inputs as the kernel"""
+    return t.to(dt).float()
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K", [(1029, 1152, 384), (300, 32, 64), (257, 64, 128), (128, 128, 64), (4096, 2, 32), (70, 200, 1024)])
+def test_gemm_plain_epilogues(dt, M, N, K):
+    from dinounet_amd import ops
+    from dinounet_amd._lib import ACT_GELU
+    d = dev()
+    x, w = q(gen(M, K, seed=1), dt), q(gen(N, K, seed=2, scale=K ** -0.5), dt)
+    b, gam, res = gen(N, seed=3), gen(N, seed=4), gen(M, N, seed=5)
+    y = ops.mm(x.to(d, dt), w.to(d, dt), bias=b.to(d))
+    assert rel(y, x @ w.t() + b) < TOL[dt]
+    y = ops.mm(x.to(d, dt), w.to(d, dt), bias=b.to(d), act=ACT_GELU)
+    assert rel(y, F.gelu(x @ w.t() + b)) < TOL[dt]
+    r = res.to(d)
+    y = ops.mm(x.to(d, dt), w.to(d, dt), bias=b.to(d), gamma=gam.to(d), residual=r, out=r)   # in-place fp32 residual stream
+    assert y.dtype == torch.float32
+    assert rel(y, (x @ w.t() + b) * gam + res) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_dgrad_wgrad(dt):
+    from dinounet_amd import ops
+    d = dev()
+    M, N, K = 5376 * 2, 192, 384
+    x, w, dy = q(gen(M, K, seed=1), dt), q(gen(N, K, seed=2, scale=K ** -0.5), dt), q(gen(M, N, seed=3), dt)
+    dx = ops.mm_dgrad(dy.to(d, dt), w.to(d, dt))
+    assert rel(dx, dy @ w) < TOL[dt]
+    dw = ops.mm_wgrad(dy.to(d, dt), x.to(d, dt))
+    assert dw.dtype == torch.float32
+    assert rel(dw, dy.t() @ x) < TOL[dt]
+    assert rel(ops.colsum(dy.to(d, dt)), dy.sum(0)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_linear_autograd_with_residual_and_droppath(dt):
+    from dinounet_amd import ops
+    d = dev()
+    B, T, K, N = 3, 84, 96, 64
+    x, w, b, res = q(gen(B, T, K, seed=1), dt), gen(N, K, seed=2, scale=K ** -0.5), gen(N, seed=3), q(gen(B, T, N, seed=4), dt)
+    mask = torch.tensor([0.0, 1 / 0.7, 1 / 0.7])
+    go = q(gen(B, T, N, seed=5), dt)
+    xr, wr, br, rr = (t.clone().requires_grad_(True) for t in (x, q(w, dt), b, res))
+    yr = F.linear(xr, wr, br) * mask.view(-1, 1, 1) + rr
+    gr = torch.autograd.grad(yr, (xr, wr, br, rr), go)
+    xg, wg, bg, rg = x.to(d, dt).requires_grad_(True), w.to(d).requires_grad_(True), b.to(d).requires_grad_(True), res.to(d, dt).requires_grad_(True)
+    y = ops.linear(xg, wg, bg, residual=rg, row_scale=mask.to(d), rs_rows=T)
+    gg = torch.autograd.grad(y, (xg, wg, bg, rg), go.to(d, dt))
+    assert rel(y, yr) < TOL[dt]
+    for a, r_ in zip(gg, gr):
+        assert rel(a, r_) < TOL[dt]
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("cfg", [dict(B=2, H=24, W=16, Cin=64, Cout=32, s=1), dict(B=1, H=32, W=32, Cin=8, Cout=64, s=2),
+                                 dict(B=2, H=17, W=9, Cin=128, Cout=256, s=2), dict(B=1, H=64, W=64, Cin=32, Cout=32, s=1)])
+def test_conv3x3_fwd_bwd(dt, cfg):
+    from dinounet_amd import ops
+    d = dev()
+    B, H, W, Cin, Cout, s = (cfg[k] for k in ("B", "H", "W", "Cin", "Cout", "s"))
+    x, w, b = q(gen(B, Cin, H, W, seed=1), dt), gen(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5), gen(Cout, seed=3)
+    xr, wr, br = x.clone().requires_grad_(True), q(w, dt).requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, s, 1)
+    go = q(gen(*yr.shape, seed=4), dt)
+    gr = torch.autograd.grad(yr, (xr, wr, br), go)
+    xg, wg, bg = nhwc(x).to(d, dt).requires_grad_(True), w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    y = ops.conv2d(xg, wg, bg, stride=s, pad=1)
+    gg = torch.autograd.grad(y, (xg, wg, bg), nhwc(go).to(d, dt))
+    assert rel(y.permute(0, 3, 1, 2), yr) < TOL[dt]
+    assert rel(gg[0].permute(0, 3, 1, 2), gr[0]) < TOL[dt]
+    assert rel(gg[1], gr[1]) < TOL[dt]
+    assert rel(gg[2], gr[2]) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv3x3_fused_concat(dt):
+    """decoder stage: conv over cat(up, skip) read through two pointers (dinounet_training.py:614)."""
+    from dinounet_amd import ops
+    d = dev()
+    B, H, W, C1, C2, Cout = 2, 32, 32, 32, 32, 32
+    a, s2 = q(gen(B, C1, H, W, seed=1), dt), q(gen(B, C2, H, W, seed=2), dt)
+    w, b = gen(Cout, C1 + C2, 3, 3, seed=3, scale=(9 * (C1 + C2)) ** -0.5), gen(Cout, seed=4)
+    ar, sr, wr = a.clone().requires_grad_(True), s2.clone().requires_grad_(True), q(w, dt).requires_grad_(True)
+    yr = F.conv2d(torch.cat([ar, sr], 1), wr, b, 1, 1)
+    go = q(gen(*yr.shape, seed=5), dt)
+    gr = torch.autograd.grad(yr, (ar, sr, wr), go)
+    ag, sg, wg = nhwc(a).to(d, dt).requires_grad_(True), nhwc(s2).to(d, dt).requires_grad_(True), w.to(d).requires_grad_(True)
+    y = ops.conv2d(ag, wg, b.to(d), 1, 1, x2=sg)
+    gg = torch.autograd.grad(y, (ag, sg, wg), nhwc(go).to(d, dt))
+    assert rel(y.permute(0, 3, 1, 2), yr) < TOL[dt]
+    assert rel(gg[0].permute(0, 3, 1, 2), gr[0]) < TOL[dt]
+    assert rel(gg[1].permute(0, 3, 1, 2), gr[1]) < TOL[dt]
+    assert rel(gg[2], gr[2]) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 256, 128), (1, 8, 12, 32, 32), (2, 4, 4, 384, 384)])
+def test_conv_transpose2x2_fwd_bwd(dt, B, H, W, Cin, Cout):
+    from dinounet_amd import ops
+    d = dev()
+    x, w, b = q(gen(B, Cin, H, W, seed=1), dt), gen(Cin, Cout, 2, 2, seed=2, scale=Cin ** -0.5), gen(Cout, seed=3)
+    xr, wr, br = x.clone().requires_grad_(True), q(w, dt).requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, br, stride=2)
+    go = q(gen(*yr.shape, seed=4), dt)
+    gr = torch.autograd.grad(yr, (xr, wr, br), go)
+    xg, wg, bg = nhwc(x).to(d, dt).requires_grad_(True), w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    y = ops.conv_transpose2x2(xg, wg, bg)
+    gg = torch.autograd.grad(y, (xg, wg, bg), nhwc(go).to(d, dt))
+    assert rel(y.permute(0, 3, 1, 2), yr) < TOL[dt]
+    assert rel(gg[0].permute(0, 3, 1, 2), gr[0]) < TOL[dt]
+    assert rel(gg[1], gr[1]) < TOL[dt]
+    assert rel(gg[2], gr[2]) < TOL[dt]
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("kind,C,H,W", [("in", 32, 64, 64), ("in", 256, 8, 8), ("bn", 64, 32, 32), ("bn", 384, 16, 16)])
+def test_norm_act_fwd_bwd(dt, kind, C, H, W):
+    from dinounet_amd import ops
+    from dinounet_amd._lib import ACT_LEAKY, ACT_RELU
+    d = dev()
+    B = 3
+    x, w, b = q(gen(B, C, H, W, seed=1) * 1.5 + 0.3, dt), 1 + 0.1 * gen(C, seed=2), 0.1 * gen(C, seed=3)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    if kind == "in":
+        yr = F.leaky_relu(F.instance_norm(xr, None, None, wr, br, True, 0.0, 1e-5), 0.01)
+        act = ACT_LEAKY
+    else:
+        yr = F.relu(F.batch_norm(xr, rm, rv, wr, br, True, 0.1, 1e-5))
+        act = ACT_RELU
+    go = q(gen(*yr.shape, seed=4), dt)
+    gr = torch.autograd.grad(yr, (xr, wr, br), go)
+    xg, wg, bg = nhwc(x).to(d, dt).requires_grad_(True), w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    rmg, rvg = torch.zeros(C, device=d), torch.ones(C, device=d)
+    y = ops.norm_act(xg, wg, bg, kind, act, 1e-5, True, rmg, rvg, 0.1, None)
+    gg = torch.autograd.grad(y, (xg, wg, bg), nhwc(go).to(d, dt))
+    t = TOL[dt] * 2
+    assert rel(y.permute(0, 3, 1, 2), yr) < t
+    assert rel(gg[0].permute(0, 3, 1, 2), gr[0]) < t
+    assert rel(gg[1], gr[1]) < t and rel(gg[2], gr[2]) < t
+    if kind == "bn":
+        assert rel(rmg, rm) < 1e-3 and rel(rvg, rv) < 1e-3                       # running-stat update (momentum 0.1, unbiased var)
+        ye = ops.norm_act(xg, wg, bg, "bn", act, 1e-5, False, rmg, rvg, 0.1, None)   # eval: running statistics
+        assert rel(ye.permute(0, 3, 1, 2), F.relu(F.batch_norm(x, rm, rv, w, b, False, 0.0, 1e-5))) < t
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("D", [384, 768, 1024, 4096])
+def test_layernorm_fwd_bwd(dt, D):
+    from dinounet_amd import ops
+    d = dev()
+    x, w, b = q(gen(2, 131, D, seed=1) * 2 + 0.5, dt), 1 + 0.1 * gen(D, seed=2), 0.1 * gen(D, seed=3)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (D,), wr, br, 1e-6)
+    go = q(gen(*yr.shape, seed=4), dt)
+    gr = torch.autograd.grad(yr, (xr, wr, br), go)
+    xg, wg, bg = x.to(d, dt).requires_grad_(True), w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    y = ops.layer_norm(xg, wg, bg, 1e-6)
+    gg = torch.autograd.grad(y, (xg, wg, bg), go.to(d, dt))
+    assert rel(y, yr) < TOL[dt]
+    for a, r_ in zip(gg, gr):
+        assert rel(a, r_) < TOL[dt]
+    # fp32 residual stream -> bf16 GEMM input (ViT path)
+    y2, _, _ = ops.layernorm_raw(x.to(d).view(-1, D), w.to(d), b.to(d), 1e-5, dt)
+    assert rel(y2, F.layer_norm(x, (D,), w, b, 1e-5).view(-1, D)) < TOL[dt]
+
+
+# ------------------------------------------------------------------------------------------------ MSDA
+@pytest.mark.parametrize("tag", ["D2", "D4", "D12", "D24", "D30", "D32", "D64", "D71", "D128", "border"])
+def test_msda_reference_fixture(tag):
+    """ops/test.py fixture (seed 3) + out-of-range sampling: forward and all three gradients vs the reference's own fp64
+    values (generated by oracle/make_golden.py from ms_deform_attn_core_pytorch), through the drop-in extension module."""
+    import MultiScaleDeformableAttention as MSDA
+    d = dev()
+    g = np.load(os.path.join(GOLD, "msda_testpy.npz"))
+    shapes, lsi = torch.from_numpy(g["shapes"]).to(d), torch.from_numpy(g["level_start_index"]).to(d)
+    v, loc, a, go = (torch.from_numpy(g[f"{tag}_{n}"]).float().to(d) for n in ("value", "loc", "attn", "grad_out"))
+    out = MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, a, 2)
+    assert rel(out, torch.from_numpy(g[f"{tag}_out"])) < 1e-5
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, a, go, 2)
+    assert rel(gv, torch.from_numpy(g[f"{tag}_grad_value"])) < 1e-5
+    assert rel(gl, torch.from_numpy(g[f"{tag}_grad_loc"])) < 2e-4      # fp32 cancellation in the corner differences
+    assert rel(ga, torch.from_numpy(g[f"{tag}_grad_attn"])) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("Dh", [12, 32])
+def test_msda_production_shape(dt, Dh):
+    """Lq = 5376 queries over a 32x32 value map, 16 heads, 4 points (dinounet_s / dinounet_l head widths), vs the oracle."""
+    from dinounet_amd import ops
+    from oracle import dinounet_oracle as O
+    d = dev()
+    N, S, M, Lq, P = 2, 1024, 16, 5376, 4
+    v = q(gen(N, S, M, Dh, seed=1), dt)
+    loc = torch.rand(N, Lq, M, 1, P, 2, generator=torch.Generator().manual_seed(2)) * 1.1 - 0.05
+    a = torch.softmax(gen(N, Lq, M, 1, P, seed=3), -1)
+    go = q(gen(N, Lq, M * Dh, seed=4), dt)
+    ref = O.msda_core(v, [(32, 32)], loc, a)
+    gvr, glr, gar = O.msda_backward(v, [(32, 32)], loc, a, go)
+    shapes, lsi = torch.tensor([[32, 32]], device=d), torch.zeros(1, dtype=torch.long, device=d)
+    vg, lg, ag = v.to(d, dt).requires_grad_(True), loc.to(d).requires_grad_(True), a.to(d).requires_grad_(True)
+    out = ops.msda(vg, shapes, lsi, lg, ag)
+    gv, gl, ga = torch.autograd.grad(out, (vg, lg, ag), go.to(d, dt))
+    t = 1e-4 if dt == torch.float32 else 2e-2
+    assert rel(out, ref) < t and rel(gv, gvr) < t and rel(ga, gar) < t and rel(gl, glr) < 5 * t
+
+
+def test_msda_prep_fwd_bwd():
+    from dinounet_amd import ops
+    d = dev()
+    rows, Lq, M, P = 2 * 84, 84, 16, 4
+    raw = gen(rows, M * P * 3, seed=1)
+    ref = torch.rand(Lq, 2, generator=torch.Generator().manual_seed(2))
+    rr = raw.clone().requires_grad_(True)
+    off = rr[:, :M * P * 2].view(rows, M, P, 2)
+    loc_r = ref.repeat(2, 1).view(rows, 1, 1, 2) + off / torch.tensor([8.0, 4.0])
+    at_r = F.softmax(rr[:, M * P * 2:].view(rows, M, P), -1)
+    g1, g2 = gen(rows, M, P, 2, seed=3), gen(rows, M, P, seed=4)
+    gr = torch.autograd.grad([loc_r, at_r], rr, [g1, g2])[0]
+    rg = raw.to(d).requires_grad_(True)
+    loc, at = ops.msda_prep(rg, ref.to(d), Lq, M, P, 4, 8)
+    gg = torch.autograd.grad([loc, at], rg, [g1.to(d), g2.to(d)])[0]
+    assert rel(loc, loc_r) < 1e-6 and rel(at, at_r) < 1e-5 and rel(gg, gr) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ small NHWC ops
+@pytest.mark.parametrize("dt", DTS)
+def test_dwconv_tokens_and_nhwc(dt):
+    from dinounet_amd import ops
+    from dinounet_amd._lib import ACT_GELU, ACT_NONE
+    d = dev()
+    B, H, W, C = 2, 4, 6, 96
+    n = H * W // 4
+    N = 21 * n
+    x, w, b = q(gen(B, N, C, seed=1), dt), gen(C, 1, 3, 3, seed=2, scale=1 / 3), gen(C, seed=3)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    outs = []
+    for (lo, hi, h, ww) in ((0, 16 * n, 2 * H, 2 * W), (16 * n, 20 * n, H, W), (20 * n, N, H // 2, W // 2)):
+        t = xr[:, lo:hi].transpose(1, 2).reshape(B, C, h, ww)
+        outs.append(F.conv2d(t, wr, br, 1, 1, groups=C).flatten(2).transpose(1, 2))
+    yr = F.gelu(torch.cat(outs, 1))
+    go = q(gen(*yr.shape, seed=4), dt)
+    gr = torch.autograd.grad(yr, (xr, wr, br), go)
+    xg, wg, bg = x.to(d, dt).requires_grad_(True), w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    y = ops.dwconv_tokens(xg, wg, bg, H, W, ACT_GELU)
+    gg = torch.autograd.grad(y, (xg, wg, bg), go.to(d, dt))
+    assert rel(y, yr) < TOL[dt]
+    for a, r_ in zip(gg, gr):
+        assert rel(a, r_) < TOL[dt]
+    x4 = q(gen(B, C, 9, 7, seed=5), dt)
+    y4 = ops.dwconv3x3(nhwc(x4).to(d, dt), w.to(d), b.to(d), ACT_NONE)
+    assert rel(y4.permute(0, 3, 1, 2), F.conv2d(x4, w, b, 1, 1, groups=C)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_maxpool_and_bilinear(dt):
+    from dinounet_amd import ops
+    d = dev()
+    x = q(F.relu(gen(2, 64, 17, 22, seed=1)), dt)          # ReLU output: many exact ties at 0, like the SPM stem
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    go = q(gen(*yr.shape, seed=2), dt)
+    gr = torch.autograd.grad(yr, xr, go)[0]
+    xg = nhwc(x).to(d, dt).requires_grad_(True)
+    y = ops.maxpool3x3s2(xg)
+    gg = torch.autograd.grad(y, xg, nhwc(go).to(d, dt))[0]
+    assert rel(y.permute(0, 3, 1, 2), yr) < 1e-6
+    assert rel(gg.permute(0, 3, 1, 2), gr) < TOL[dt]
+    for (hs, ws, ho, wo) in ((4, 4, 16, 16), (4, 6, 8, 12), (4, 4, 4, 4), (8, 8, 4, 4)):
+        src, base = q(gen(2, 32, hs, ws, seed=3), dt), q(gen(2, 32, ho, wo, seed=4), dt)
+        out = ops.bilinear_add(nhwc(src).to(d, dt), nhwc(base).to(d, dt))
+        ref = base + F.interpolate(src, size=(ho, wo), mode="bilinear", align_corners=False)
+        assert rel(out.permute(0, 3, 1, 2), ref) < TOL[dt]
+
+
+def test_layout_helpers():
+    from dinounet_amd import ops
+    d = dev()
+    x = gen(2, 3, 32, 48, seed=1)
+    y = ops.nchw_to_nhwc(x.to(d), torch.float32, 8)
+    assert rel(y[..., :3], x.permute(0, 2, 3, 1)) < 1e-7 and float(y[..., 3:].abs().max()) == 0.0
+    assert rel(ops.nhwc_to_nchw_f32(y[..., :3]), x) < 1e-7
+    p = ops.patchify16(x.to(d), torch.float32)
+    assert rel(p, F.unfold(x, 16, stride=16).transpose(1, 2).reshape(-1, 768)) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,H,N,Dh", [(2, 6, 1029, 64), (1, 3, 21, 64), (1, 2, 260, 128)])
+def test_vit_attention(dt, B, H, N, Dh):
+    """RoPE + head split + softmax(QK^T)V vs torch SDPA in fp32 (layers/attention.py:66-118), 5 prefix tokens un-rotated."""
+    from dinounet_amd import ops
+    d = dev()
+    prefix = 5
+    qkv = q(gen(B * N, 3 * H * Dh, seed=1), dt)
+    ang = gen(N - prefix, Dh, seed=2)
+    sin, cos = torch.sin(ang), torch.cos(ang)
+    qq, kk, vv = [t.transpose(1, 2) for t in qkv.view(B, N, 3, H, Dh).unbind(2)]
+
+    def rope(t):
+        a = t[:, :, prefix:]
+        x1, x2 = a.chunk(2, -1)
+        return torch.cat([t[:, :, :prefix], a * cos + torch.cat([-x2, x1], -1) * sin], 2)
+
+    ref = F.scaled_dot_product_attention(rope(qq), rope(kk), vv).transpose(1, 2).reshape(B * N, H * Dh)
+    out = ops.attention(qkv.to(d, dt), sin.to(d), cos.to(d), B, N, H, Dh, prefix, {})
+    assert rel(out, ref) < (2e-4 if dt == torch.float32 else 3e-2)
