@@ -292,7 +292,7 @@ int ln_bwd_dispatch(const void* x, const void* dy, const float* w, const float* 
   dim3 grid((unsigned)((nwaves + 3) / 4)), block(256);
 #define LNB_LAUNCH(MV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV>), grid, block, 0, st, (const T*)x, (const T*)dy, w, mean, rstd, (T*)dx, dw, db, rows, D, rpw)
   if (maxv <= 1) LNB_LAUNCH(1); else if (maxv <= 2) LNB_LAUNCH(2); else if (maxv <= 4) LNB_LAUNCH(4);
-  else if (maxv <= 8) LNB_LAUNCH(8); else return DU_ERR_UNSUPPORTED;
+  else if (maxv <= 8) LNB_LAUNCH(8); else if (maxv <= 16) LNB_LAUNCH(16); else return DU_ERR_UNSUPPORTED;
 #undef LNB_LAUNCH
   return du_check_launch();
 }

@@ -312,7 +312,14 @@ class UNetDecoder(nn.Module):
             x = self.stages[s](up, skips[-(s + 2)])          # concat (DT:614) fused into the conv's two-pointer gather
             if self.deep_supervision or s == n - 1:
                 sl = self.seg_layers[s if self.deep_supervision else -1]
-                segs.append(ops.nhwc_to_nchw_f32(ops.conv1x1(x, sl.weight, sl.bias, out_dtype=torch.float32)))
+                # the K-class head runs as a GEMM with its output columns zero-padded to a multiple of 8 (16-byte rows for the
+                # vectorised dgrad/wgrad loads); the logits are the first K columns, in fp32
+                K = sl.weight.shape[0]
+                Kp = (K + 7) // 8 * 8
+                w8 = torch.nn.functional.pad(sl.weight.flatten(1), (0, 0, 0, Kp - K))
+                b8 = torch.nn.functional.pad(sl.bias, (0, Kp - K))
+                y8 = ops.conv1x1(x, w8, b8, out_dtype=torch.float32)
+                segs.append(ops.nhwc_to_nchw_f32(y8[..., :K]))
             lres = x
         segs = segs[::-1]
         return segs if self.deep_supervision else segs[0]

@@ -89,10 +89,21 @@ def test_stage_taps_fp32():
     taps = {}
     ad = net.encoder.dinov3_adapter
     for i, blk in enumerate(ad.interactions):
-        blk.register_forward_hook(lambda m, a, out, i=i: taps.__setitem__(f"c{i + 1}", out))
-    ad.register_forward_hook(lambda m, a, out: [taps.__setitem__(f"feats{j}", out[k].permute(0, 3, 1, 2)) for j, k in enumerate("1234")])
-    net.encoder.fapm.register_forward_hook(lambda m, a, out: [taps.__setitem__(f"fapm{j}", o.permute(0, 3, 1, 2)) for j, o in enumerate(out)])
-    net.encoder.register_forward_hook(lambda m, a, out: [taps.__setitem__(f"skips{j}", o.permute(0, 3, 1, 2)) for j, o in enumerate(out)])
+        blk.register_forward_hook(lambda m, a, out, i=i: taps.__setitem__(f"c{i + 1}", out))   # __setitem__ returns None
+    # NB: a forward hook must return None, otherwise its return value replaces the module output
+    def h_feats(m, a, out):
+        for j, k in enumerate("1234"):
+            taps[f"feats{j}"] = out[k].permute(0, 3, 1, 2)
+
+    def h_list(prefix):
+        def h(m, a, out):
+            for j, o in enumerate(out):
+                taps[f"{prefix}{j}"] = o.permute(0, 3, 1, 2)
+        return h
+
+    ad.register_forward_hook(h_feats)
+    net.encoder.fapm.register_forward_hook(h_list("fapm"))
+    net.encoder.register_forward_hook(h_list("skips"))
     orig = ad.backbone.get_intermediate_layers
 
     def gil(*a, **k):
