@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="slices per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--graph", default=os.environ.get("DINOUNET_BENCH_GRAPH", "auto"), choices=["auto", "on", "off"],
+                    help="capture the train step into a hipGraph (auto = on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -47,7 +49,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_pg = os.environ.get("DINOUNET_FORCE_REDUCER") == "1" and "RANK" in os.environ   # single-rank RCCL smoke test
+    if world > 1 or force_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
@@ -55,37 +58,31 @@ def main():
     from dinounet_amd import ops
     from dinounet_amd.network_architecture import DinoUNet
     from dinounet_amd.parallel import GradAllReducer
-    from dinounet_amd.training import dc_and_ce_loss
+    from dinounet_amd.training import TrainStep
 
     torch.manual_seed(1234)
     net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name=a.model, precision=a.precision)
     net = net.to(dev).train()
     params = [p for p in net.parameters() if p.requires_grad]
-    reducer = GradAllReducer(net, world) if world > 1 else None
+    reducer = GradAllReducer(net, world) if (world > 1 or force_pg) else None
     opt = torch.optim.SGD(params, lr=1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5)   # nnUNetTrainer.py:486, DT:1024
 
     g = torch.Generator(device="cpu").manual_seed(100 + rank)
     x = torch.randn(a.batch, 3, a.size, a.size, generator=g).to(dev)
     tgt = torch.randint(0, 2, (a.batch, 1, a.size, a.size), generator=g).to(dev)
+    use_graph = a.graph != "off"
+    ts = TrainStep(net, opt, params, x.shape, tgt.shape, dev, reducer=reducer, graph=use_graph, warmup=max(2, min(a.warmup, 3)))
+    ts(x, tgt)
 
     def step():
-        opt.zero_grad(set_to_none=True)
-        logits = net(x)
-        loss = dc_and_ce_loss(logits, tgt)
-        loss.backward()
-        if reducer is not None:
-            reducer.finish()
-        torch.nn.utils.clip_grad_norm_(params, 12)          # nnUNetTrainer.py:922
-        opt.step()
-        return loss
+        return ts()
 
-    for _ in range(a.warmup):
+    # W untimed warm-up steps (the first ones run eagerly; with --graph the capture happens inside the warm-up)
+    for _ in range(max(a.warmup, (4 if use_graph else 1)) - 1):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    if not a.no_roofline:
-        ops.PROFILE = ops.KernelProfile()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -94,6 +91,16 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # roofline leg: the same step run eagerly with a HIP-event pair around every launch of the GEMM / attention kernels
+    prof = None
+    if not a.no_roofline and rank == 0:
+        ts.use_graph = False
+        ts()
+        torch.cuda.synchronize()
+        ops.PROFILE = ops.KernelProfile()
+        for _ in range(2):
+            ts()
+        torch.cuda.synchronize()
     prof = ops.PROFILE
     ops.PROFILE = None
     if world > 1:
@@ -109,11 +116,11 @@ def main():
            "config": {"workload": f"{a.model} train step (fwd+loss+bwd+clip+SGD), {a.size}x{a.size}x3 slices, batch {a.batch}/GPU, "
                                   f"frozen ViT + adapter + FAPM + U-Net decoder, random-init weights",
                       "global_batch": a.batch * world, "parallelism": f"dp{world}"},
-           "final_loss": round(float(loss.item()), 5)}
+           "final_loss": round(float(loss.item()), 5), "hipgraph": bool(use_graph)}
     if rank == 0:
         if prof is not None:
             try:
-                out["roofline"], out["kernel_breakdown"] = prof.roofline(MFMA_BF16_PEAK_TFLOPS, HBM_PEAK_GBS, a.steps)
+                out["roofline"], out["kernel_breakdown"] = prof.roofline(MFMA_BF16_PEAK_TFLOPS, HBM_PEAK_GBS, 2)
             except Exception as e:  # noqa: BLE001
                 out["roofline"] = {"error": repr(e)}
         if not a.no_cpu_baseline and world == 1:
@@ -122,7 +129,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_pg:
         dist.destroy_process_group()
 
 

@@ -91,13 +91,16 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const T* __restric
   }
 }
 
-// dw[c][tap] += sum_pix x[pix+tap][c] * dy[pix][c]; db[c] += sum dy.  Block = strip of pixels, thread = (pixel lane, cvec).
+// dw[c][tap] += sum_pix x[pix+tap][c] * dy[pix][c]; db[c] += sum dy.  Block = strip of pixels, thread = (pixel lane, cvec);
+// per-thread register partials are reduced across the block's pixel lanes through LDS, so each block issues one atomic
+// per (channel, tap) instead of one per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, long ldx, long xbs,
                                                                 const T* __restrict__ dy, long lddy, long dybs,
                                                                 float* __restrict__ dw, float* __restrict__ db, int B, int H,
                                                                 int W, int C, int strip) {
   constexpr int V = Elem<T>::VEC;
+  __shared__ float red[256 * V];
   const int cvn = C / V;
   const int cvb = min(cvn, 256);
   const int np = 256 / cvb;
@@ -106,41 +109,51 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
   const long p0 = (long)blockIdx.x * strip, p1 = min(npix, p0 + strip);
   for (int cv0 = 0; cv0 < cvn; cv0 += cvb) {
     const int cv = cv0 + tcv;
-    if (cv >= cvn || tp >= np) continue;
+    const bool active = (cv < cvn) && (tp < np);
     const int c0 = cv * V;
-    float aw[9][V], ab[V];
+    float aw[10][V];
 #pragma unroll
-    for (int j = 0; j < V; j++) {
-      ab[j] = 0.f;
+    for (int k = 0; k < 10; k++)
 #pragma unroll
-      for (int k = 0; k < 9; k++) aw[k][j] = 0.f;
-    }
-    for (long p = p0 + tp; p < p1; p += np) {
-      const int xo = (int)(p % W); long t = p / W;
-      const int yo = (int)(t % H); const int b = (int)(t / H);
-      Vec16<T> g = as_vec<T>(*(const uint4*)(dy + (long)b * dybs + ((long)yo * W + xo) * lddy + c0));
-      float gf[V];
+      for (int j = 0; j < V; j++) aw[k][j] = 0.f;
+    if (active) {
+      for (long p = p0 + tp; p < p1; p += np) {
+        const int xo = (int)(p % W); long t = p / W;
+        const int yo = (int)(t % H); const int b = (int)(t / H);
+        Vec16<T> g = as_vec<T>(*(const uint4*)(dy + (long)b * dybs + ((long)yo * W + xo) * lddy + c0));
+        float gf[V];
 #pragma unroll
-      for (int j = 0; j < V; j++) { gf[j] = to_f32(g.v[j]); ab[j] += gf[j]; }
+        for (int j = 0; j < V; j++) { gf[j] = to_f32(g.v[j]); aw[9][j] += gf[j]; }
 #pragma unroll
-      for (int ky = 0; ky < 3; ky++) {
-        const int yi = yo + ky - 1;
-        if (yi < 0 || yi >= H) continue;
+        for (int ky = 0; ky < 3; ky++) {
+          const int yi = yo + ky - 1;
+          if (yi < 0 || yi >= H) continue;
 #pragma unroll
-        for (int kx = 0; kx < 3; kx++) {
-          const int xi = xo + kx - 1;
-          if (xi < 0 || xi >= W) continue;
-          Vec16<T> v = as_vec<T>(*(const uint4*)(x + (long)b * xbs + ((long)yi * W + xi) * ldx + c0));
+          for (int kx = 0; kx < 3; kx++) {
+            const int xi = xo + kx - 1;
+            if (xi < 0 || xi >= W) continue;
+            Vec16<T> v = as_vec<T>(*(const uint4*)(x + (long)b * xbs + ((long)yi * W + xi) * ldx + c0));
 #pragma unroll
-          for (int j = 0; j < V; j++) aw[ky * 3 + kx][j] += to_f32(v.v[j]) * gf[j];
+            for (int j = 0; j < V; j++) aw[ky * 3 + kx][j] += to_f32(v.v[j]) * gf[j];
+          }
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j < V; j++) {
-      if (db) atomic_add_f32(db + c0 + j, ab[j]);
+    for (int k = 0; k < 10; k++) {
 #pragma unroll
-      for (int k = 0; k < 9; k++) atomic_add_f32(dw + (c0 + j) * 9 + k, aw[k][j]);
+      for (int j = 0; j < V; j++) red[threadIdx.x * V + j] = aw[k][j];
+      __syncthreads();
+      if (tp == 0 && cv < cvn) {
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+          float sacc = 0.f;
+          for (int q = 0; q < np; q++) sacc += red[(q * cvb + tcv) * V + j];
+          if (k < 9) atomic_add_f32(dw + (c0 + j) * 9 + k, sacc);
+          else if (db) atomic_add_f32(db + c0 + j, sacc);
+        }
+      }
+      __syncthreads();
     }
   }
 }
@@ -406,7 +419,7 @@ extern "C" int du_dwconv3x3_bwd_weight(int dtype, const void* x, int64_t ldx, in
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (!x || !dy || !dw || B <= 0 || C % v || ldx % v || lddy % v || xbs % v || dybs % v) return DU_ERR_BAD_ARG;
   const long npix = (long)B * H * W;
-  int strip = 512;
+  int strip = 1024;
   long blocks = (npix + strip - 1) / strip;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(dwconv_bwd_weight_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, xbs, (const bf16_t*)dy, lddy, dybs, dw, db, B, H, W, C, strip),

@@ -204,6 +204,110 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ val
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// backward, LDS-resident grad_value: one workgroup owns one (batch, head) value plane (S x D fp32 <= 144 KB of the
+// 160 KB LDS) and a chunk of the queries; the 4-corner scatter goes to LDS atomics (ds_add_f32) and is flushed once
+// with one global atomic per plane element.  Cuts global fp32 atomics from Lq*P*4*D to S*D per (b, head, chunk).
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int CPT, int MAXLP>
+__global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                            const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+                                                            const float* __restrict__ attn, const T* __restrict__ gout,
+                                                            float* __restrict__ gvalue, float* __restrict__ gloc,
+                                                            float* __restrict__ gattn, int N, int S, int M, int D, int L, int Lq,
+                                                            int P, int LPP, int q_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) float gacc[];   // [S][D]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y / M, m = blockIdx.y % M;
+  const int q0 = blockIdx.x * q_per_chunk;
+  const int q1 = min(Lq, q0 + q_per_chunk);
+  for (int i = tid; i < S * D; i += 1024) gacc[i] = 0.f;
+  __syncthreads();
+  const int gpw = 1024 / LPP;
+  const int sub = tid % LPP;
+  const int chunks = (D + CPT - 1) / CPT;
+  const long qstride = (long)M * D;
+  const int LP = L * P;
+  for (int q = q0 + tid / LPP; q < q1; q += gpw) {
+    const long pr = ((long)b * Lq + q) * M + m;
+    const float* lp = loc + pr * (long)LP * 2;
+    const float* ap = attn + pr * (long)LP;
+    float ga[MAXLP], gx[MAXLP], gy[MAXLP];
+#pragma unroll
+    for (int s = 0; s < MAXLP; s++) { ga[s] = 0.f; gx[s] = 0.f; gy[s] = 0.f; }
+    for (int ch = sub; ch < chunks; ch += LPP) {
+      const int c0 = ch * CPT;
+      float tg[CPT];
+      load_chan<T, CPT>(gout + pr * (long)D + c0, tg);
+#pragma unroll
+      for (int s = 0; s < MAXLP; s++) {
+        if (s < LP) {
+          const int l = s / P;
+          const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+          const int ls = (int)lsi[l];
+          const long base = ((long)b * S + ls) * qstride + (long)m * D + c0;
+          const float lw_ = lp[s * 2], lh_ = lp[s * 2 + 1];
+          const float a = ap[s];
+          const float h = lh_ * H - 0.5f, w = lw_ * W - 0.5f;
+          if (h > -1.f && w > -1.f && h < (float)H && w < (float)W) {
+            Corner c = corners(h, w, H, W);
+            const float hh = 1.f - c.lh, hw = 1.f - c.lw;
+            const float dh[4] = {-hw, -c.lw, hw, c.lw};
+            const float dw[4] = {-hh, hh, -c.lh, c.lh};
+            float val[CPT], ghw[CPT], gww[CPT];
+#pragma unroll
+            for (int j = 0; j < CPT; j++) { val[j] = 0.f; ghw[j] = 0.f; gww[j] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              if (c.ok[k]) {
+                float v[CPT];
+                load_chan<T, CPT>(value + base + (long)c.off[k] * qstride, v);
+                float* ldst = gacc + (ls + c.off[k]) * D + c0;
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                  val[j] += c.wt[k] * v[j];
+                  ghw[j] += dh[k] * v[j];
+                  gww[j] += dw[k] * v[j];
+                  atomicAdd(ldst + j, c.wt[k] * tg[j] * a);
+                }
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+              ga[s] += tg[j] * val[j];
+              gx[s] += (float)W * gww[j] * tg[j] * a;
+              gy[s] += (float)H * ghw[j] * tg[j] * a;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < MAXLP; s++) {
+      if (s < LP) {
+        float a = ga[s], x = gx[s], y = gy[s];
+        for (int o = LPP >> 1; o > 0; o >>= 1) {
+          a += __shfl_xor(a, o, 64); x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64);
+        }
+        if (sub == 0) {
+          gattn[pr * (long)LP + s] = a;
+          gloc[(pr * (long)LP + s) * 2] = x;
+          gloc[(pr * (long)LP + s) * 2 + 1] = y;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < S * D; i += 1024) {
+    const float v = gacc[i];
+    if (v != 0.f) {
+      const int sidx = i / D, c = i - sidx * D;
+      atomic_add_f32(gvalue + ((long)b * S + sidx) * qstride + (long)m * D + c, v);
+    }
+  }
+}
+
 int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
 template <typename T>
@@ -234,6 +338,26 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
   long blocks = (npairs + gpw - 1) / gpw;
   if (blocks > 65535 * 8) blocks = 65535 * 8;
   const int LP = L * P;
+  const size_t plane = (size_t)S * D * sizeof(float);
+  if (plane <= 144 * 1024 && LP <= 8 && LPP <= 64) {
+    // enough workgroups to fill 256 CUs; each chunk costs one S*D flush
+    int nchunk = (int)((512 + (long)N * M - 1) / ((long)N * M));
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > 16) nchunk = 16;
+    int qpc = (Lq + nchunk - 1) / nchunk;
+    const int gq = 1024 / LPP;
+    qpc = ((qpc + gq - 1) / gq) * gq;
+    nchunk = (Lq + qpc - 1) / qpc;
+    dim3 grid(nchunk, N * M);
+#define MSDA_BWD_LDS(MAXLP) do { \
+      auto kfn = msda_bwd_lds_kernel<T, CPT, MAXLP>; \
+      if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plane) != hipSuccess) return DU_ERR_LAUNCH; \
+      hipLaunchKernelGGL(kfn, grid, dim3(1024), plane, st, (const T*)value, shapes, lsi, loc, attn, (const T*)gout, gv, gl, ga, N, S, M, D, L, Lq, P, LPP, qpc); \
+    } while (0)
+    if (LP <= 4) MSDA_BWD_LDS(4); else MSDA_BWD_LDS(8);
+#undef MSDA_BWD_LDS
+    return du_check_launch();
+  }
 #define MSDA_BWD(MAXLP) hipLaunchKernelGGL((msda_bwd_kernel<T, CPT, MAXLP>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value, shapes, lsi, loc, attn, (const T*)gout, gv, gl, ga, N, S, M, D, L, Lq, P, LPP, npairs)
   if (LP <= 4) MSDA_BWD(4); else if (LP <= 8) MSDA_BWD(8); else if (LP <= 16) MSDA_BWD(16); else return DU_ERR_UNSUPPORTED;
 #undef MSDA_BWD

@@ -57,72 +57,44 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict
   }
 }
 
-// LayerNorm backward: each wave walks a strip of rows; lanes own fixed columns so dw/db partials stay in
-// registers until one atomic flush per block-strip.
+// LayerNorm backward, part 1: dx, one wave per row (same shape as the forward).
 template <typename T, int MAXV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                            const float* __restrict__ w, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, T* __restrict__ dx,
-                                                            float* __restrict__ dw, float* __restrict__ db, long rows,
-                                                            int D, int rows_per_wave) {
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                               const float* __restrict__ w, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, T* __restrict__ dx, long rows, int D) {
   constexpr int VI = Elem<T>::VEC;
   const int lane = threadIdx.x & 63;
-  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long r0 = wave_id * rows_per_wave;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
   const int nvec = D / VI;
-  float aw[MAXV][VI], ab[MAXV][VI], wv[MAXV][VI];
-#pragma unroll
-  for (int i = 0; i < MAXV; i++)
-#pragma unroll
-    for (int j = 0; j < VI; j++) {
-      aw[i][j] = 0.f; ab[i][j] = 0.f;
-      int vi = lane + i * 64;
-      wv[i][j] = vi < nvec ? w[vi * VI + j] : 0.f;
-    }
-  for (long row = r0; row < r0 + rows_per_wave && row < rows; row++) {
-    const float mu = mean[row], rs = rstd[row];
-    float xh[MAXV][VI], g[MAXV][VI];
-    float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; i++) {
-      int vi = lane + i * 64;
-      if (vi < nvec) {
-        Vec16<T> tx = as_vec<T>(*(const uint4*)(x + row * (long)D + (long)vi * VI));
-        Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + row * (long)D + (long)vi * VI));
-#pragma unroll
-        for (int j = 0; j < VI; j++) {
-          xh[i][j] = (to_f32(tx.v[j]) - mu) * rs;
-          float gy = to_f32(tg.v[j]);
-          aw[i][j] += gy * xh[i][j];
-          ab[i][j] += gy;
-          g[i][j] = gy * wv[i][j];
-          c1 += g[i][j];
-          c2 += g[i][j] * xh[i][j];
-        }
-      }
-    }
-    c1 = wave_sum(c1) / (float)D;
-    c2 = wave_sum(c2) / (float)D;
-#pragma unroll
-    for (int i = 0; i < MAXV; i++) {
-      int vi = lane + i * 64;
-      if (vi < nvec) {
-        Vec16<T> o;
-#pragma unroll
-        for (int j = 0; j < VI; j++) o.v[j] = from_f32<T>(rs * (g[i][j] - c1 - xh[i][j] * c2));
-        *(uint4*)(dx + row * (long)D + (long)vi * VI) = as_u4(o);
-      }
-    }
-  }
+  const float mu = mean[row], rs = rstd[row];
+  float xh[MAXV][VI], g[MAXV][VI];
+  float c1 = 0.f, c2 = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; i++) {
     int vi = lane + i * 64;
     if (vi < nvec) {
+      Vec16<T> tx = as_vec<T>(*(const uint4*)(x + row * (long)D + (long)vi * VI));
+      Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + row * (long)D + (long)vi * VI));
 #pragma unroll
       for (int j = 0; j < VI; j++) {
-        atomic_add_f32(dw + vi * VI + j, aw[i][j]);
-        atomic_add_f32(db + vi * VI + j, ab[i][j]);
+        xh[i][j] = (to_f32(tx.v[j]) - mu) * rs;
+        g[i][j] = to_f32(tg.v[j]) * w[vi * VI + j];
+        c1 += g[i][j];
+        c2 += g[i][j] * xh[i][j];
       }
+    }
+  }
+  c1 = wave_sum(c1) / (float)D;
+  c2 = wave_sum(c2) / (float)D;
+#pragma unroll
+  for (int i = 0; i < MAXV; i++) {
+    int vi = lane + i * 64;
+    if (vi < nvec) {
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < VI; j++) o.v[j] = from_f32<T>(rs * (g[i][j] - c1 - xh[i][j] * c2));
+      *(uint4*)(dx + row * (long)D + (long)vi * VI) = as_u4(o);
     }
   }
 }
@@ -155,6 +127,7 @@ __device__ __forceinline__ void strip_reduce(int G, long P, int C, float* out /*
 #pragma unroll
     for (int j = 0; j < V; j++) { a[j] = 0.f; b[j] = 0.f; }
     if (cv < cv_total && tp < np) {
+#pragma unroll 4
       for (long p = p0 + tp; p < p1; p += np) f((long)g * P + p, g, cv * V, a, b);
     }
 #pragma unroll
@@ -171,6 +144,26 @@ __device__ __forceinline__ void strip_reduce(int G, long P, int C, float* out /*
     }
     __syncthreads();
   }
+}
+
+// LayerNorm backward, part 2: dw[c] += sum_rows dy*xhat, db[c] += sum_rows dy  (column reduction over row strips),
+// written interleaved as out[c][0..1] = (dw, db).
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_wb_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               float* __restrict__ out, long rows, int D) {
+  constexpr int V = Elem<T>::VEC;
+  strip_reduce<T>(1, rows, D, out, [&](long row, int g, int c0, float* a, float* b) {
+    Vec16<T> tx = as_vec<T>(*(const uint4*)(x + row * (long)D + c0));
+    Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + row * (long)D + c0));
+    const float mu = mean[row], rs = rstd[row];
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      float gy = to_f32(tg.v[j]);
+      a[j] += gy * (to_f32(tx.v[j]) - mu) * rs;
+      b[j] += gy;
+    }
+  });
 }
 
 template <typename T>
@@ -281,19 +274,17 @@ int ln_fwd_dispatch(const void* x, long ldx, const float* w, const float* b, voi
 }
 
 template <typename T>
-int ln_bwd_dispatch(const void* x, const void* dy, const float* w, const float* mean, const float* rstd, void* dx, float* dw,
-                    float* db, long rows, int D, hipStream_t st) {
+int ln_bwd_dispatch(const void* x, const void* dy, const float* w, const float* mean, const float* rstd, void* dx, float* dwdb,
+                    long rows, int D, hipStream_t st) {
   const int nvec = D / Elem<T>::VEC;
   const int maxv = (nvec + 63) / 64;
-  long waves = 2048;  // 512 blocks
-  int rpw = (int)((rows + waves - 1) / waves);
-  if (rpw < 1) rpw = 1;
-  long nwaves = (rows + rpw - 1) / rpw;
-  dim3 grid((unsigned)((nwaves + 3) / 4)), block(256);
-#define LNB_LAUNCH(MV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV>), grid, block, 0, st, (const T*)x, (const T*)dy, w, mean, rstd, (T*)dx, dw, db, rows, D, rpw)
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define LNB_LAUNCH(MV) hipLaunchKernelGGL((layernorm_bwd_dx_kernel<T, MV>), grid, block, 0, st, (const T*)x, (const T*)dy, w, mean, rstd, (T*)dx, rows, D)
   if (maxv <= 1) LNB_LAUNCH(1); else if (maxv <= 2) LNB_LAUNCH(2); else if (maxv <= 4) LNB_LAUNCH(4);
   else if (maxv <= 8) LNB_LAUNCH(8); else if (maxv <= 16) LNB_LAUNCH(16); else return DU_ERR_UNSUPPORTED;
 #undef LNB_LAUNCH
+  long strips = (rows + STRIP - 1) / STRIP;
+  hipLaunchKernelGGL(layernorm_bwd_wb_kernel<T>, dim3((unsigned)strips), block, 0, st, (const T*)x, (const T*)dy, mean, rstd, dwdb, rows, D);
   return du_check_launch();
 }
 
@@ -313,13 +304,13 @@ extern "C" int du_layernorm_fwd(int in_dtype, int out_dtype, const void* x, int6
 }
 
 extern "C" int du_layernorm_bwd(int dtype, const void* x, const void* dy, const float* w, const float* mean, const float* rstd,
-                                void* dx, float* dw, float* db, int64_t rows, int D, void* stream) {
+                                void* dx, float* dwdb, int64_t rows, int D, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (rows <= 0 || D <= 0 || !x || !dy || !dx || !dw || !db) return DU_ERR_BAD_ARG;
+  if (rows <= 0 || D <= 0 || !x || !dy || !dx || !dwdb) return DU_ERR_BAD_ARG;
   const int vi = dtype == DU_BF16 ? 8 : 4;
   if (D % vi) return DU_ERR_BAD_ARG;
-  if (dtype == DU_F32) return ln_bwd_dispatch<float>(x, dy, w, mean, rstd, dx, dw, db, rows, D, st);
-  if (dtype == DU_BF16) return ln_bwd_dispatch<bf16_t>(x, dy, w, mean, rstd, dx, dw, db, rows, D, st);
+  if (dtype == DU_F32) return ln_bwd_dispatch<float>(x, dy, w, mean, rstd, dx, dwdb, rows, D, st);
+  if (dtype == DU_BF16) return ln_bwd_dispatch<bf16_t>(x, dy, w, mean, rstd, dx, dwdb, rows, D, st);
   return DU_ERR_BAD_ARG;
 }
 

@@ -72,10 +72,20 @@ class MSDeformAttn(nn.Module):
         b_cat = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
         raw = ops.linear(query, w_cat, b_cat, out_dtype=torch.float32).view(N * Lq, M * P * 3)   # MSA:188-189, kept fp32 (MSA:30)
         loc, attn = ops.msda_prep(raw, reference_points, Lq, M, P, Hs, Ws)                   # MSA:190-197
-        shapes = torch.tensor([[Hs, Ws]], dtype=torch.long, device=query.device)
-        lsi = torch.zeros(1, dtype=torch.long, device=query.device)
+        shapes, lsi = _level_tensors(Hs, Ws, query.device)   # cached: no host->device copy (sync) per call
         out = ops.msda(value, shapes, lsi, loc.view(N, Lq, M, 1, P, 2), attn.view(N, Lq, M, 1, P))   # MSA:207-214
         return ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=residual)
+
+
+_LEVEL_CACHE = {}
+
+
+def _level_tensors(Hs, Ws, device):
+    key = (Hs, Ws, str(device))
+    if key not in _LEVEL_CACHE:
+        _LEVEL_CACHE[key] = (torch.tensor([[Hs, Ws]], dtype=torch.long, device=device),
+                             torch.zeros(1, dtype=torch.long, device=device))
+    return _LEVEL_CACHE[key]
 
 
 class DWConv(nn.Module):

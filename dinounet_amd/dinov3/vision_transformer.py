@@ -103,21 +103,31 @@ class RopePositionEmbedding(nn.Module):
         self.rescale_coords = rescale_coords
         n = self.D_head // 4
         self.register_buffer("periods", base ** (2 * torch.arange(n, dtype=torch.float32) / (self.D_head // 2)), persistent=True)
+        self._cache = {}
 
     def sincos(self, H, W, device, training):
         """Returns (sin, cos) (HW, D_head) fp32 on `device`.  In train mode the reference draws ONE log-uniform
-        rescale factor per call (:93-97) -- per block, since the table is rebuilt in every block
-        (vision_transformer.py:271-272); we draw it host-side from torch's CPU generator."""
-        coords_h = torch.arange(0.5, H, dtype=torch.float32) / H
-        coords_w = torch.arange(0.5, W, dtype=torch.float32) / W
-        coords = torch.stack(torch.meshgrid(coords_h, coords_w, indexing="ij"), dim=-1).flatten(0, 1)
-        coords = 2.0 * coords - 1.0
+        rescale factor per call (:93-97) -- i.e. per block, since the table is rebuilt in every block
+        (vision_transformer.py:271-272).  Everything is computed on the device (device RNG, no host sync, graph-safe);
+        the eval table is cached."""
+        key = (H, W, str(device))
+        c = self._cache.get(key)
+        if c is None:
+            coords_h = torch.arange(0.5, H, dtype=torch.float32) / H
+            coords_w = torch.arange(0.5, W, dtype=torch.float32) / W
+            coords = torch.stack(torch.meshgrid(coords_h, coords_w, indexing="ij"), dim=-1).flatten(0, 1)
+            coords = (2.0 * coords - 1.0).to(device)
+            base = 2 * math.pi * coords[:, :, None] / self.periods.detach().float().to(device)[None, None, :]   # (HW, 2, D/4)
+            ang = base.flatten(1, 2).tile(2)
+            c = (base, torch.sin(ang), torch.cos(ang))
+            self._cache = {key: c}
+        base, sin, cos = c
         if training and self.rescale_coords is not None:
             mx = float(np.log(self.rescale_coords))
-            coords = coords * torch.empty(1).uniform_(-mx, mx).exp()
-        angles = 2 * math.pi * coords[:, :, None] / self.periods.detach().float().cpu()[None, None, :]
-        angles = angles.flatten(1, 2).tile(2)
-        return torch.sin(angles).to(device), torch.cos(angles).to(device)
+            scale = torch.empty(1, device=device, dtype=torch.float32).uniform_(-mx, mx).exp()
+            ang = (base * scale).flatten(1, 2).tile(2)
+            return torch.sin(ang), torch.cos(ang)
+        return sin, cos
 
 
 class DinoVisionTransformer(nn.Module):

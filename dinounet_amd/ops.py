@@ -535,11 +535,10 @@ class _LayerNorm(torch.autograd.Function):
         D = xc.shape[-1]
         dyc = dy.contiguous()
         dx = torch.empty_like(xc)
-        dw = torch.zeros(D, dtype=torch.float32, device=xc.device)
-        db = torch.zeros(D, dtype=torch.float32, device=xc.device)
-        _lib.check(_lib.lib().du_layernorm_bwd(_code(xc.dtype), _p(xc), _p(dyc), _p(wf), _p(mean), _p(rstd), _p(dx), _p(dw), _p(db),
+        dwdb = torch.zeros((D, 2), dtype=torch.float32, device=xc.device)
+        _lib.check(_lib.lib().du_layernorm_bwd(_code(xc.dtype), _p(xc), _p(dyc), _p(wf), _p(mean), _p(rstd), _p(dx), _p(dwdb),
                                                xc.numel() // D, D, _st()), "du_layernorm_bwd")
-        return dx, dw, db, None
+        return dx, dwdb[:, 0], dwdb[:, 1], None
 
 
 def layer_norm(x, w, b, eps):

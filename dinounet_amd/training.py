@@ -46,3 +46,58 @@ def dc_and_ce_loss(logits, target, smooth=1e-5, ddp=None, group=None):
         sum_gt = _AllReduceSumGrad.apply(sum_gt, group)
     dc = (2 * inter + smooth) / torch.clip(sum_gt + sum_pred + smooth, 1e-8)
     return ce - dc.mean()
+
+
+class TrainStep:
+    """One optimiser step of the reference trainer (nnUNetTrainer.py:899-929) on static input buffers:
+    zero_grad -> forward -> DC+CE -> backward [-> bucketed RCCL all-reduce] -> clip_grad_norm_(12) -> SGD step.
+
+    With `graph=True` the whole step (a few thousand launches, most of them small) is captured once into a hipGraph
+    after `warmup` eager iterations and replayed afterwards, which removes the host launch path from the critical path
+    (MI355X guide: "capture launch-bound inner loops in hipGraphs").  Device-side RNG (drop-path masks, RoPE rescale) stays
+    live under replay because torch registers the generator's Philox offset with the graph."""
+
+    def __init__(self, net, optimizer, params, x_shape, tgt_shape, device, reducer=None, max_norm=12.0, graph=True, warmup=3):
+        self.net, self.opt, self.params, self.reducer, self.max_norm = net, optimizer, params, reducer, max_norm
+        self.x = torch.zeros(x_shape, device=device)
+        self.tgt = torch.zeros(tgt_shape, dtype=torch.long, device=device)
+        self.loss = None
+        self.graph = None
+        self.use_graph = graph
+        self.warmup = warmup
+        self._n = 0
+
+    def _step(self):
+        self.opt.zero_grad(set_to_none=True)
+        logits = self.net(self.x)
+        loss = dc_and_ce_loss(logits, self.tgt)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
+        self.opt.step()
+        return loss.detach()
+
+    def __call__(self, x=None, tgt=None):
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+        if tgt is not None:
+            self.tgt.copy_(tgt, non_blocking=True)
+        if not self.use_graph:
+            self.loss = self._step()
+            return self.loss
+        if self.graph is None:
+            if self._n < self.warmup:                  # eager warm-up on a side stream (allocator + lazy caches settle)
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self.loss = self._step()
+                torch.cuda.current_stream().wait_stream(s)
+                self._n += 1
+                return self.loss
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._step()
+        self.graph.replay()
+        return self.loss

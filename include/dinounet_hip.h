@@ -117,9 +117,9 @@ int du_softmax_rows_f32(float* x, int64_t rows, int cols, int64_t ld, void* stre
 /* ---- LayerNorm -------------------------------------------------------------------------------- */
 int du_layernorm_fwd(int in_dtype, int out_dtype, const void* x, int64_t ldx, const float* w, const float* b, void* y,
                      int64_t ldy, float* mean_out, float* rstd_out, int64_t rows, int D, float eps, void* stream);
-/* dx (same dtype as x); dw/db accumulate with atomics into fp32 buffers the caller zero-fills. */
+/* dx (same dtype as x); dwdb is a zero-filled fp32 (D, 2) buffer receiving (dw[c], db[c]) interleaved (atomics). */
 int du_layernorm_bwd(int dtype, const void* x, const void* dy, const float* w, const float* mean, const float* rstd,
-                     void* dx, float* dw, float* db, int64_t rows, int D, void* stream);
+                     void* dx, float* dwdb, int64_t rows, int D, void* stream);
 
 /* ---- channel-statistics norms (InstanceNorm2d / BatchNorm2d over NHWC) ---------------------------- */
 /* sums[g][c][0..1] += (sum x, sum x^2) over the pixels of group g (G groups of `pix_per_group` pixels). */
