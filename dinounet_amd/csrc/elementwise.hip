@@ -384,6 +384,125 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ z, c
   GRID_STRIDE(i, n) dz[i] = from_f32<T>(to_f32(dy[i]) * act_grad(to_f32(z[i]), act));
 }
 
+
+// ---------------- squeeze-excitation (dinounet_training.py:210-225) ----------------
+// gate[b][c] = sigmoid(W2 relu(W1 pooled_b + b1) + b2), pooled = channel sums / P.  One workgroup per sample.
+__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restrict__ sums /*(B,C,2)*/, float invP,
+                                                          const float* __restrict__ W1, const float* __restrict__ b1,
+                                                          const float* __restrict__ W2, const float* __restrict__ b2,
+                                                          float* __restrict__ hidden, float* __restrict__ gate, int C, int R) {
+  extern __shared__ float sm[];   // pooled[C] | h[R]
+  float* pooled = sm;
+  float* h = sm + C;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < C; c += 256) pooled[c] = sums[((long)b * C + c) * 2] * invP;
+  __syncthreads();
+  for (int r = tid; r < R; r += 256) {
+    float acc = b1[r];
+    for (int c = 0; c < C; c++) acc += W1[r * C + c] * pooled[c];
+    acc = acc > 0.f ? acc : 0.f;
+    h[r] = acc;
+    hidden[(long)b * R + r] = acc;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float acc = b2[c];
+    for (int r = 0; r < R; r++) acc += W2[c * R + r] * h[r];
+    gate[(long)b * C + c] = 1.f / (1.f + __expf(-acc));
+  }
+}
+
+// y = x * gate[b][c] (+ shortcut)
+template <typename T>
+__global__ __launch_bounds__(256) void se_scale_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gate,
+                                                       const T* __restrict__ sc, long ldsc, T* __restrict__ y, long ldy, long P, int C,
+                                                       long total) {
+  constexpr int V = Elem<T>::VEC;
+  const int cvn = C / V;
+  GRID_STRIDE(i, total) {
+    const int c0 = (int)(i % cvn) * V;
+    const long pix = i / cvn;
+    const int b = (int)(pix / P);
+    Vec16<T> t = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
+    Vec16<T> o;
+    if (sc) {
+      Vec16<T> s2 = as_vec<T>(*(const uint4*)(sc + pix * ldsc + c0));
+#pragma unroll
+      for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(to_f32(t.v[j]) * gate[(long)b * C + c0 + j] + to_f32(s2.v[j]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(to_f32(t.v[j]) * gate[(long)b * C + c0 + j]);
+    }
+    *(uint4*)(y + pix * ldy + c0) = as_u4(o);
+  }
+}
+
+// gate MLP backward; a single workgroup walks the samples so the parameter gradients accumulate deterministically.
+// dsum (B,C,2): [..,0] = sum_pix dy * x.   Outputs: dpool (B,C) = d loss / d x[b,p,c] through the pooling path (already / P);
+// dW1 (R,C), db1 (R), dW2 (C,R), db2 (C) -- written (not accumulated).
+__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restrict__ dsum, const float* __restrict__ sums, float invP,
+                                                          const float* __restrict__ gate, const float* __restrict__ hidden,
+                                                          const float* __restrict__ W1, const float* __restrict__ W2,
+                                                          float* __restrict__ dpool, float* __restrict__ dW1, float* __restrict__ db1,
+                                                          float* __restrict__ dW2, float* __restrict__ db2, int B, int C, int R) {
+  extern __shared__ float sm[];   // dgp[C] | pooled[C] | h[R] | dhp[R]
+  float* dgp = sm;
+  float* pooled = sm + C;
+  float* h = sm + 2 * C;
+  float* dhp = sm + 2 * C + R;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < C * R; i += 256) { dW1[i] = 0.f; dW2[i] = 0.f; }
+  for (int i = tid; i < C; i += 256) db2[i] = 0.f;
+  for (int i = tid; i < R; i += 256) db1[i] = 0.f;
+  __syncthreads();
+  for (int b = 0; b < B; b++) {
+    for (int c = tid; c < C; c += 256) {
+      const float g = gate[(long)b * C + c];
+      dgp[c] = dsum[((long)b * C + c) * 2] * g * (1.f - g);
+      pooled[c] = sums[((long)b * C + c) * 2] * invP;
+    }
+    for (int r = tid; r < R; r += 256) h[r] = hidden[(long)b * R + r];
+    __syncthreads();
+    for (int r = tid; r < R; r += 256) {
+      float acc = 0.f;
+      for (int c = 0; c < C; c++) acc += W2[c * R + r] * dgp[c];
+      dhp[r] = h[r] > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < C * R; i += 256) {
+      { const int c = i / R, r = i - c * R; dW2[i] += dgp[c] * h[r]; }        // W2 is (C,R)
+      { const int r = i / C, c = i - r * C; dW1[i] += dhp[r] * pooled[c]; }   // W1 is (R,C)
+    }
+    for (int c = tid; c < C; c += 256) {
+      db2[c] += dgp[c];
+      float acc = 0.f;
+      for (int r = 0; r < R; r++) acc += W1[r * C + c] * dhp[r];
+      dpool[(long)b * C + c] = acc * invP;
+    }
+    for (int r = tid; r < R; r += 256) db1[r] += dhp[r];
+    __syncthreads();
+  }
+}
+
+// dx = dy * gate[b][c] + dpool[b][c]
+template <typename T>
+__global__ __launch_bounds__(256) void se_scale_bwd_kernel(const T* __restrict__ dy, long lddy, const float* __restrict__ gate,
+                                                           const float* __restrict__ dpool, T* __restrict__ dx, long lddx, long P,
+                                                           int C, long total) {
+  constexpr int V = Elem<T>::VEC;
+  const int cvn = C / V;
+  GRID_STRIDE(i, total) {
+    const int c0 = (int)(i % cvn) * V;
+    const long pix = i / cvn;
+    const int b = (int)(pix / P);
+    Vec16<T> t = as_vec<T>(*(const uint4*)(dy + pix * lddy + c0));
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(to_f32(t.v[j]) * gate[(long)b * C + c0 + j] + dpool[(long)b * C + c0 + j]);
+    *(uint4*)(dx + pix * lddx + c0) = as_u4(o);
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
@@ -419,7 +538,12 @@ extern "C" int du_dwconv3x3_bwd_weight(int dtype, const void* x, int64_t ldx, in
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (!x || !dy || !dw || B <= 0 || C % v || ldx % v || lddy % v || xbs % v || dybs % v) return DU_ERR_BAD_ARG;
   const long npix = (long)B * H * W;
-  int strip = 1024;
+  // ~1024 workgroups per launch, but at least 4 pixels per pixel lane so the 10-round LDS reduction stays amortised
+  const int cvb_ = (C / v) < 256 ? (C / v) : 256;
+  const int np_ = 256 / cvb_;
+  long strip_l = (npix + 1023) / 1024;
+  if (strip_l < (long)np_ * 4) strip_l = (long)np_ * 4;
+  int strip = (int)strip_l;
   long blocks = (npix + strip - 1) / strip;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(dwconv_bwd_weight_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, xbs, (const bf16_t*)dy, lddy, dybs, dw, db, B, H, W, C, strip),
@@ -537,6 +661,49 @@ extern "C" int du_act_bwd(int dtype, const void* z, const void* dy, void* dz, in
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(grid_1d(n)), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)dy, (bf16_t*)dz, (long)n, act),
              hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid_1d(n)), dim3(256), 0, st, (const float*)z, (const float*)dy, (float*)dz, (long)n, act));
+  return du_check_launch();
+}
+
+extern "C" int du_se_gate_fwd(const float* sums, float inv_count, const float* W1, const float* b1, const float* W2, const float* b2,
+                              float* hidden, float* gate, int B, int C, int R, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!sums || !W1 || !b1 || !W2 || !b2 || !hidden || !gate || B <= 0 || C <= 0 || R <= 0) return DU_ERR_BAD_ARG;
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), st, sums, inv_count, W1, b1, W2, b2, hidden, gate, C, R);
+  return du_check_launch();
+}
+
+extern "C" int du_se_scale_fwd(int dtype, const void* x, int64_t ldx, const float* gate, const void* shortcut, int64_t ldsc, void* y,
+                               int64_t ldy, int B, int64_t P, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (!x || !gate || !y || B <= 0 || P <= 0 || C % v || ldx % v || ldy % v || (shortcut && ldsc % v)) return DU_ERR_BAD_ARG;
+  long total = (long)B * P * (C / v);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(se_scale_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, (const bf16_t*)x, ldx, gate, (const bf16_t*)shortcut, ldsc, (bf16_t*)y, ldy, (long)P, C, total),
+             hipLaunchKernelGGL(se_scale_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, (const float*)x, ldx, gate, (const float*)shortcut, ldsc, (float*)y, ldy, (long)P, C, total));
+  return du_check_launch();
+}
+
+extern "C" int du_se_gate_bwd(const float* dsum, const float* sums, float inv_count, const float* gate, const float* hidden,
+                              const float* W1, const float* W2, float* dpool, float* dW1, float* db1, float* dW2, float* db2, int B, int C,
+                              int R, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!dsum || !sums || !gate || !hidden || !W1 || !W2 || !dpool || !dW1 || !db1 || !dW2 || !db2 || B <= 0 || C <= 0 || R <= 0)
+    return DU_ERR_BAD_ARG;
+  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(1), dim3(256), (2 * C + 2 * R) * sizeof(float), st, dsum, sums, inv_count, gate, hidden, W1, W2,
+                     dpool, dW1, db1, dW2, db2, B, C, R);
+  return du_check_launch();
+}
+
+extern "C" int du_se_scale_bwd(int dtype, const void* dy, int64_t lddy, const float* gate, const float* dpool, void* dx, int64_t lddx,
+                               int B, int64_t P, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (!dy || !gate || !dpool || !dx || B <= 0 || P <= 0 || C % v || lddy % v || lddx % v) return DU_ERR_BAD_ARG;
+  long total = (long)B * P * (C / v);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(se_scale_bwd_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, (const bf16_t*)dy, lddy, gate, dpool, (bf16_t*)dx, lddx, (long)P, C, total),
+             hipLaunchKernelGGL(se_scale_bwd_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, (const float*)dy, lddy, gate, dpool, (float*)dx, lddx, (long)P, C, total));
   return du_check_launch();
 }
 

@@ -11,6 +11,7 @@
 // threads for the s/b/l models -- half a wavefront or less) and reduces through shared memory with a serial loop;
 // here the D-reduction of grad_loc / grad_attn is an in-wave xor-shuffle tree and several (q, head) pairs share a wave.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -339,7 +340,8 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
   if (blocks > 65535 * 8) blocks = 65535 * 8;
   const int LP = L * P;
   const size_t plane = (size_t)S * D * sizeof(float);
-  if (plane <= 144 * 1024 && LP <= 8 && LPP <= 64) {
+  static const bool no_lds = getenv("DU_MSDA_NO_LDS") != nullptr;   // debugging aid: force the global-atomics kernel
+  if (!no_lds && plane <= 144 * 1024 && LP <= 8 && LPP <= 64) {
     // enough workgroups to fill 256 CUs; each chunk costs one S*D flush
     int nchunk = (int)((512 + (long)N * M - 1) / ((long)N * M));
     if (nchunk < 1) nchunk = 1;

@@ -102,14 +102,25 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const T* __restri
 // ------------------------------------------------------------------------------------------------------
 // Channel statistics over NHWC: thread = (pixel lane, channel vector); block = one strip of one group.
 // ------------------------------------------------------------------------------------------------------
-constexpr int STRIP = 2048;  // pixels per block
+// pixels per block: sized so a launch has ~2048 workgroups (256 CUs x 8) but every pixel lane still runs >= 4 iterations
+static inline int pick_strip(int G, long P, int C, int vec) {
+  const int cvb = (C / vec) < 256 ? (C / vec) : 256;
+  const int np = 256 / (cvb > 0 ? cvb : 1);
+  long per_group = 2048 / (G > 0 ? G : 1);
+  if (per_group < 1) per_group = 1;
+  long s = (P + per_group - 1) / per_group;
+  const long smin = (long)np * 4;
+  if (s < smin) s = smin;
+  if (s > P) s = P;
+  return (int)s;
+}
 
 template <typename T, int KIND>
 struct StatOp;
 
 // generic strip reducer: F(xvec, dyvec, g, c0) -> (a[VEC], b[VEC]) accumulated per channel, then written with atomics
 template <typename T, typename F>
-__device__ __forceinline__ void strip_reduce(int G, long P, int C, float* out /*[G][C][2]*/, F f) {
+__device__ __forceinline__ void strip_reduce(int G, long P, int C, int STRIP, float* out /*[G][C][2]*/, F f) {
   constexpr int V = Elem<T>::VEC;
   __shared__ float red[2][256 * V];
   const int cv_total = C / V;
@@ -151,9 +162,9 @@ __device__ __forceinline__ void strip_reduce(int G, long P, int C, float* out /*
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_wb_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                               float* __restrict__ out, long rows, int D) {
+                                                               float* __restrict__ out, long rows, int D, int strip) {
   constexpr int V = Elem<T>::VEC;
-  strip_reduce<T>(1, rows, D, out, [&](long row, int g, int c0, float* a, float* b) {
+  strip_reduce<T>(1, rows, D, strip, out, [&](long row, int g, int c0, float* a, float* b) {
     Vec16<T> tx = as_vec<T>(*(const uint4*)(x + row * (long)D + c0));
     Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + row * (long)D + c0));
     const float mu = mean[row], rs = rstd[row];
@@ -168,12 +179,25 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wb_kernel(const T* __restri
 
 template <typename T>
 __global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ x, long ldx, float* __restrict__ sums, int G,
-                                                         long P, int C) {
+                                                         long P, int C, int strip) {
   constexpr int V = Elem<T>::VEC;
-  strip_reduce<T>(G, P, C, sums, [&](long pix, int g, int c0, float* a, float* b) {
+  strip_reduce<T>(G, P, C, strip, sums, [&](long pix, int g, int c0, float* a, float* b) {
     Vec16<T> t = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
 #pragma unroll
     for (int j = 0; j < V; j++) { float v = to_f32(t.v[j]); a[j] += v; b[j] += v * v; }
+  });
+}
+
+// sums[g][c] += (sum_pix a*b, sum_pix a)   (squeeze-excitation gate gradient: a = dy, b = x)
+template <typename T>
+__global__ __launch_bounds__(256) void chan_dot_kernel(const T* __restrict__ a_, long lda, const T* __restrict__ b_, long ldb,
+                                                       float* __restrict__ sums, int G, long P, int C, int strip) {
+  constexpr int V = Elem<T>::VEC;
+  strip_reduce<T>(G, P, C, strip, sums, [&](long pix, int g, int c0, float* a, float* b) {
+    Vec16<T> ta = as_vec<T>(*(const uint4*)(a_ + pix * lda + c0));
+    Vec16<T> tb = as_vec<T>(*(const uint4*)(b_ + pix * ldb + c0));
+#pragma unroll
+    for (int j = 0; j < V; j++) { float va = to_f32(ta.v[j]); a[j] += va * to_f32(tb.v[j]); b[j] += va; }
   });
 }
 
@@ -205,9 +229,9 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stats_kernel(const T* __rest
                                                                  long lddy, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const float* __restrict__ w,
                                                                  const float* __restrict__ b, float* __restrict__ bsums, int G,
-                                                                 long P, int C, int act) {
+                                                                 long P, int C, int act, int strip) {
   constexpr int V = Elem<T>::VEC;
-  strip_reduce<T>(G, P, C, bsums, [&](long pix, int g, int c0, float* a, float* bb) {
+  strip_reduce<T>(G, P, C, strip, bsums, [&](long pix, int g, int c0, float* a, float* bb) {
     Vec16<T> tx = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
     Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + pix * lddy + c0));
 #pragma unroll
@@ -283,8 +307,9 @@ int ln_bwd_dispatch(const void* x, const void* dy, const float* w, const float* 
   if (maxv <= 1) LNB_LAUNCH(1); else if (maxv <= 2) LNB_LAUNCH(2); else if (maxv <= 4) LNB_LAUNCH(4);
   else if (maxv <= 8) LNB_LAUNCH(8); else if (maxv <= 16) LNB_LAUNCH(16); else return DU_ERR_UNSUPPORTED;
 #undef LNB_LAUNCH
+  const int STRIP = pick_strip(1, rows, D, Elem<T>::VEC);
   long strips = (rows + STRIP - 1) / STRIP;
-  hipLaunchKernelGGL(layernorm_bwd_wb_kernel<T>, dim3((unsigned)strips), block, 0, st, (const T*)x, (const T*)dy, mean, rstd, dwdb, rows, D);
+  hipLaunchKernelGGL(layernorm_bwd_wb_kernel<T>, dim3((unsigned)strips), block, 0, st, (const T*)x, (const T*)dy, mean, rstd, dwdb, rows, D, STRIP);
   return du_check_launch();
 }
 
@@ -318,10 +343,25 @@ extern "C" int du_chan_stats(int dtype, const void* x, int64_t ldx, float* sums,
   hipStream_t st = (hipStream_t)stream;
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (G <= 0 || P <= 0 || C <= 0 || C % v || ldx % v || !x || !sums) return DU_ERR_BAD_ARG;
+  const int STRIP = pick_strip(G, P, C, v);
   long strips = (P + STRIP - 1) / STRIP;
   dim3 grid((unsigned)(G * strips)), block(256);
-  if (dtype == DU_BF16) hipLaunchKernelGGL(chan_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, sums, G, P, C);
-  else if (dtype == DU_F32) hipLaunchKernelGGL(chan_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, sums, G, P, C);
+  if (dtype == DU_BF16) hipLaunchKernelGGL(chan_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, sums, G, P, C, STRIP);
+  else if (dtype == DU_F32) hipLaunchKernelGGL(chan_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, sums, G, P, C, STRIP);
+  else return DU_ERR_BAD_ARG;
+  return du_check_launch();
+}
+
+extern "C" int du_chan_dot(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, float* sums, int G, int64_t P, int C,
+                           void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (G <= 0 || P <= 0 || C <= 0 || C % v || lda % v || ldb % v || !a || !b || !sums) return DU_ERR_BAD_ARG;
+  const int STRIP = pick_strip(G, P, C, v);
+  long strips = (P + STRIP - 1) / STRIP;
+  dim3 grid((unsigned)(G * strips)), block(256);
+  if (dtype == DU_BF16) hipLaunchKernelGGL(chan_dot_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, sums, G, P, C, STRIP);
+  else if (dtype == DU_F32) hipLaunchKernelGGL(chan_dot_kernel<float>, grid, block, 0, st, (const float*)a, lda, (const float*)b, ldb, sums, G, P, C, STRIP);
   else return DU_ERR_BAD_ARG;
   return du_check_launch();
 }
@@ -345,10 +385,11 @@ extern "C" int du_norm_act_bwd_stats(int dtype, const void* x, int64_t ldx, cons
   hipStream_t st = (hipStream_t)stream;
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (G <= 0 || P <= 0 || C % v || ldx % v || lddy % v) return DU_ERR_BAD_ARG;
+  const int STRIP = pick_strip(G, P, C, v);
   long strips = (P + STRIP - 1) / STRIP;
   dim3 grid((unsigned)(G * strips)), block(256);
-  if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_bwd_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act);
-  else if (dtype == DU_F32) hipLaunchKernelGGL(norm_act_bwd_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act);
+  if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_bwd_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP);
+  else if (dtype == DU_F32) hipLaunchKernelGGL(norm_act_bwd_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP);
   else return DU_ERR_BAD_ARG;
   return du_check_launch();
 }

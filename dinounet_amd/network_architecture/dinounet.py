@@ -76,12 +76,8 @@ class SqueezeExcitation(nn.Module):
                                 nn.Conv2d(reduced, channels, kernel_size=1, bias=True), nn.Sigmoid())
 
     def forward(self, x, shortcut=None):
-        """x NHWC.  The (B, C) gate is a few hundred flops: computed with torch on the pooled vector."""
-        s = x.float().mean((1, 2))
-        s = torch.relu(s @ self.fc[0].weight.flatten(1).t() + self.fc[0].bias)
-        s = torch.sigmoid(s @ self.fc[2].weight.flatten(1).t() + self.fc[2].bias).to(x.dtype)
-        y = x * s[:, None, None, :]
-        return y if shortcut is None else y + shortcut
+        """x NHWC; the residual add of DT:438 is fused into the scaling kernel."""
+        return ops.squeeze_excite(x, self.fc[0].weight, self.fc[0].bias, self.fc[2].weight, self.fc[2].bias, shortcut)
 
 
 class DepthwiseSeparableConv(nn.Module):

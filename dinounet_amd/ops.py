@@ -17,7 +17,7 @@ from ._lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, DU_BF16, DU_F32, IM2
                    PLAIN_ROW, STORE_PIXEL_SHUFFLE2, ConvGeom, GemmArgs)
 
 __all__ = ["mm", "linear", "conv2d", "conv_transpose2x2", "norm_act", "layer_norm", "msda", "dwconv3x3",
-           "maxpool3x3s2", "bilinear_add"]
+           "maxpool3x3s2", "bilinear_add", "squeeze_excite"]
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -71,8 +71,9 @@ class KernelProfile:
     """HIP-event timing of individual kernel launches on the stream they are launched on (torch's current stream).
     Enabled by bench.py inside its timed region: ops.PROFILE = KernelProfile()."""
 
-    def __init__(self):
+    def __init__(self, detail=False):
         self.rec = []
+        self.detail = detail      # key GEMM launches by full shape signature (tools/debug_step.py --shapes)
 
     def start(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -137,7 +138,10 @@ def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat,
         es = 2 if dtype == DU_BF16 else 4
         eo = 2 if out_dtype == DU_BF16 else 4
         kin = K if geom is None else K // max(geom.KH * geom.KW, 1) if a_mode == IM2COL_ROW else K
-        PROFILE.stop(f"gemm_kernel<{'bf16' if dtype == DU_BF16 else 'f32'},{_MODE_NAMES.get((a_mode, b_mode), 'other')}>", e0,
+        tag = f"gemm_kernel<{'bf16' if dtype == DU_BF16 else 'f32'},{_MODE_NAMES.get((a_mode, b_mode), 'other')}>"
+        if PROFILE.detail:
+            tag += f" M{M} N{N} K{K} b{batch} sk{split_k}" + (f" k{geom.KH}s{geom.stride}t{geom.transposed}" if geom is not None else "")
+        PROFILE.stop(tag, e0,
                      2.0 * M * N * K * batch, float(batch) * (M * kin * es + N * K * es + M * N * eo))
         return
     _lib.check(_lib.lib().du_gemm(C.byref(a), _st()), "du_gemm")
@@ -737,6 +741,59 @@ class _BilinearAdd(torch.autograd.Function):
 
 def bilinear_add(src, base):
     return _BilinearAdd.apply(src, base)
+
+
+class _SqueezeExcite(torch.autograd.Function):
+    """SqueezeExcitation (dinounet_training.py:210-225) with the residual add of :438 fused:
+    y = x * sigmoid(W2 relu(W1 mean_hw(x) + b1) + b2) [+ shortcut].  x, shortcut NHWC; weights fp32 (R,C) / (C,R)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, shortcut):
+        B, H, W, Cc, ld = _nhwc(x)
+        P = H * W
+        R = w1.shape[0]
+        L = _lib.lib()
+        w1f, b1f, w2f, b2f = _f32(w1.reshape(R, Cc)), _f32(b1), _f32(w2.reshape(Cc, R)), _f32(b2)
+        sums, _ = chan_stats(x, B)
+        hidden = torch.empty((B, R), dtype=torch.float32, device=x.device)
+        gate = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+        _lib.check(L.du_se_gate_fwd(_p(sums), 1.0 / P, _p(w1f), _p(b1f), _p(w2f), _p(b2f), _p(hidden), _p(gate), B, Cc, R, _st()),
+                   "du_se_gate_fwd")
+        y = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device)
+        lds = 0
+        if shortcut is not None:
+            Bs, Hs, Ws, Cs, lds = _nhwc(shortcut)
+            assert (Bs, Hs, Ws, Cs) == (B, H, W, Cc) and shortcut.dtype == x.dtype
+        _lib.check(L.du_se_scale_fwd(_code(x.dtype), _p(x), ld, _p(gate), _p(shortcut), lds, _p(y), Cc, B, P, Cc, _st()), "du_se_scale_fwd")
+        ctx.save_for_backward(x, sums, hidden, gate, w1f, w2f)
+        ctx.shapes = (w1.shape, w2.shape, shortcut is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sums, hidden, gate, w1f, w2f = ctx.saved_tensors
+        w1s, w2s, has_sc = ctx.shapes
+        B, H, W, Cc, ld = _nhwc(x)
+        P = H * W
+        R = w1f.shape[0]
+        L = _lib.lib()
+        dy = dy.contiguous()
+        dsum = torch.zeros((B, Cc, 2), dtype=torch.float32, device=x.device)
+        _lib.check(L.du_chan_dot(_code(x.dtype), _p(dy), Cc, _p(x), ld, _p(dsum), B, P, Cc, _st()), "du_chan_dot")
+        dpool = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+        dw1 = torch.empty((R, Cc), dtype=torch.float32, device=x.device)
+        db1 = torch.empty(R, dtype=torch.float32, device=x.device)
+        dw2 = torch.empty((Cc, R), dtype=torch.float32, device=x.device)
+        db2 = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        _lib.check(L.du_se_gate_bwd(_p(dsum), _p(sums), 1.0 / P, _p(gate), _p(hidden), _p(w1f), _p(w2f), _p(dpool), _p(dw1), _p(db1),
+                                    _p(dw2), _p(db2), B, Cc, R, _st()), "du_se_gate_bwd")
+        dx = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device)
+        _lib.check(L.du_se_scale_bwd(_code(x.dtype), _p(dy), Cc, _p(gate), _p(dpool), _p(dx), Cc, B, P, Cc, _st()), "du_se_scale_bwd")
+        return dx, dw1.view(w1s), db1, dw2.view(w2s), db2, (dy if has_sc else None)
+
+
+def squeeze_excite(x, w1, b1, w2, b2, shortcut=None):
+    return _SqueezeExcite.apply(x, w1, b1, w2, b2, shortcut)
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -27,7 +27,8 @@
  *          (dinounet_training.py:235)
  *   du_maxpool3x3s2_*            <- nn.MaxPool2d(3,2,1) (dinov3_adapter.py:250)
  *   du_bilinear_add_*            <- F.interpolate(bilinear, align_corners=False)+add (dinov3_adapter.py:472-476)
- *   du_softmax_lastdim4 / du_msda_locations <- ms_deform_attn.py:188-197
+ *   du_se_gate_* / du_se_scale_*  <- SqueezeExcitation + residual (dinounet_training.py:210-225,438)
+ *   du_msda_prep / du_msda_prep_bwd <- ms_deform_attn.py:188-197
  */
 #ifndef DINOUNET_HIP_H
 #define DINOUNET_HIP_H
@@ -124,6 +125,9 @@ int du_layernorm_bwd(int dtype, const void* x, const void* dy, const float* w, c
 /* ---- channel-statistics norms (InstanceNorm2d / BatchNorm2d over NHWC) ---------------------------- */
 /* sums[g][c][0..1] += (sum x, sum x^2) over the pixels of group g (G groups of `pix_per_group` pixels). */
 int du_chan_stats(int dtype, const void* x, int64_t ldx, float* sums, int G, int64_t pix_per_group, int C, void* stream);
+/* sums[g][c][0..1] += (sum a*b, sum a) over the pixels of group g (squeeze-excitation gate gradient, a = dy, b = x). */
+int du_chan_dot(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, float* sums, int G, int64_t pix_per_group, int C,
+                void* stream);
 /* y = act((x - mean[g,c]) * rstd[g,c] * w[c] + b[c]); mean/rstd: (G, C) fp32. */
 int du_norm_act_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* mean, const float* rstd,
                     const float* w, const float* b, int G, int64_t pix_per_group, int C, int act, void* stream);
@@ -176,6 +180,21 @@ int du_bilinear_add_fwd(int src_dtype, int dtype, const void* src, int64_t lds_,
                         int64_t ldo, int B, int Hs, int Ws, int Ho, int Wo, int C, void* stream);
 /* dz = dy * act'(z) */
 int du_act_bwd(int dtype, const void* z, const void* dy, void* dz, int64_t n, int act, void* stream);
+
+/* ---- squeeze-excitation (SqueezeExcitation, dinounet_training.py:210-225; residual add of :438 fused) -------------- */
+/* sums (B,C,2) from du_chan_stats(G=B); W1 (R,C), b1 (R), W2 (C,R), b2 (C) fp32; hidden (B,R) post-ReLU, gate (B,C) = sigmoid. */
+int du_se_gate_fwd(const float* sums, float inv_count, const float* W1, const float* b1, const float* W2, const float* b2,
+                   float* hidden, float* gate, int B, int C, int R, void* stream);
+/* y = x * gate[b][c] (+ shortcut, nullable) over (B, P pixels, C) NHWC */
+int du_se_scale_fwd(int dtype, const void* x, int64_t ldx, const float* gate, const void* shortcut, int64_t ldsc, void* y, int64_t ldy,
+                    int B, int64_t P, int C, void* stream);
+/* dsum (B,C,2) from du_chan_dot(dy, x).  Writes dpool (B,C) (gradient reaching every pixel through the pooling path, already
+   divided by P) and the gate-MLP parameter gradients dW1 (R,C), db1 (R), dW2 (C,R), db2 (C). */
+int du_se_gate_bwd(const float* dsum, const float* sums, float inv_count, const float* gate, const float* hidden, const float* W1,
+                   const float* W2, float* dpool, float* dW1, float* db1, float* dW2, float* db2, int B, int C, int R, void* stream);
+/* dx = dy * gate[b][c] + dpool[b][c] */
+int du_se_scale_bwd(int dtype, const void* dy, int64_t lddy, const float* gate, const float* dpool, void* dx, int64_t lddx, int B,
+                    int64_t P, int C, void* stream);
 
 /* ---- elementwise helpers --------------------------------------------------------------------------- */
 int du_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

@@ -121,6 +121,14 @@ def bilinear_add(src, base):
     return base + _nhwc(up).to(base.dtype)
 
 
+def squeeze_excite(x, w1, b1, w2, b2, shortcut=None):
+    s = x.float().mean((1, 2))
+    s = F.relu(F.linear(s, w1.flatten(1), b1))
+    s = torch.sigmoid(F.linear(s, w2.flatten(1), b2)).to(x.dtype)
+    y = x * s[:, None, None, :]
+    return y if shortcut is None else y + shortcut
+
+
 def nchw_to_nhwc(x, dt, cpad=None):
     y = x.float().permute(0, 2, 3, 1)
     if cpad and cpad > y.shape[-1]:
@@ -154,7 +162,7 @@ def attention(qkv, sin, cos, B, N, H, Dh, prefix, workspace):
 
 
 _NAMES = ["mm", "linear", "conv1x1", "conv2d", "conv_transpose2x2", "norm_act", "layer_norm", "layernorm_raw", "msda_prep", "msda",
-          "dwconv3x3", "dwconv_tokens", "maxpool3x3s2", "bilinear_add", "nchw_to_nhwc", "nhwc_to_nchw_f32", "patchify16", "cast",
+          "dwconv3x3", "dwconv_tokens", "maxpool3x3s2", "bilinear_add", "squeeze_excite", "nchw_to_nhwc", "nhwc_to_nchw_f32", "patchify16", "cast",
           "attention"]
 
 

@@ -353,3 +353,73 @@ def test_vit_attention(dt, B, H, N, Dh):
     ref = F.scaled_dot_product_attention(rope(qq), rope(kk), vv).transpose(1, 2).reshape(B * N, H * Dh)
     out = ops.attention(qkv.to(d, dt), sin.to(d), cos.to(d), B, N, H, Dh, prefix, {})
     assert rel(out, ref) < (2e-4 if dt == torch.float32 else 3e-2)
+
+
+# ------------------------------------------------------------------------------------------------ squeeze-excitation
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,H,W,C,with_sc", [(2, 16, 16, 32, True), (3, 8, 8, 256, False), (8, 32, 32, 128, True)])
+def test_squeeze_excite_fwd_bwd(dt, B, H, W, C, with_sc):
+    """SqueezeExcitation + fused residual (dinounet_training.py:210-225,438) vs the torch formula, forward and all gradients."""
+    from dinounet_amd import ops
+    d = dev()
+    R = max(1, C // 16)
+    x = q(gen(B, H, W, C, seed=1), dt)
+    sc = q(gen(B, H, W, C, seed=2), dt) if with_sc else None
+    w1, b1 = gen(R, C, 1, 1, seed=3, scale=0.3), gen(R, seed=4, scale=0.3)
+    w2, b2 = gen(C, R, 1, 1, seed=5, scale=0.3), gen(C, seed=6, scale=0.3)
+    go = q(gen(B, H, W, C, seed=7), dt)
+    ref_in = [t.clone().requires_grad_(True) for t in ([x, w1, b1, w2, b2] + ([sc] if with_sc else []))]
+    s = ref_in[0].mean((1, 2))
+    s = torch.sigmoid(F.linear(F.relu(F.linear(s, ref_in[1].flatten(1), ref_in[2])), ref_in[3].flatten(1), ref_in[4]))
+    yr = ref_in[0] * s[:, None, None, :]
+    if with_sc:
+        yr = yr + ref_in[5]
+    yr.backward(go)
+    ins = [t.to(d).requires_grad_(True) for t in (x.to(dt), w1, b1, w2, b2)]
+    scd = sc.to(d).to(dt).requires_grad_(True) if with_sc else None
+    y = ops.squeeze_excite(*ins, scd)
+    y.backward(go.to(d).to(dt))
+    tol = TOL[dt]
+    assert rel(y, yr) < tol
+    for got, want in zip(ins + ([scd] if with_sc else []), ref_in):
+        assert rel(got.grad, want.grad) < tol * 2, (got.shape, rel(got.grad, want.grad))
+
+
+def test_train_step_hipgraph_matches_eager():
+    """A hipGraph-captured TrainStep (training.TrainStep, what bench.py times) must reproduce eager steps: same losses over several
+    replays, finite gradients (regression test: library reductions/GEMMs inside the captured region went non-finite on the 2nd replay)."""
+    import copy
+    from oracle import weights
+    from oracle.refshim import PLANS_2D
+    from dinounet_amd.dinov3.adapter import DropPath
+    from dinounet_amd.network_architecture import DinoUNet
+    from dinounet_amd.training import TrainStep
+    d = dev()
+
+    def build():
+        net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name="dinounet_s", precision="bf16")
+        ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        net.load_state_dict(weights.make_state_dict(ks, seed=0), strict=True)
+        net = net.to(d).train()
+        for m in net.modules():
+            if isinstance(m, DropPath):
+                m.drop_prob = 0.0
+        net.encoder.dinov3_adapter.backbone.rope_embed.rescale_coords = None
+        return net
+
+    x = weights.make_input(4, 3, 128, 128, seed=3).to(d)
+    tgt = weights.make_target(4, 128, 128, 2, seed=3).to(d)
+    losses = {}
+    for mode in (False, True):
+        net = build()
+        params = [p for p in net.parameters() if p.requires_grad]
+        opt = torch.optim.SGD(params, 1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5)
+        ts = TrainStep(net, opt, params, x.shape, tgt.shape, d, graph=mode, warmup=2)
+        ts(x, tgt)
+        ls = [float(ts()) for _ in range(7)]
+        torch.cuda.synchronize()
+        assert all(np.isfinite(ls)), (mode, ls)
+        assert all(torch.isfinite(p.grad).all() for p in params if p.grad is not None)
+        losses[mode] = ls
+    print("eager", losses[False], "graph", losses[True])
+    assert max(abs(a - b) for a, b in zip(losses[False], losses[True])) < 5e-3

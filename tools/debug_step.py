@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""GPU debugging aid: run eager train steps of the bench workload, print the loss per step and the first
+parameters whose gradient is non-finite; then a per-GEMM-shape timing table (HIP events around every du_gemm launch).
+usage: python tools/debug_step.py [--model dinounet_l] [--batch 8] [--steps 6] [--shapes]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="dinounet_l")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--shapes", action="store_true")
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--graph", action="store_true", help="run the steps through training.TrainStep with hipGraph capture")
+    ap.add_argument("--no-jitter", action="store_true", help="disable drop-path and RoPE rescale")
+    a = ap.parse_args()
+    from oracle.refshim import PLANS_2D
+    from dinounet_amd import ops
+    from dinounet_amd.network_architecture import DinoUNet
+    from dinounet_amd.training import dc_and_ce_loss
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1234)
+    net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name=a.model, precision=a.precision).to(dev).train()
+    params = [p for p in net.parameters() if p.requires_grad]
+    named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=a.lr, momentum=0.99, nesterov=True, weight_decay=3e-5)
+    g = torch.Generator(device="cpu").manual_seed(100)
+    x = torch.randn(a.batch, 3, a.size, a.size, generator=g).to(dev)
+    tgt = torch.randint(0, 2, (a.batch, 1, a.size, a.size), generator=g).to(dev)
+    if a.no_jitter:
+        for m in net.modules():
+            if m.__class__.__name__ == "DropPath":
+                m.drop_prob = 0.0
+        net.encoder.dinov3_adapter.backbone.rope_embed.rescale_coords = None
+    if a.graph:
+        from dinounet_amd.training import TrainStep, dc_and_ce_loss as dcl
+
+        REC = []
+        CNT = [0]
+
+        def wrap(name, fn):
+            def w(*aa, **kk):
+                y = fn(*aa, **kk)
+                outs = y if isinstance(y, tuple) else (y,)
+                for j, o in enumerate(outs):
+                    if torch.is_tensor(o) and o.requires_grad:
+                        idx = CNT[0]; CNT[0] += 1
+                        o.register_hook(lambda g, idx=idx, j=j, shp=tuple(o.shape): REC.append(
+                            (idx, f"{name}[{j}]", shp, g.isfinite().all(), g.float().abs().max())))
+                return y
+            return w
+
+        for fname in ("linear", "conv2d", "conv1x1", "conv_transpose2x2", "norm_act", "layer_norm", "msda", "msda_prep", "dwconv3x3",
+                      "dwconv_tokens", "maxpool3x3s2", "bilinear_add", "nhwc_to_nchw_f32"):
+            setattr(ops, fname, wrap(fname, getattr(ops, fname)))
+
+        class DbgStep(TrainStep):
+            def _step(self):
+                REC.clear(); CNT[0] = 0
+                self.opt.zero_grad(set_to_none=True)
+                logits = self.net(self.x)
+                loss = dcl(logits, self.tgt)
+                loss.backward()
+                self.fin = torch.stack([p.grad.isfinite().all() for _, p in named if p.grad is not None])
+                self.gn = torch.stack([p.grad.float().norm() for _, p in named if p.grad is not None])
+                torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
+                self.opt.step()
+                return loss.detach()
+
+        ts = DbgStep(net, opt, params, x.shape, tgt.shape, dev, graph=True, warmup=3)
+        ts(x, tgt)
+        for it in range(a.steps):
+            loss = ts()
+            torch.cuda.synchronize()
+            gnames = [n for n, p in named if p.grad is not None]
+            pre = [(gnames[i], float(ts.gn[i])) for i in range(len(gnames)) if not bool(ts.fin[i])]
+            def collapse(names, depth=4):
+                d = {}
+                for n in names:
+                    k = ".".join(n.split(".")[:depth])
+                    d[k] = d.get(k, 0) + 1
+                return d
+            badset = set(n for n, _ in pre)
+            print(f"   pre-clip nonfinite: {len(pre)} total pre-clip norm {float(ts.gn.norm()):.4f}")
+            if pre and not getattr(ts, "_reported", False):
+                ts._reported = True
+                print(f"   backward-order activation-gradient trace ({len(REC)} hooks): first non-finite and its neighbours")
+                firstbad = next((i for i, r in enumerate(REC) if not bool(r[3])), None)
+                if firstbad is not None:
+                    for r in REC[max(0, firstbad - 6):firstbad + 4]:
+                        print(f"      fwd#{r[0]:4d} {r[1]:22s} out{r[2]} grad finite={bool(r[3])} absmax={float(r[4]):.4g}")
+                print("   BAD :", collapse(badset))
+                print("   GOOD:", collapse([n for n in gnames if n not in badset]))
+            badg = [n for n, p in named if p.grad is not None and not torch.isfinite(p.grad).all()]
+            badp = [n for n, p in named if not torch.isfinite(p).all()]
+            badb = [n for n, b in net.named_buffers() if b.dtype.is_floating_point and not torch.isfinite(b).all() and "bias_mask" not in n]
+            print(f"graph step {it} (captured={ts.graph is not None}): loss {float(loss):.5f} nonfinite grads {len(badg)} "
+                  f"params {len(badp)} buffers {len(badb)}", flush=True)
+        return
+    for it in range(a.steps):
+        opt.zero_grad(set_to_none=True)
+        y = net(x)
+        loss = dc_and_ce_loss(y, tgt)
+        loss.backward()
+        bad = [(n, float(p.grad.float().abs().max())) for n, p in named if p.grad is not None and not torch.isfinite(p.grad).all()]
+        gn = torch.nn.utils.clip_grad_norm_(params, 12.0)
+        big = sorted(((float(p.grad.float().norm()), n) for n, p in named if p.grad is not None), reverse=True)[:4]
+        print(f"step {it}: loss {float(loss):.5f} logits absmax {float(y.abs().max()):.3f} finite {bool(torch.isfinite(y).all())} "
+              f"gradnorm {float(gn):.4f} nonfinite grads {len(bad)} {bad[:5]} top {big}", flush=True)
+        opt.step()
+    if a.shapes:
+        ops.PROFILE = ops.KernelProfile(detail=True)
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            loss = dc_and_ce_loss(net(x), tgt)
+            loss.backward()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        agg = {}
+        for name, e0, e1, fl, nb in prof.rec:
+            v = agg.setdefault(name, [0.0, 0, 0.0, 0.0])
+            v[0] += e0.elapsed_time(e1); v[1] += 1; v[2] += fl; v[3] += nb
+        tot = sum(v[0] for v in agg.values()) / 2
+        print(f"# per-shape GEMM/attention table (2 eager steps averaged); total {tot:.2f} ms/step")
+        print(f"{'ms/step':>9} {'n/step':>6} {'us/call':>9} {'TF/s':>8} {'GB/s':>8}  kernel")
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            print(f"{v[0] / 2:9.3f} {v[1] // 2:6d} {v[0] / v[1] * 1e3:9.1f} {v[2] / v[0] / 1e9:8.1f} {v[3] / v[0] / 1e6:8.1f}  {k}")
+
+
+if __name__ == "__main__":
+    main()
