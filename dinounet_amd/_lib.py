@@ -45,7 +45,7 @@ def header_prototypes(path=HEADER):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(du_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(du_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         types = []
         if args and args != "void":
@@ -55,7 +55,7 @@ def header_prototypes(path=HEADER):
                     types.append(C.c_void_p)
                 else:
                     types.append(_CTYPE[a.split()[0] if not a.startswith("const") else a.split()[1]])
-        protos[name] = (C.c_char_p if "char" in ret else C.c_int, types)
+        protos[name] = (C.c_char_p if "char" in ret else (C.c_int64 if ret == "int64_t" else C.c_int), types)
     return protos
 
 

@@ -98,7 +98,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, long ldx, long xbs,
                                                                 const T* __restrict__ dy, long lddy, long dybs,
                                                                 float* __restrict__ dw, float* __restrict__ db, int B, int H,
-                                                                int W, int C, int strip) {
+                                                                int W, int C, int strip, float* __restrict__ part) {
   constexpr int V = Elem<T>::VEC;
   __shared__ float red[256 * V];
   const int cvn = C / V;
@@ -149,13 +149,27 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
         for (int j = 0; j < V; j++) {
           float sacc = 0.f;
           for (int q = 0; q < np; q++) sacc += red[(q * cvb + tcv) * V + j];
-          if (k < 9) atomic_add_f32(dw + (c0 + j) * 9 + k, sacc);
+          if (part) part[((long)blockIdx.x * C + c0 + j) * 10 + k] = sacc;    // two-stage: dwconv_wgrad_finalize_kernel sums the strips
+          else if (k < 9) atomic_add_f32(dw + (c0 + j) * 9 + k, sacc);
           else if (db) atomic_add_f32(db + c0 + j, sacc);
         }
       }
       __syncthreads();
     }
   }
+}
+
+// dw[c][k] (+)= sum_blocks part[blk][c][k] (k < 9), db[c] (+)= part[blk][c][9]; `accum` adds to the existing values (later image
+// segments of the same depthwise kernel, dinov3_adapter.py:99-109)
+__global__ __launch_bounds__(256) void dwconv_wgrad_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                    float* __restrict__ db, int blocks, int C, int accum) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * 10) return;
+  float acc = 0.f;
+  for (int b = 0; b < blocks; b++) acc += part[(long)b * C * 10 + i];
+  const int c = i / 10, k = i - c * 10;
+  if (k < 9) dw[c * 9 + k] = accum ? dw[c * 9 + k] + acc : acc;
+  else if (db) db[c] = accum ? db[c] + acc : acc;
 }
 
 // ---------------- max-pool 3x3 stride 2 pad 1 (dinov3_adapter.py:250); idx = winning tap (first max in scan order) -----------
@@ -532,22 +546,38 @@ extern "C" int du_dwconv3x3_bwd_data(int dtype, const void* dy, int64_t lddy, in
   return du_check_launch();
 }
 
-extern "C" int du_dwconv3x3_bwd_weight(int dtype, const void* x, int64_t ldx, int64_t xbs, const void* dy, int64_t lddy, int64_t dybs,
-                                       float* dw, float* db, int B, int H, int W, int C, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  const int v = dtype == DU_BF16 ? 8 : 4;
-  if (!x || !dy || !dw || B <= 0 || C % v || ldx % v || lddy % v || xbs % v || dybs % v) return DU_ERR_BAD_ARG;
-  const long npix = (long)B * H * W;
+static inline int dwconv_wgrad_strip(long npix, int C, int v) {
   // ~1024 workgroups per launch, but at least 4 pixels per pixel lane so the 10-round LDS reduction stays amortised
   const int cvb_ = (C / v) < 256 ? (C / v) : 256;
   const int np_ = 256 / cvb_;
   long strip_l = (npix + 1023) / 1024;
   if (strip_l < (long)np_ * 4) strip_l = (long)np_ * 4;
-  int strip = (int)strip_l;
+  return (int)strip_l;
+}
+
+extern "C" int64_t du_dwconv_wgrad_ws_elems(int dtype, int B, int H, int W, int C) {
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % v) return 0;
+  const long npix = (long)B * H * W;
+  const int strip = dwconv_wgrad_strip(npix, C, v);
+  return (int64_t)((npix + strip - 1) / strip) * C * 10;
+}
+
+extern "C" int du_dwconv3x3_bwd_weight(int dtype, const void* x, int64_t ldx, int64_t xbs, const void* dy, int64_t lddy, int64_t dybs,
+                                       float* dw, float* db, int B, int H, int W, int C, float* ws, int64_t ws_elems, int accumulate,
+                                       void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (!x || !dy || !dw || B <= 0 || C % v || ldx % v || lddy % v || xbs % v || dybs % v) return DU_ERR_BAD_ARG;
+  const long npix = (long)B * H * W;
+  const int strip = dwconv_wgrad_strip(npix, C, v);
   long blocks = (npix + strip - 1) / strip;
+  float* part = (ws && ws_elems >= blocks * C * 10) ? ws : nullptr;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, xbs, (const bf16_t*)dy, lddy, dybs, dw, db, B, H, W, C, strip),
-             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, ldx, xbs, (const float*)dy, lddy, dybs, dw, db, B, H, W, C, strip));
+             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, xbs, (const bf16_t*)dy, lddy, dybs, dw, db, B, H, W, C, strip, part),
+             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, ldx, xbs, (const float*)dy, lddy, dybs, dw, db, B, H, W, C, strip, part));
+  if (part)
+    hipLaunchKernelGGL(dwconv_wgrad_finalize_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, st, (const float*)part, dw, db, (int)blocks, C, accumulate);
   return du_check_launch();
 }
 

@@ -14,59 +14,9 @@
 // padding per row); the next tile's global loads are issued before the current tile's MFMAs so HBM/L2 latency
 // hides under the matrix pipe.
 #include "common.h"
+#include "gemm_params.h"
 
 namespace {
-
-struct Operand {
-  const void* p; long ld; long bstride;
-  const void* p2; long ld2; int C1;
-  int Hi, Wi, C, KH, KW, stride, pad, Ho, Wo, transposed;
-  int logC;  // log2(C) if C is a power of two else -1
-};
-
-struct GemmParams {
-  Operand a, b;
-  void* C; long ldc; long cbs;
-  int M, N, K;
-  int split_k, k_per_split;
-  float alpha; const float* bias; int act; const float* gamma; const float* row_scale; int rs_rows;
-  const void* residual; long ldr;
-  int store_mode, ps_H, ps_W, ps_C;
-  int tiles_n;
-};
-
-__device__ __forceinline__ int div_small(int x, int d) {
-  if (d == 3) return (x * 11) >> 5;  // exact for x < 32
-  if (d == 2) return x >> 1;
-  if (d == 1) return x;
-  return x / d;
-}
-
-// address of element (pixel (b,yo,xo), column c=(tap,ci)) of the im2col matrix; returns nullptr if padding
-template <typename T>
-__device__ __forceinline__ const T* im2col_ptr(const Operand& op, int b, int yo, int xo, int c) {
-  int tap = op.logC >= 0 ? (c >> op.logC) : (c / op.C);
-  int ci = c - tap * op.C;
-  int dy = div_small(tap, op.KW);
-  int dx = tap - dy * op.KW;
-  int yi, xi;
-  bool ok;
-  if (!op.transposed) {
-    yi = yo * op.stride - op.pad + dy;
-    xi = xo * op.stride - op.pad + dx;
-    ok = (yi >= 0) & (yi < op.Hi) & (xi >= 0) & (xi < op.Wi);
-  } else {
-    int ty = yo + op.pad - dy, tx = xo + op.pad - dx;
-    if (op.stride == 1) { yi = ty; xi = tx; ok = true; }
-    else if (op.stride == 2) { yi = ty >> 1; xi = tx >> 1; ok = ((ty & 1) == 0) & ((tx & 1) == 0); }
-    else { yi = ty / op.stride; xi = tx / op.stride; ok = (yi * op.stride == ty) & (xi * op.stride == tx); }
-    ok = ok & (ty >= 0) & (tx >= 0) & (yi < op.Hi) & (xi < op.Wi);
-  }
-  if (!ok) return nullptr;
-  long sp = ((long)b * op.Hi + yi) * op.Wi + xi;
-  if (ci < op.C1) return (const T*)op.p + sp * op.ld + ci;
-  return (const T*)op.p2 + sp * op.ld2 + (ci - op.C1);
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // Tile loader: OUTER x BK tile of one operand -> registers -> LDS S[OUTER][BK + VEC]
@@ -309,41 +259,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams P) {
   }
 }
 
-int ilog2_exact(int x) {
-  if (x <= 0 || (x & (x - 1))) return -1;
-  int l = 0; while ((1 << l) < x) l++;
-  return l;
-}
-
-Operand make_operand(const void* p, long ld, long bs, int mode, const du_conv_geom& g) {
-  Operand o{};
-  o.p = p; o.ld = ld; o.bstride = bs;
-  if (mode == DU_IM2COL_ROW || mode == DU_IM2COL_COL) {
-    o.p2 = g.p2; o.ld2 = g.ld2; o.C1 = g.p2 ? g.C1 : g.C;
-    o.Hi = g.Hi; o.Wi = g.Wi; o.C = g.C; o.KH = g.KH; o.KW = g.KW; o.stride = g.stride; o.pad = g.pad;
-    o.Ho = g.Ho; o.Wo = g.Wo; o.transposed = g.transposed; o.logC = ilog2_exact(g.C);
-  }
-  return o;
-}
-
 template <typename T, typename TC, int AMODE, int BMODE, int WM, int WN, int TM, int TN>
 int launch_cfg(const du_gemm_args& a, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = TileK<T>::BK;
-  GemmParams P{};
-  P.a = make_operand(a.A, a.lda, a.a_batch_stride, AMODE, a.geom);
-  P.b = make_operand(a.B, a.ldb, a.b_batch_stride, BMODE, a.geom);
-  P.C = a.C; P.ldc = a.ldc; P.cbs = a.c_batch_stride;
-  P.M = a.M; P.N = a.N; P.K = a.K;
-  P.split_k = a.split_k < 1 ? 1 : a.split_k;
-  int kps = (a.K + P.split_k - 1) / P.split_k;
-  kps = ((kps + BK - 1) / BK) * BK;
-  P.k_per_split = kps;
-  P.split_k = (a.K + kps - 1) / kps;  // drop empty splits
-  if (a.split_k > 1 && P.split_k == 1) P.split_k = 1;
-  P.alpha = a.alpha; P.bias = a.bias; P.act = a.act; P.gamma = a.gamma; P.row_scale = a.row_scale; P.rs_rows = a.rs_rows > 0 ? a.rs_rows : 1; P.residual = a.residual; P.ldr = a.ldr;
-  P.store_mode = a.store_mode; P.ps_H = a.ps_H; P.ps_W = a.ps_W; P.ps_C = a.ps_C;
+  GemmParams P = make_params(a, AMODE, BMODE, BM, BN, BK);
   int tiles_m = (a.M + BM - 1) / BM;
-  P.tiles_n = (a.N + BN - 1) / BN;
   // when the caller asked for split-K but it collapsed to one split the epilogue must still accumulate
   // (C was zero-filled, no epilogue ops) -- plain store of alpha*acc is equivalent.
   dim3 grid(tiles_m * P.tiles_n, (a.batch < 1 ? 1 : a.batch) * P.split_k);
@@ -372,6 +292,8 @@ int launch_dtype(const du_gemm_args& a, hipStream_t st) {
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
+
+int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st);   // gemm_bf16.hip
 
 extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
   if (!pa) return DU_ERR_BAD_ARG;
@@ -402,6 +324,11 @@ extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
   if (a.split_k > 1 && (a.out_dtype != DU_F32 || a.bias || a.act || a.gamma || a.row_scale || a.residual || a.store_mode)) return DU_ERR_BAD_ARG;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && (a.ps_C <= 0 || a.N != 4 * a.ps_C || a.M % (a.ps_H * a.ps_W))) return DU_ERR_BAD_ARG;
   if (a.dtype == DU_BF16) {
+    static const bool generic_only = getenv("DU_GEMM_GENERIC") != nullptr;   // debugging aid: force the generic kernel
+    if (!generic_only) {
+      int rc = du_gemm_bf16_fast(a, st);
+      if (rc != DU_ERR_UNSUPPORTED) return rc;
+    }
     if (a.out_dtype == DU_BF16) return launch_dtype<bf16_t, bf16_t>(a, st);
     return launch_dtype<bf16_t, float>(a, st);
   }

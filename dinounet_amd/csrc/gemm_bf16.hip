@@ -1,0 +1,361 @@
+// bf16 MFMA GEMM / implicit-convolution engine for gfx950 (throughput path of du_gemm; the fp32 parity mode and the rarely
+// used operand combinations stay on the generic kernel in gemm.hip).
+//
+//   C[m][n] = epilogue( alpha * sum_k A(m,k) * B(n,k) ),  v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+//
+// What is different from the generic kernel, and why (rocprofv3 per-shape table, profiles/r01_*):
+//  * operands whose CONTRACTION index is the slow one in memory (weight gradients: A = dY^T, B = X^T / im2col(X)^T) are staged
+//    as they lie -- LDS image [k][outer], 16-byte copies, no element-wise transposing stores -- and the MFMA fragments are
+//    fetched with the LDS transpose read ds_read_b64_tr_b16 (two per fragment).  Row pitch = 64 B (mod 256 B) keeps the four
+//    k-rows of one transpose read on disjoint bank groups.
+//  * two LDS buffers and ONE barrier per K step: tile t+1 is fetched into registers before the MFMAs of tile t are issued and
+//    written to the other buffer after them.
+//  * the epilogue goes through LDS: accumulators are parked as fp32 rows, then every thread applies bias / activation /
+//    LayerScale / DropPath scale / residual to 4 consecutive columns and stores 8 B (bf16) or 16 B (fp32) so each output row is
+//    written in full cache lines (the per-lane scalar stores of the generic kernel ran the HBM-bound small-K shapes at < 1 TB/s).
+//  * workgroup -> tile mapping is XCD-aware: the 8 XCDs each walk a contiguous range of tiles, so tiles that share an A row
+//    panel hit the same L2.
+#include "common.h"
+#include "gemm_params.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 64;
+constexpr int ROW_LD = BK + 8;   // ROW image: S[outer][BK + 8]   (144-B pitch: conflict-free ds_read_b128 fragments)
+
+__host__ __device__ constexpr int col_pitch(int outer) { return (outer * 2) % 256 == 64 || (outer * 2) % 256 == 192 ? outer : outer + 32; }
+__host__ __device__ constexpr bool is_row(int mode) { return mode == DU_PLAIN_ROW || mode == DU_IM2COL_ROW; }
+__host__ __device__ constexpr int tile_elems(int mode, int outer) { return is_row(mode) ? outer * ROW_LD : BK * col_pitch(outer); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// global -> registers -> LDS tile loader (OUTER x BK of one operand), 16-byte vectors
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE, int OUTER>
+struct Loader {
+  static constexpr int NT = 256, VEC = 8;
+  static constexpr bool ROWMODE = is_row(MODE);
+  static constexpr int PITCH = ROWMODE ? ROW_LD : col_pitch(OUTER);
+  static constexpr int TOTAL = OUTER * BK / VEC;
+  static constexpr int NV = (TOTAL + NT - 1) / NT;
+  static constexpr int KV = BK / VEC;      // vectors per row (ROW modes)
+  static constexpr int OV = OUTER / VEC;   // vectors per k-row (COL modes)
+  uint4 regs[NV];
+  int pb[NV], py[NV], px[NV];
+
+  __device__ __forceinline__ void init(const Operand& op, int tid, int o0, int outer_dim, int kbeg) {
+    if constexpr (MODE == DU_IM2COL_ROW) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        int v = tid + i * NT;
+        int o = o0 + v / KV;
+        if (o >= outer_dim) o = outer_dim - 1;
+        int xo = o % op.Wo; int t = o / op.Wo;
+        px[i] = xo; py[i] = t % op.Ho; pb[i] = t / op.Ho;
+      }
+    } else if constexpr (MODE == DU_IM2COL_COL) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        int v = tid + i * NT;
+        long pix = (long)kbeg + v / OV;
+        int xo = (int)(pix % op.Wo); long t = pix / op.Wo;
+        px[i] = xo; py[i] = (int)(t % op.Ho); pb[i] = (int)(t / op.Ho);
+      }
+    }
+  }
+  __device__ __forceinline__ void advance(const Operand& op) {
+    if constexpr (MODE == DU_IM2COL_COL) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        px[i] += BK;
+        while (px[i] >= op.Wo) { px[i] -= op.Wo; py[i]++; }
+        while (py[i] >= op.Ho) { py[i] -= op.Ho; pb[i]++; }
+      }
+    }
+  }
+  __device__ __forceinline__ void load(const Operand& op, int tid, int o0, int outer_dim, int k0, int kend) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      int v = tid + i * NT;
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (TOTAL % NT == 0 || v < TOTAL) {
+        if constexpr (MODE == DU_PLAIN_ROW) {
+          int o = o0 + v / KV, k = k0 + (v % KV) * VEC;
+          if (o < outer_dim && k < kend) r = *(const uint4*)((const bf16_t*)op.p + (long)o * op.ld + k);
+        } else if constexpr (MODE == DU_PLAIN_COL) {
+          int k = k0 + v / OV, o = o0 + (v % OV) * VEC;
+          if (o < outer_dim && k < kend) r = *(const uint4*)((const bf16_t*)op.p + (long)k * op.ld + o);
+        } else if constexpr (MODE == DU_IM2COL_ROW) {
+          int o = o0 + v / KV, k = k0 + (v % KV) * VEC;
+          if (o < outer_dim && k < kend) {
+            const bf16_t* q = im2col_ptr<bf16_t>(op, pb[i], py[i], px[i], k);
+            if (q) r = *(const uint4*)q;
+          }
+        } else {
+          int k = k0 + v / OV, o = o0 + (v % OV) * VEC;
+          if (o < outer_dim && k < kend) {
+            const bf16_t* q = im2col_ptr<bf16_t>(op, pb[i], py[i], px[i], o);
+            if (q) r = *(const uint4*)q;
+          }
+        }
+      }
+      regs[i] = r;
+    }
+  }
+  __device__ __forceinline__ void store(bf16_t* S, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      int v = tid + i * NT;
+      if (TOTAL % NT == 0 || v < TOTAL) {
+        if constexpr (ROWMODE) *(uint4*)(S + (v / KV) * PITCH + (v % KV) * VEC) = regs[i];
+        else *(uint4*)(S + (v / OV) * PITCH + (v % OV) * VEC) = regs[i];
+      }
+    }
+  }
+  // MFMA operand fragment of the 32-row block starting at outer index i0 (tile-local), k-step kk (16 contraction elements):
+  // lane l <-> outer i0 + (l & 31), contraction kk*16 + 8*(l >> 5) + 0..7
+  static __device__ __forceinline__ bf16x8 frag(const bf16_t* S, int i0, int kk, int lane) {
+    if constexpr (ROWMODE) {
+      return *(const bf16x8*)(S + (i0 + (lane & 31)) * PITCH + kk * 16 + (lane >> 5) * 8);
+    } else {
+      const int g = lane >> 4, p = lane & 15;
+      const bf16_t* q = S + (kk * 16 + 8 * (g >> 1) + (p >> 2)) * PITCH + i0 + 16 * (g & 1) + 4 * (p & 3);
+      typedef __attribute__((address_space(3))) s16x4 lds_v4;
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)q);
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(q + 4 * PITCH));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      s16x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      return __builtin_bit_cast(bf16x8, r);
+    }
+  }
+};
+
+template <typename TC> struct Out4;
+template <> struct Out4<float> {
+  static __device__ __forceinline__ void load(const float* p, float* v) { float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  static __device__ __forceinline__ void store(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Out4<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float* v) {
+    bf16x4 t = __builtin_bit_cast(bf16x4, *(const uint2*)p);
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = (float)t[j];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
+    bf16x4 t;
+#pragma unroll
+    for (int j = 0; j < 4; j++) t[j] = (bf16_t)v[j];
+    *(uint2*)p = __builtin_bit_cast(uint2, t);
+  }
+};
+
+template <int AMODE, int BMODE, typename TC, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int A_EL = tile_elems(AMODE, BM), B_EL = tile_elems(BMODE, BN);
+  constexpr int STG_LD = BN + 4;
+  static_assert(WM * WN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* smem = (bf16_t*)smem_raw;
+  constexpr int BUF_EL = A_EL + B_EL;       // buffer b: A tile at smem + b*BUF_EL, B tile right behind it
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  // XCD-aware tile order: hardware places workgroup b on XCD b % 8; give each XCD a contiguous range of tiles
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (tile / P.tiles_n) * BM, n0 = (tile % P.tiles_n) * BN;
+  const int z = blockIdx.y;
+  const int batch = z / P.split_k, split = z % P.split_k;
+  const int kbeg = split * P.k_per_split;
+  const int kend = min(P.K, kbeg + P.k_per_split);
+
+  Operand opa = P.a, opb = P.b;
+  opa.p = (const bf16_t*)opa.p + (long)batch * opa.bstride;
+  opb.p = (const bf16_t*)opb.p + (long)batch * opb.bstride;
+
+  Loader<AMODE, BM> la;
+  Loader<BMODE, BN> lb;
+  la.init(opa, tid, m0, P.M, kbeg);
+  lb.init(opb, tid, n0, P.N, kbeg);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    la.load(opa, tid, m0, P.M, kbeg, kend);
+    lb.load(opb, tid, n0, P.N, kbeg, kend);
+    la.store(smem, tid);
+    lb.store(smem + A_EL, tid);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      la.advance(opa); lb.advance(opb);
+      la.load(opa, tid, m0, P.M, kbeg + (kt + 1) * BK, kend);
+      lb.load(opb, tid, n0, P.N, kbeg + (kt + 1) * BK, kend);
+    }
+    const bf16_t* Ac = smem + cur * BUF_EL;
+    const bf16_t* Bc = Ac + A_EL;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; kk++) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) fa[i] = Loader<AMODE, BM>::frag(Ac, (wm * TM + i) * 32, kk, lane);
+#pragma unroll
+      for (int j = 0; j < TN; j++) fb[j] = Loader<BMODE, BN>::frag(Bc, (wn * TN + j) * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      la.store(smem + (cur ^ 1) * BUF_EL, tid);
+      lb.store(smem + (cur ^ 1) * BUF_EL + A_EL, tid);
+    }
+    __syncthreads();
+  }
+
+  TC* Cb = (TC*)P.C + (long)batch * P.cbs;
+  // ---- split-K: fp32 atomics straight from the accumulators (lanes 0..31 = 32 consecutive columns) ----
+  if (P.split_k > 1) {
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+      if (n >= P.N) continue;
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < P.M) atomic_add_f32((float*)Cb + (long)m * P.ldc + n, acc[i][j][r] * P.alpha);
+        }
+    }
+    return;
+  }
+  // ---- LDS-staged epilogue: WM*32 rows x BN columns of fp32 per pass ----
+  float* stg = (float*)smem_raw;
+  const TC* Rb = (const TC*)P.residual;
+  if (Rb) Rb += (long)batch * P.cbs;
+  constexpr int C4 = BN / 4;                 // float4 groups per staged row
+  constexpr int NVEC = WM * 32 * C4;
+#pragma unroll
+  for (int i = 0; i < TM; i++) {
+    if (i > 0) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        stg[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * STG_LD + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
+    __syncthreads();
+    for (int v = tid; v < NVEC; v += 256) {
+      const int row = v / C4, c4 = v % C4;
+      const int m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
+      const int n = n0 + c4 * 4;
+      if (m >= P.M || n >= P.N) continue;
+      float4 t = *(const float4*)(stg + row * STG_LD + c4 * 4);
+      float o[4] = {t.x * P.alpha, t.y * P.alpha, t.z * P.alpha, t.w * P.alpha};
+      if (P.bias) {
+        float4 bb = *(const float4*)(P.bias + n);
+        o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
+      }
+      if (P.act != DU_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = apply_act(o[e], P.act);
+      }
+      if (P.gamma) {
+        float4 gg = *(const float4*)(P.gamma + n);
+        o[0] *= gg.x; o[1] *= gg.y; o[2] *= gg.z; o[3] *= gg.w;
+      }
+      if (P.row_scale) {
+        const float rs = P.row_scale[m / P.rs_rows];
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] *= rs;
+      }
+      if (Rb) {
+        float rr[4];
+        Out4<TC>::load(Rb + (long)m * P.ldr + n, rr);
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] += rr[e];
+      }
+      long off;
+      if (P.store_mode == DU_STORE_PIXEL_SHUFFLE2) {
+        const int ps_q = n / P.ps_C, ps_co = n - ps_q * P.ps_C;
+        int x = m % P.ps_W; int t2 = m / P.ps_W; int y = t2 % P.ps_H; int b = t2 / P.ps_H;
+        off = (((long)b * 2 * P.ps_H + 2 * y + (ps_q >> 1)) * (2 * P.ps_W) + 2 * x + (ps_q & 1)) * P.ldc + ps_co;
+      } else {
+        off = (long)m * P.ldc + n;
+      }
+      Out4<TC>::store(Cb + off, o);
+    }
+  }
+}
+
+template <int AMODE, int BMODE, typename TC, int WM, int WN, int TM, int TN>
+int launch_cfg(const du_gemm_args& a, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int A_EL = tile_elems(AMODE, BM), B_EL = tile_elems(BMODE, BN);
+  constexpr int MAIN_BYTES = 2 * (A_EL + B_EL) * 2;
+  constexpr int STG_BYTES = WM * 32 * (BN + 4) * 4;
+  constexpr int LDS_BYTES = MAIN_BYTES > STG_BYTES ? MAIN_BYTES : STG_BYTES;
+  GemmParams P = make_params(a, AMODE, BMODE, BM, BN, BK);
+  dim3 grid(((a.M + BM - 1) / BM) * P.tiles_n, (a.batch < 1 ? 1 : a.batch) * P.split_k);
+  auto kfn = gemm_bf16_kernel<AMODE, BMODE, TC, WM, WN, TM, TN>;
+  static bool attr_set = false;   // per instantiation
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return DU_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kfn, grid, dim3(256), LDS_BYTES, st, P);
+  return du_check_launch();
+}
+
+template <int AMODE, int BMODE, typename TC>
+int launch_shape(const du_gemm_args& a, hipStream_t st) {
+  // tile shapes: 128x128 default; narrow-N and narrow-M variants keep the MFMA work close to the useful work for the
+  // 32/64-channel decoder convolutions (N small) and their weight gradients (M small)
+  if (a.N <= 32) return launch_cfg<AMODE, BMODE, TC, 4, 1, 1, 1>(a, st);                  // 128 x 32
+  if (a.M <= 32) return launch_cfg<AMODE, BMODE, TC, 1, 4, 1, 1>(a, st);                  // 32 x 128
+  if (a.N <= 64) return launch_cfg<AMODE, BMODE, TC, 2, 2, 2, 1>(a, st);                  // 128 x 64
+  if (a.M <= 64) return launch_cfg<AMODE, BMODE, TC, 2, 2, 1, 2>(a, st);                  // 64 x 128
+  return launch_cfg<AMODE, BMODE, TC, 2, 2, 2, 2>(a, st);                                  // 128 x 128
+}
+
+template <typename TC>
+int launch_modes(const du_gemm_args& a, hipStream_t st) {
+  const int am = a.a_mode, bm = a.b_mode;
+  if (am == DU_PLAIN_ROW && bm == DU_PLAIN_ROW) return launch_shape<DU_PLAIN_ROW, DU_PLAIN_ROW, TC>(a, st);
+  if (am == DU_IM2COL_ROW && bm == DU_PLAIN_ROW) return launch_shape<DU_IM2COL_ROW, DU_PLAIN_ROW, TC>(a, st);
+  if (am == DU_PLAIN_COL && bm == DU_PLAIN_COL) return launch_shape<DU_PLAIN_COL, DU_PLAIN_COL, TC>(a, st);
+  if (am == DU_PLAIN_COL && bm == DU_IM2COL_COL) return launch_shape<DU_PLAIN_COL, DU_IM2COL_COL, TC>(a, st);
+  if (am == DU_PLAIN_ROW && bm == DU_PLAIN_COL) return launch_shape<DU_PLAIN_ROW, DU_PLAIN_COL, TC>(a, st);
+  return DU_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// returns DU_ERR_UNSUPPORTED when the generic kernel must be used instead
+int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
+  if (a.dtype != DU_BF16) return DU_ERR_UNSUPPORTED;
+  if (a.N % 4 || a.ldc % 4 || (((uintptr_t)a.C) & 15)) return DU_ERR_UNSUPPORTED;
+  if (a.bias && (((uintptr_t)a.bias) & 15)) return DU_ERR_UNSUPPORTED;
+  if (a.gamma && (((uintptr_t)a.gamma) & 15)) return DU_ERR_UNSUPPORTED;
+  if (a.residual && (a.ldr % 4 || (((uintptr_t)a.residual) & 15))) return DU_ERR_UNSUPPORTED;
+  if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && a.ps_C % 4) return DU_ERR_UNSUPPORTED;
+  if (a.c_batch_stride % 4) return DU_ERR_UNSUPPORTED;
+  if (a.out_dtype == DU_BF16) return launch_modes<bf16_t>(a, st);
+  return launch_modes<float>(a, st);
+}

@@ -1,0 +1,99 @@
+// Shared by gemm.hip (generic fp32/bf16 kernel) and gemm_bf16.hip (bf16 throughput kernel): kernel parameter block,
+// im2col addressing and the host-side packing of du_gemm_args.
+#pragma once
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+struct Operand {
+  const void* p; long ld; long bstride;
+  const void* p2; long ld2; int C1;
+  int Hi, Wi, C, KH, KW, stride, pad, Ho, Wo, transposed;
+  int logC;  // log2(C) if C is a power of two else -1
+};
+
+struct GemmParams {
+  Operand a, b;
+  void* C; long ldc; long cbs;
+  int M, N, K;
+  int split_k, k_per_split;
+  float alpha; const float* bias; int act; const float* gamma; const float* row_scale; int rs_rows;
+  const void* residual; long ldr;
+  int store_mode, ps_H, ps_W, ps_C;
+  int tiles_n;
+};
+
+__device__ __forceinline__ int div_small(int x, int d) {
+  if (d == 3) return (x * 11) >> 5;  // exact for x < 32
+  if (d == 2) return x >> 1;
+  if (d == 1) return x;
+  return x / d;
+}
+
+// address of element (pixel (b,yo,xo), column c=(tap,ci)) of the im2col matrix; returns nullptr if padding
+template <typename T>
+__device__ __forceinline__ const T* im2col_ptr(const Operand& op, int b, int yo, int xo, int c) {
+  int tap = op.logC >= 0 ? (c >> op.logC) : (c / op.C);
+  int ci = c - tap * op.C;
+  int dy = div_small(tap, op.KW);
+  int dx = tap - dy * op.KW;
+  int yi, xi;
+  bool ok;
+  if (!op.transposed) {
+    yi = yo * op.stride - op.pad + dy;
+    xi = xo * op.stride - op.pad + dx;
+    ok = (yi >= 0) & (yi < op.Hi) & (xi >= 0) & (xi < op.Wi);
+  } else {
+    int ty = yo + op.pad - dy, tx = xo + op.pad - dx;
+    if (op.stride == 1) { yi = ty; xi = tx; ok = true; }
+    else if (op.stride == 2) { yi = ty >> 1; xi = tx >> 1; ok = ((ty & 1) == 0) & ((tx & 1) == 0); }
+    else { yi = ty / op.stride; xi = tx / op.stride; ok = (yi * op.stride == ty) & (xi * op.stride == tx); }
+    ok = ok & (ty >= 0) & (tx >= 0) & (yi < op.Hi) & (xi < op.Wi);
+  }
+  if (!ok) return nullptr;
+  long sp = ((long)b * op.Hi + yi) * op.Wi + xi;
+  if (ci < op.C1) return (const T*)op.p + sp * op.ld + ci;
+  return (const T*)op.p2 + sp * op.ld2 + (ci - op.C1);
+}
+
+
+inline int ilog2_exact(int x) {
+  if (x <= 0 || (x & (x - 1))) return -1;
+  int l = 0; while ((1 << l) < x) l++;
+  return l;
+}
+
+inline Operand make_operand(const void* p, long ld, long bs, int mode, const du_conv_geom& g) {
+  Operand o{};
+  o.p = p; o.ld = ld; o.bstride = bs;
+  if (mode == DU_IM2COL_ROW || mode == DU_IM2COL_COL) {
+    o.p2 = g.p2; o.ld2 = g.ld2; o.C1 = g.p2 ? g.C1 : g.C;
+    o.Hi = g.Hi; o.Wi = g.Wi; o.C = g.C; o.KH = g.KH; o.KW = g.KW; o.stride = g.stride; o.pad = g.pad;
+    o.Ho = g.Ho; o.Wo = g.Wo; o.transposed = g.transposed; o.logC = ilog2_exact(g.C);
+  }
+  return o;
+}
+
+
+// BM/BN/BK: tile shape of the kernel about to be launched (split-K chunks are rounded to whole K tiles)
+inline GemmParams make_params(const du_gemm_args& a, int amode, int bmode, int BM, int BN, int BKt) {
+  GemmParams P{};
+  P.a = make_operand(a.A, a.lda, a.a_batch_stride, amode, a.geom);
+  P.b = make_operand(a.B, a.ldb, a.b_batch_stride, bmode, a.geom);
+  P.C = a.C; P.ldc = a.ldc; P.cbs = a.c_batch_stride;
+  P.M = a.M; P.N = a.N; P.K = a.K;
+  P.split_k = a.split_k < 1 ? 1 : a.split_k;
+  int kps = (a.K + P.split_k - 1) / P.split_k;
+  kps = ((kps + BKt - 1) / BKt) * BKt;
+  P.k_per_split = kps;
+  P.split_k = (a.K + kps - 1) / kps;  // drop empty splits
+  P.alpha = a.alpha; P.bias = a.bias; P.act = a.act; P.gamma = a.gamma; P.row_scale = a.row_scale;
+  P.rs_rows = a.rs_rows > 0 ? a.rs_rows : 1; P.residual = a.residual; P.ldr = a.ldr;
+  P.store_mode = a.store_mode; P.ps_H = a.ps_H; P.ps_W = a.ps_W; P.ps_C = a.ps_C;
+  P.tiles_n = (a.N + BN - 1) / BN;
+  (void)BM;
+  return P;
+}
+
+}  // namespace

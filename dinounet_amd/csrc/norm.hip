@@ -106,7 +106,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const T* __restri
 static inline int pick_strip(int G, long P, int C, int vec) {
   const int cvb = (C / vec) < 256 ? (C / vec) : 256;
   const int np = 256 / (cvb > 0 ? cvb : 1);
-  long per_group = 2048 / (G > 0 ? G : 1);
+  long target = 65536L * 8 / C;              // wide rows: fewer, longer strips keep the partial buffer (strips x C x 2) small
+  if (target > 2048) target = 2048;
+  if (target < 256) target = 256;
+  long per_group = target / (G > 0 ? G : 1);
   if (per_group < 1) per_group = 1;
   long s = (P + per_group - 1) / per_group;
   const long smin = (long)np * 4;
@@ -120,7 +123,7 @@ struct StatOp;
 
 // generic strip reducer: F(xvec, dyvec, g, c0) -> (a[VEC], b[VEC]) accumulated per channel, then written with atomics
 template <typename T, typename F>
-__device__ __forceinline__ void strip_reduce(int G, long P, int C, int STRIP, float* out /*[G][C][2]*/, F f) {
+__device__ __forceinline__ void strip_reduce(int G, long P, int C, int STRIP, float* out /*[G][C][2]*/, float* part, F f) {
   constexpr int V = Elem<T>::VEC;
   __shared__ float red[2][256 * V];
   const int cv_total = C / V;
@@ -149,8 +152,13 @@ __device__ __forceinline__ void strip_reduce(int G, long P, int C, int STRIP, fl
       for (int j = 0; j < V; j++) {
         float sa = 0.f, sb = 0.f;
         for (int q = 0; q < np; q++) { sa += red[0][(q * cvb + tcv) * V + j]; sb += red[1][(q * cvb + tcv) * V + j]; }
-        atomic_add_f32(out + ((long)g * C + cv * V + j) * 2 + 0, sa);
-        atomic_add_f32(out + ((long)g * C + cv * V + j) * 2 + 1, sb);
+        if (part) {   // two-stage: this strip's partial goes to part[blockIdx.x][C][2]; finalize_kernel sums the strips
+          part[((long)blockIdx.x * C + cv * V + j) * 2 + 0] = sa;
+          part[((long)blockIdx.x * C + cv * V + j) * 2 + 1] = sb;
+        } else {
+          atomic_add_f32(out + ((long)g * C + cv * V + j) * 2 + 0, sa);
+          atomic_add_f32(out + ((long)g * C + cv * V + j) * 2 + 1, sb);
+        }
       }
     }
     __syncthreads();
@@ -162,9 +170,9 @@ __device__ __forceinline__ void strip_reduce(int G, long P, int C, int STRIP, fl
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_wb_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                               float* __restrict__ out, long rows, int D, int strip) {
+                                                               float* __restrict__ out, long rows, int D, int strip, float* part) {
   constexpr int V = Elem<T>::VEC;
-  strip_reduce<T>(1, rows, D, strip, out, [&](long row, int g, int c0, float* a, float* b) {
+  strip_reduce<T>(1, rows, D, strip, out, part, [&](long row, int g, int c0, float* a, float* b) {
     Vec16<T> tx = as_vec<T>(*(const uint4*)(x + row * (long)D + c0));
     Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + row * (long)D + c0));
     const float mu = mean[row], rs = rstd[row];
@@ -179,9 +187,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wb_kernel(const T* __restri
 
 template <typename T>
 __global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ x, long ldx, float* __restrict__ sums, int G,
-                                                         long P, int C, int strip) {
+                                                         long P, int C, int strip, float* part) {
   constexpr int V = Elem<T>::VEC;
-  strip_reduce<T>(G, P, C, strip, sums, [&](long pix, int g, int c0, float* a, float* b) {
+  strip_reduce<T>(G, P, C, strip, sums, part, [&](long pix, int g, int c0, float* a, float* b) {
     Vec16<T> t = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
 #pragma unroll
     for (int j = 0; j < V; j++) { float v = to_f32(t.v[j]); a[j] += v; b[j] += v * v; }
@@ -191,9 +199,9 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ x
 // sums[g][c] += (sum_pix a*b, sum_pix a)   (squeeze-excitation gate gradient: a = dy, b = x)
 template <typename T>
 __global__ __launch_bounds__(256) void chan_dot_kernel(const T* __restrict__ a_, long lda, const T* __restrict__ b_, long ldb,
-                                                       float* __restrict__ sums, int G, long P, int C, int strip) {
+                                                       float* __restrict__ sums, int G, long P, int C, int strip, float* part) {
   constexpr int V = Elem<T>::VEC;
-  strip_reduce<T>(G, P, C, strip, sums, [&](long pix, int g, int c0, float* a, float* b) {
+  strip_reduce<T>(G, P, C, strip, sums, part, [&](long pix, int g, int c0, float* a, float* b) {
     Vec16<T> ta = as_vec<T>(*(const uint4*)(a_ + pix * lda + c0));
     Vec16<T> tb = as_vec<T>(*(const uint4*)(b_ + pix * ldb + c0));
 #pragma unroll
@@ -229,9 +237,9 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stats_kernel(const T* __rest
                                                                  long lddy, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const float* __restrict__ w,
                                                                  const float* __restrict__ b, float* __restrict__ bsums, int G,
-                                                                 long P, int C, int act, int strip) {
+                                                                 long P, int C, int act, int strip, float* part) {
   constexpr int V = Elem<T>::VEC;
-  strip_reduce<T>(G, P, C, strip, bsums, [&](long pix, int g, int c0, float* a, float* bb) {
+  strip_reduce<T>(G, P, C, strip, bsums, part, [&](long pix, int g, int c0, float* a, float* bb) {
     Vec16<T> tx = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
     Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + pix * lddy + c0));
 #pragma unroll
@@ -282,6 +290,40 @@ __global__ __launch_bounds__(256) void norm_act_bwd_dx_kernel(const T* __restric
   }
 }
 
+// out[g][c][j] = sum over the strips of group g of part[g*strips + s][c][j].  Workgroup = 32 columns x 8 strip lanes.
+__global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int strips, int C2) {
+  __shared__ float red[8][33];
+  const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int chunks = (C2 + 31) / 32;
+  const int g = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 32 + col;
+  float acc = 0.f;
+  if (c < C2) {
+    const float* p = part + (long)g * strips * C2 + c;
+    for (int s = sl; s < strips; s += 8) acc += p[(long)s * C2];
+  }
+  red[sl][col] = acc;
+  __syncthreads();
+  if (sl == 0 && c < C2) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) t += red[q][col];
+    out[(long)g * C2 + c] = t;
+  }
+}
+
+// launches the strip kernel through `launch(part)` and, in two-stage mode, the finalize kernel
+template <typename L>
+int strip_launch(float* out, float* ws, long ws_elems, int G, long strips, int C, hipStream_t st, L launch) {
+  const long need = (long)G * strips * C * 2;
+  float* part = (ws && ws_elems >= need && strips > 1) ? ws : nullptr;
+  launch(part);
+  if (part) {
+    const int chunks = (C * 2 + 31) / 32;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)(G * chunks)), dim3(256), 0, st, (const float*)part, out, G, (int)strips, C * 2);
+  }
+  return du_check_launch();
+}
+
 int grid_for(long total) { long g = (total + 255) / 256; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
 
 template <typename TI, typename TO>
@@ -299,7 +341,7 @@ int ln_fwd_dispatch(const void* x, long ldx, const float* w, const float* b, voi
 
 template <typename T>
 int ln_bwd_dispatch(const void* x, const void* dy, const float* w, const float* mean, const float* rstd, void* dx, float* dwdb,
-                    long rows, int D, hipStream_t st) {
+                    long rows, int D, float* ws, long ws_elems, hipStream_t st) {
   const int nvec = D / Elem<T>::VEC;
   const int maxv = (nvec + 63) / 64;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
@@ -309,8 +351,9 @@ int ln_bwd_dispatch(const void* x, const void* dy, const float* w, const float* 
 #undef LNB_LAUNCH
   const int STRIP = pick_strip(1, rows, D, Elem<T>::VEC);
   long strips = (rows + STRIP - 1) / STRIP;
-  hipLaunchKernelGGL(layernorm_bwd_wb_kernel<T>, dim3((unsigned)strips), block, 0, st, (const T*)x, (const T*)dy, mean, rstd, dwdb, rows, D, STRIP);
-  return du_check_launch();
+  return strip_launch(dwdb, ws, ws_elems, 1, strips, D, st, [&](float* part) {
+    hipLaunchKernelGGL(layernorm_bwd_wb_kernel<T>, dim3((unsigned)strips), block, 0, st, (const T*)x, (const T*)dy, mean, rstd, dwdb, rows, D, STRIP, part);
+  });
 }
 
 }  // namespace
@@ -328,42 +371,52 @@ extern "C" int du_layernorm_fwd(int in_dtype, int out_dtype, const void* x, int6
   return DU_ERR_BAD_ARG;
 }
 
+extern "C" int64_t du_reduce_ws_elems(int dtype, int G, int64_t P, int C) {
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (G <= 0 || P <= 0 || C <= 0 || C % v) return 0;
+  const int STRIP = pick_strip(G, P, C, v);
+  return (int64_t)G * ((P + STRIP - 1) / STRIP) * C * 2;
+}
+
 extern "C" int du_layernorm_bwd(int dtype, const void* x, const void* dy, const float* w, const float* mean, const float* rstd,
-                                void* dx, float* dwdb, int64_t rows, int D, void* stream) {
+                                void* dx, float* dwdb, int64_t rows, int D, float* ws, int64_t ws_elems, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (rows <= 0 || D <= 0 || !x || !dy || !dx || !dwdb) return DU_ERR_BAD_ARG;
   const int vi = dtype == DU_BF16 ? 8 : 4;
   if (D % vi) return DU_ERR_BAD_ARG;
-  if (dtype == DU_F32) return ln_bwd_dispatch<float>(x, dy, w, mean, rstd, dx, dwdb, rows, D, st);
-  if (dtype == DU_BF16) return ln_bwd_dispatch<bf16_t>(x, dy, w, mean, rstd, dx, dwdb, rows, D, st);
+  if (dtype == DU_F32) return ln_bwd_dispatch<float>(x, dy, w, mean, rstd, dx, dwdb, rows, D, ws, ws_elems, st);
+  if (dtype == DU_BF16) return ln_bwd_dispatch<bf16_t>(x, dy, w, mean, rstd, dx, dwdb, rows, D, ws, ws_elems, st);
   return DU_ERR_BAD_ARG;
 }
 
-extern "C" int du_chan_stats(int dtype, const void* x, int64_t ldx, float* sums, int G, int64_t P, int C, void* stream) {
+extern "C" int du_chan_stats(int dtype, const void* x, int64_t ldx, float* sums, int G, int64_t P, int C, float* ws, int64_t ws_elems,
+                             void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (G <= 0 || P <= 0 || C <= 0 || C % v || ldx % v || !x || !sums) return DU_ERR_BAD_ARG;
   const int STRIP = pick_strip(G, P, C, v);
   long strips = (P + STRIP - 1) / STRIP;
   dim3 grid((unsigned)(G * strips)), block(256);
-  if (dtype == DU_BF16) hipLaunchKernelGGL(chan_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, sums, G, P, C, STRIP);
-  else if (dtype == DU_F32) hipLaunchKernelGGL(chan_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, sums, G, P, C, STRIP);
-  else return DU_ERR_BAD_ARG;
-  return du_check_launch();
+  if (dtype != DU_BF16 && dtype != DU_F32) return DU_ERR_BAD_ARG;
+  return strip_launch(sums, ws, ws_elems, G, strips, C, st, [&](float* part) {
+    if (dtype == DU_BF16) hipLaunchKernelGGL(chan_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, sums, G, P, C, STRIP, part);
+    else hipLaunchKernelGGL(chan_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, sums, G, P, C, STRIP, part);
+  });
 }
 
 extern "C" int du_chan_dot(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, float* sums, int G, int64_t P, int C,
-                           void* stream) {
+                           float* ws, int64_t ws_elems, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (G <= 0 || P <= 0 || C <= 0 || C % v || lda % v || ldb % v || !a || !b || !sums) return DU_ERR_BAD_ARG;
   const int STRIP = pick_strip(G, P, C, v);
   long strips = (P + STRIP - 1) / STRIP;
   dim3 grid((unsigned)(G * strips)), block(256);
-  if (dtype == DU_BF16) hipLaunchKernelGGL(chan_dot_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, sums, G, P, C, STRIP);
-  else if (dtype == DU_F32) hipLaunchKernelGGL(chan_dot_kernel<float>, grid, block, 0, st, (const float*)a, lda, (const float*)b, ldb, sums, G, P, C, STRIP);
-  else return DU_ERR_BAD_ARG;
-  return du_check_launch();
+  if (dtype != DU_BF16 && dtype != DU_F32) return DU_ERR_BAD_ARG;
+  return strip_launch(sums, ws, ws_elems, G, strips, C, st, [&](float* part) {
+    if (dtype == DU_BF16) hipLaunchKernelGGL(chan_dot_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, sums, G, P, C, STRIP, part);
+    else hipLaunchKernelGGL(chan_dot_kernel<float>, grid, block, 0, st, (const float*)a, lda, (const float*)b, ldb, sums, G, P, C, STRIP, part);
+  });
 }
 
 extern "C" int du_norm_act_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* mean, const float* rstd,
@@ -381,17 +434,18 @@ extern "C" int du_norm_act_fwd(int dtype, const void* x, int64_t ldx, void* y, i
 
 extern "C" int du_norm_act_bwd_stats(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* mean,
                                      const float* rstd, const float* w, const float* b, float* bsums, int G, int64_t P, int C,
-                                     int act, void* stream) {
+                                     int act, float* ws, int64_t ws_elems, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (G <= 0 || P <= 0 || C % v || ldx % v || lddy % v) return DU_ERR_BAD_ARG;
   const int STRIP = pick_strip(G, P, C, v);
   long strips = (P + STRIP - 1) / STRIP;
   dim3 grid((unsigned)(G * strips)), block(256);
-  if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_bwd_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP);
-  else if (dtype == DU_F32) hipLaunchKernelGGL(norm_act_bwd_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP);
-  else return DU_ERR_BAD_ARG;
-  return du_check_launch();
+  if (dtype != DU_BF16 && dtype != DU_F32) return DU_ERR_BAD_ARG;
+  return strip_launch(bsums, ws, ws_elems, G, strips, C, st, [&](float* part) {
+    if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_bwd_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, part);
+    else hipLaunchKernelGGL(norm_act_bwd_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, part);
+  });
 }
 
 extern "C" int du_norm_act_bwd_dx(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx,

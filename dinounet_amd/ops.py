@@ -208,11 +208,19 @@ def mm_wgrad(dy, x):
     return out
 
 
+def _reduce_ws(dt, G, P, Cc, device):
+    """scratch for the two-stage column reductions (du_reduce_ws_elems); a plain torch.empty: the caching allocator makes it free
+    and it is captured like any other temporary under hipGraph."""
+    n = int(_lib.lib().du_reduce_ws_elems(_code(dt), G, P, Cc))
+    return torch.empty(max(n, 1), dtype=torch.float32, device=device), n
+
+
 def colsum(x2d):
     """sum over rows of a (rows, C) matrix -> fp32 (C,)   (bias gradients)."""
     rows, Cc, ld = _rows2d(x2d)
     sums = torch.zeros((1, Cc, 2), dtype=torch.float32, device=x2d.device)
-    _lib.check(_lib.lib().du_chan_stats(_code(x2d.dtype), _p(x2d), ld, _p(sums), 1, rows, Cc, _st()), "du_chan_stats")
+    ws, n = _reduce_ws(x2d.dtype, 1, rows, Cc, x2d.device)
+    _lib.check(_lib.lib().du_chan_stats(_code(x2d.dtype), _p(x2d), ld, _p(sums), 1, rows, Cc, _p(ws), n, _st()), "du_chan_stats")
     return sums[0, :, 0].contiguous()
 
 
@@ -434,7 +442,8 @@ def chan_stats(x, G):
     B, H, W, Cc, ld = _nhwc(x)
     P = (B // G) * H * W
     sums = torch.zeros((G, Cc, 2), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().du_chan_stats(_code(x.dtype), _p(x), ld, _p(sums), G, P, Cc, _st()), "du_chan_stats")
+    ws, n = _reduce_ws(x.dtype, G, P, Cc, x.device)
+    _lib.check(_lib.lib().du_chan_stats(_code(x.dtype), _p(x), ld, _p(sums), G, P, Cc, _p(ws), n, _st()), "du_chan_stats")
     return sums, P
 
 
@@ -492,8 +501,9 @@ class _NormAct(torch.autograd.Function):
         dy = dy.contiguous()
         L = _lib.lib()
         bs = torch.zeros((G, Cc, 2), dtype=torch.float32, device=x.device)
+        ws, n = _reduce_ws(x.dtype, G, P, Cc, x.device)
         _lib.check(L.du_norm_act_bwd_stats(_code(x.dtype), _p(x), ld, _p(dy), Cc, _p(mean), _p(rstd), _p(wf), _p(bf), _p(bs), G, P,
-                                           Cc, act, _st()), "du_norm_act_bwd_stats")
+                                           Cc, act, _p(ws), n, _st()), "du_norm_act_bwd_stats")
         dw = bs[..., 1].sum(0)
         db = bs[..., 0].sum(0)
         bsr = bs
@@ -540,8 +550,9 @@ class _LayerNorm(torch.autograd.Function):
         dyc = dy.contiguous()
         dx = torch.empty_like(xc)
         dwdb = torch.zeros((D, 2), dtype=torch.float32, device=xc.device)
+        ws, n = _reduce_ws(xc.dtype, 1, xc.numel() // D, D, xc.device)
         _lib.check(_lib.lib().du_layernorm_bwd(_code(xc.dtype), _p(xc), _p(dyc), _p(wf), _p(mean), _p(rstd), _p(dx), _p(dwdb),
-                                               xc.numel() // D, D, _st()), "du_layernorm_bwd")
+                                               xc.numel() // D, D, _p(ws), n, _st()), "du_layernorm_bwd")
         return dx, dwdb[:, 0], dwdb[:, 1], None
 
 
@@ -670,13 +681,15 @@ class _DWConvSegs(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw = torch.zeros((Cc, 9), dtype=torch.float32, device=x.device)
         db = torch.zeros(Cc, dtype=torch.float32, device=x.device) if has_bias else None
-        for (off, B, h, ww, ld, bs) in segs:
+        for si, (off, B, h, ww, ld, bs) in enumerate(segs):
             _lib.check(L.du_dwconv3x3_bwd_data(code, C.c_void_p(dz.data_ptr() + off * es), ld, bs, _p(wf),
                                                C.c_void_p(dx.data_ptr() + off * es), ld, bs, B, h, ww, Cc, _st()),
                        "du_dwconv3x3_bwd_data")
+            n = int(L.du_dwconv_wgrad_ws_elems(code, B, h, ww, Cc))
+            ws = torch.empty(max(n, 1), dtype=torch.float32, device=x.device)
             _lib.check(L.du_dwconv3x3_bwd_weight(code, C.c_void_p(x.data_ptr() + off * es), ld, bs,
                                                  C.c_void_p(dz.data_ptr() + off * es), ld, bs, _p(dw), _p(db), B, h, ww, Cc,
-                                                 _st()), "du_dwconv3x3_bwd_weight")
+                                                 _p(ws), n, 1 if si > 0 else 0, _st()), "du_dwconv3x3_bwd_weight")
         return dx, dw.view(Cc, 1, 3, 3), db, None, None
 
 
@@ -779,7 +792,8 @@ class _SqueezeExcite(torch.autograd.Function):
         L = _lib.lib()
         dy = dy.contiguous()
         dsum = torch.zeros((B, Cc, 2), dtype=torch.float32, device=x.device)
-        _lib.check(L.du_chan_dot(_code(x.dtype), _p(dy), Cc, _p(x), ld, _p(dsum), B, P, Cc, _st()), "du_chan_dot")
+        ws, n = _reduce_ws(x.dtype, B, P, Cc, x.device)
+        _lib.check(L.du_chan_dot(_code(x.dtype), _p(dy), Cc, _p(x), ld, _p(dsum), B, P, Cc, _p(ws), n, _st()), "du_chan_dot")
         dpool = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
         dw1 = torch.empty((R, Cc), dtype=torch.float32, device=x.device)
         db1 = torch.empty(R, dtype=torch.float32, device=x.device)

@@ -118,23 +118,29 @@ int du_softmax_rows_f32(float* x, int64_t rows, int cols, int64_t ld, void* stre
 /* ---- LayerNorm -------------------------------------------------------------------------------- */
 int du_layernorm_fwd(int in_dtype, int out_dtype, const void* x, int64_t ldx, const float* w, const float* b, void* y,
                      int64_t ldy, float* mean_out, float* rstd_out, int64_t rows, int D, float eps, void* stream);
-/* dx (same dtype as x); dwdb is a zero-filled fp32 (D, 2) buffer receiving (dw[c], db[c]) interleaved (atomics). */
+/* Column reductions (statistics, bias / norm-parameter gradients) run in two stages when the caller lends a scratch buffer
+   `ws` of at least du_reduce_ws_elems(...) floats: every workgroup writes its strip's partial sums, a second kernel adds them
+   up and OVERWRITES the result buffer.  With ws == NULL the partials are accumulated with fp32 atomics into a result buffer the
+   caller must have zero-filled (same-cache-line atomics serialise: ~0.1 us each, measured, so this is the slow fallback). */
+int64_t du_reduce_ws_elems(int dtype, int G, int64_t pix_per_group, int C);
+/* dx (same dtype as x); dwdb fp32 (D, 2) receives (dw[c], db[c]) interleaved; scratch: du_reduce_ws_elems(dtype, 1, rows, D). */
 int du_layernorm_bwd(int dtype, const void* x, const void* dy, const float* w, const float* mean, const float* rstd,
-                     void* dx, float* dwdb, int64_t rows, int D, void* stream);
+                     void* dx, float* dwdb, int64_t rows, int D, float* ws, int64_t ws_elems, void* stream);
 
 /* ---- channel-statistics norms (InstanceNorm2d / BatchNorm2d over NHWC) ---------------------------- */
 /* sums[g][c][0..1] += (sum x, sum x^2) over the pixels of group g (G groups of `pix_per_group` pixels). */
-int du_chan_stats(int dtype, const void* x, int64_t ldx, float* sums, int G, int64_t pix_per_group, int C, void* stream);
+int du_chan_stats(int dtype, const void* x, int64_t ldx, float* sums, int G, int64_t pix_per_group, int C, float* ws,
+                  int64_t ws_elems, void* stream);
 /* sums[g][c][0..1] += (sum a*b, sum a) over the pixels of group g (squeeze-excitation gate gradient, a = dy, b = x). */
 int du_chan_dot(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, float* sums, int G, int64_t pix_per_group, int C,
-                void* stream);
+                float* ws, int64_t ws_elems, void* stream);
 /* y = act((x - mean[g,c]) * rstd[g,c] * w[c] + b[c]); mean/rstd: (G, C) fp32. */
 int du_norm_act_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* mean, const float* rstd,
                     const float* w, const float* b, int G, int64_t pix_per_group, int C, int act, void* stream);
 /* backward pass 1: through the activation, accumulate per-(g,c) sum(dz) and sum(dz*xhat) into bsums (G,C,2). */
 int du_norm_act_bwd_stats(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* mean,
                           const float* rstd, const float* w, const float* b, float* bsums, int G, int64_t pix_per_group,
-                          int C, int act, void* stream);
+                          int C, int act, float* ws, int64_t ws_elems, void* stream);
 /* backward pass 2: dx = w*rstd*(dz - s1/n - xhat*s2/n) with (s1,s2) from bsums (G,C,2) and n = `count` (pixels the
    statistics were taken over: pix_per_group for IN, all pixels x world for BN).  use_batch_stats=0 => dx = dz*w*rstd */
 int du_norm_act_bwd_dx(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx,
@@ -169,9 +175,13 @@ int du_dwconv3x3_fwd(int dtype, const void* x, int64_t ldx, int64_t xbs, const f
                      int64_t ldy, int64_t ybs, void* z, int B, int H, int W, int C, int act, void* stream);
 int du_dwconv3x3_bwd_data(int dtype, const void* dy, int64_t lddy, int64_t dybs, const float* w, void* dx, int64_t lddx,
                           int64_t dxbs, int B, int H, int W, int C, void* stream);
-/* dw (C,9) and db (C, nullable) accumulate with atomics into zero-filled fp32 buffers */
+/* dw (C,9) and db (C, nullable).  With scratch `ws` (>= du_dwconv_wgrad_ws_elems floats) the result is written (accumulate = 0)
+   or added to dw/db (accumulate = 1: further image segments of the same kernel); with ws == NULL partials are added with atomics
+   into buffers the caller zero-filled. */
+int64_t du_dwconv_wgrad_ws_elems(int dtype, int B, int H, int W, int C);
 int du_dwconv3x3_bwd_weight(int dtype, const void* x, int64_t ldx, int64_t xbs, const void* dy, int64_t lddy, int64_t dybs,
-                            float* dw, float* db, int B, int H, int W, int C, void* stream);
+                            float* dw, float* db, int B, int H, int W, int C, float* ws, int64_t ws_elems, int accumulate,
+                            void* stream);
 /* MaxPool2d(3, 2, 1) on contiguous NHWC; idx (nullable, same shape as y, uint8) records the winning tap */
 int du_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
 int du_maxpool3x3s2_bwd(int dtype, const uint8_t* idx, const void* dy, void* dx, int B, int H, int W, int C, void* stream);
