@@ -163,13 +163,23 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
 // segments of the same depthwise kernel, dinov3_adapter.py:99-109)
 __global__ __launch_bounds__(256) void dwconv_wgrad_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                     float* __restrict__ db, int blocks, int C, int accum) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= C * 10) return;
+  // workgroup = 32 columns (of the C*10 partial columns) x 8 block lanes
+  __shared__ float red[8][33];
+  const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + col;
   float acc = 0.f;
-  for (int b = 0; b < blocks; b++) acc += part[(long)b * C * 10 + i];
-  const int c = i / 10, k = i - c * 10;
-  if (k < 9) dw[c * 9 + k] = accum ? dw[c * 9 + k] + acc : acc;
-  else if (db) db[c] = accum ? db[c] + acc : acc;
+  if (i < C * 10)
+    for (int b = sl; b < blocks; b += 8) acc += part[(long)b * C * 10 + i];
+  red[sl][col] = acc;
+  __syncthreads();
+  if (sl == 0 && i < C * 10) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) t += red[q][col];
+    const int c = i / 10, k = i - c * 10;
+    if (k < 9) dw[c * 9 + k] = accum ? dw[c * 9 + k] + t : t;
+    else if (db) db[c] = accum ? db[c] + t : t;
+  }
 }
 
 // ---------------- max-pool 3x3 stride 2 pad 1 (dinov3_adapter.py:250); idx = winning tap (first max in scan order) -----------
@@ -577,7 +587,7 @@ extern "C" int du_dwconv3x3_bwd_weight(int dtype, const void* x, int64_t ldx, in
              hipLaunchKernelGGL(dwconv_bwd_weight_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, xbs, (const bf16_t*)dy, lddy, dybs, dw, db, B, H, W, C, strip, part),
              hipLaunchKernelGGL(dwconv_bwd_weight_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, ldx, xbs, (const float*)dy, lddy, dybs, dw, db, B, H, W, C, strip, part));
   if (part)
-    hipLaunchKernelGGL(dwconv_wgrad_finalize_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, st, (const float*)part, dw, db, (int)blocks, C, accumulate);
+    hipLaunchKernelGGL(dwconv_wgrad_finalize_kernel, dim3((C * 10 + 31) / 32), dim3(256), 0, st, (const float*)part, dw, db, (int)blocks, C, accumulate);
   return du_check_launch();
 }
 

@@ -347,6 +347,8 @@ int launch_modes(const du_gemm_args& a, hipStream_t st) {
 
 }  // namespace
 
+int du_gemm_nt_glds(const du_gemm_args& a, hipStream_t st);   // gemm_glds.hip
+
 // returns DU_ERR_UNSUPPORTED when the generic kernel must be used instead
 int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
   if (a.dtype != DU_BF16) return DU_ERR_UNSUPPORTED;
@@ -356,6 +358,10 @@ int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
   if (a.residual && (a.ldr % 4 || (((uintptr_t)a.residual) & 15))) return DU_ERR_UNSUPPORTED;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && a.ps_C % 4) return DU_ERR_UNSUPPORTED;
   if (a.c_batch_stride % 4) return DU_ERR_UNSUPPORTED;
+  {
+    int rc = du_gemm_nt_glds(a, st);      // direct-to-LDS kernel for the large contraction-contiguous products
+    if (rc != DU_ERR_UNSUPPORTED) return rc;
+  }
   if (a.out_dtype == DU_BF16) return launch_modes<bf16_t>(a, st);
   return launch_modes<float>(a, st);
 }

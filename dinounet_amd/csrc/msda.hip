@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ val
 // grad_attn / grad_loc are reduced across the LPP lanes with xor shuffles; grad_value uses fp32 atomics
 // (contiguous per (pixel, head): D floats = one or two cache lines).
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int CPT, int MAXLP>
+template <typename T, int CPT, int MAXLP, bool GV>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ value, const int64_t* __restrict__ shapes,
                                                        const int64_t* __restrict__ lsi, const float* __restrict__ loc,
                                                        const float* __restrict__ attn, const T* __restrict__ gout,
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ val
                   val[j] += c.wt[k] * v[j];
                   ghw[j] += dh[k] * v[j];
                   gww[j] += dw[k] * v[j];
-                  if (live) atomic_add_f32(gvalue + base + (long)c.off[k] * qstride + j, c.wt[k] * tg[j] * a);
+                  if constexpr (GV) atomic_add_f32(gvalue + base + (long)c.off[k] * qstride + j, c.wt[k] * tg[j] * a);
                 }
               }
             }
@@ -217,14 +217,19 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(const T* __restrict_
                                                             const float* __restrict__ attn, const T* __restrict__ gout,
                                                             float* __restrict__ gvalue, float* __restrict__ gloc,
                                                             float* __restrict__ gattn, int N, int S, int M, int D, int L, int Lq,
-                                                            int P, int LPP, int q_per_chunk) {
-  extern __shared__ __attribute__((aligned(16))) float gacc[];   // [S][D]
+                                                            int P, int LPP, int q_per_chunk, float* __restrict__ part, int PLD) {
+  // gacc[S][PLD]: one pixel row per value pixel, padded (PLD = D + 4 when it fits) so that the rows of different pixels start
+  // on different banks; within a row channel c sits at position (c % CPT) * (D / CPT) + c / CPT, so the lanes of a query group
+  // (lane `sub` carries channels CPT*sub .. CPT*sub + CPT-1) hit CONSECUTIVE banks in each of the CPT atomic instructions
+  // instead of every CPT-th one (4-way+ bank conflicts on ds_add_f32 were 80 % of this kernel's time).
+  extern __shared__ __attribute__((aligned(16))) float gacc[];
   const int tid = threadIdx.x;
   const int b = blockIdx.y / M, m = blockIdx.y % M;
   const int q0 = blockIdx.x * q_per_chunk;
   const int q1 = min(Lq, q0 + q_per_chunk);
-  for (int i = tid; i < S * D; i += 1024) gacc[i] = 0.f;
+  for (int i = tid; i < S * PLD; i += 1024) gacc[i] = 0.f;
   __syncthreads();
+  const int DQ = D / CPT;                    // channels-per-position stride of the permuted row layout
   const int gpw = 1024 / LPP;
   const int sub = tid % LPP;
   const int chunks = (D + CPT - 1) / CPT;
@@ -264,13 +269,13 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(const T* __restrict_
               if (c.ok[k]) {
                 float v[CPT];
                 load_chan<T, CPT>(value + base + (long)c.off[k] * qstride, v);
-                float* ldst = gacc + (ls + c.off[k]) * D + c0;
+                float* ldst = gacc + (ls + c.off[k]) * PLD + ch;
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {
                   val[j] += c.wt[k] * v[j];
                   ghw[j] += dh[k] * v[j];
                   gww[j] += dw[k] * v[j];
-                  atomicAdd(ldst + j, c.wt[k] * tg[j] * a);
+                  atomicAdd(ldst + j * DQ, c.wt[k] * tg[j] * a);
                 }
               }
             }
@@ -300,11 +305,137 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(const T* __restrict_
     }
   }
   __syncthreads();
-  for (int i = tid; i < S * D; i += 1024) {
-    const float v = gacc[i];
-    if (v != 0.f) {
+  if (part) {
+    // two-stage: this query chunk's plane goes to part[chunk][b][s][m][:] with plain stores; msda_gv_finalize_kernel adds the chunks
+    float* dst = part + (long)blockIdx.x * N * S * qstride;
+    for (int i = tid; i < S * D; i += 1024) {
       const int sidx = i / D, c = i - sidx * D;
-      atomic_add_f32(gvalue + ((long)b * S + sidx) * qstride + (long)m * D + c, v);
+      dst[((long)b * S + sidx) * qstride + (long)m * D + c] = gacc[sidx * PLD + (c % CPT) * DQ + c / CPT];
+    }
+    return;
+  }
+  for (int i = tid; i < S * D; i += 1024) {
+    const int sidx = i / D, c = i - sidx * D;
+    const float v = gacc[sidx * PLD + (c % CPT) * DQ + c / CPT];
+    if (v != 0.f) atomic_add_f32(gvalue + ((long)b * S + sidx) * qstride + (long)m * D + c, v);
+  }
+}
+
+// grad_value = sum over the query chunks of the partial planes
+__global__ __launch_bounds__(256) void msda_gv_finalize_kernel(const float* __restrict__ part, float* __restrict__ gvalue, int nchunk,
+                                                               long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 a = ((const float4*)part)[i];
+    for (int c = 1; c < nchunk; c++) {
+      float4 t = ((const float4*)part)[i + (long)c * n4];
+      a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+    ((float4*)gvalue)[i] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// grad_value as a matrix product on the MFMA pipe (bf16 throughput mode, single level).
+//
+//   grad_value[pix][c] = sum over (query q, point p) of  W[pix][(q,p)] * grad_out[q][c]
+//   W[pix][(q,p)] = attn(q,p) * (bilinear weight of sample (q,p) at corner pixel pix), 0 elsewhere (<= 4 non-zeros per column)
+//
+// The scatter of the reference (atomicAdd per corner and channel, ms_deform_im2col_cuda.cuh:130-157) becomes: write the <= 4
+// non-zeros of each (q,p) column into an LDS image of W (no two threads ever write the same element: distinct columns, or
+// distinct corner pixels of one column), multiply with v_mfma_f32_32x32x16_bf16, accumulate the plane tile in registers.  Measured
+// motive: ds_add_f32 runs lane-serially on gfx950 (the LDS-atomic kernel spent 1.75 ms per call, independent of bank layout).
+//
+// Workgroup = 1024 threads = 16 waves; it owns PT = 512 consecutive value pixels of one (batch, head) plane: wave w accumulates
+// pixels [32w, 32w+32) x 32 channels (one f32x16).  K step = 128 columns = 32 queries x 4 points:
+//   zero own previous non-zero -> barrier -> write new non-zeros + G^T tile -> barrier -> 8 MFMAs -> barrier.
+// ------------------------------------------------------------------------------------------------------
+constexpr int GV_PT = 512;        // plane pixels per workgroup
+constexpr int GV_KQ = 32;         // queries per K step
+constexpr int GV_WLD = 128 + 8;   // W row pitch (bf16): 272 B, conflict-free ds_read_b128 fragments
+constexpr int GV_GLD = 128 + 8;
+
+__global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __restrict__ gout, const int64_t* __restrict__ shapes,
+                                                            const float* __restrict__ loc, const float* __restrict__ attn,
+                                                            float* __restrict__ gvalue, int N, int S, int M, int D, int Lq,
+                                                            int q_per_chunk, int tiles, long chunk_stride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Wl = (bf16_t*)smem_raw;                       // [GV_PT][GV_WLD]
+  bf16_t* Gt = Wl + GV_PT * GV_WLD;                     // [32 channels][GV_GLD]   (G^T: k contiguous)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Hs = (int)shapes[0], Ws = (int)shapes[1];   // single level
+  const int bm = blockIdx.y / tiles, ptile = blockIdx.y % tiles;
+  const int b = bm / M, m = bm % M;
+  const int pix0 = ptile * GV_PT;
+  const int q0 = blockIdx.x * q_per_chunk;
+  const int q1 = min(Lq, q0 + q_per_chunk);
+  for (int i = tid; i < GV_PT * GV_WLD / 8; i += 1024) ((uint4*)Wl)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < 32 * GV_GLD / 8; i += 1024) ((uint4*)Gt)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+  // scatter role (threads 0..511): column col = (query ql, point p), one bilinear corner each
+  const int col = tid >> 2, corner = tid & 3;
+  const int ql_s = col >> 2, p_s = col & 3;
+  // G role (all threads): query ql_g, channel c_g
+  const int ql_g = tid >> 5, c_g = tid & 31;
+  int my_off = -1;
+  for (int qs = q0; qs < q1; qs += GV_KQ) {
+    // ---- loads for this step (issued before the barrier so they overlap the previous step's MFMAs of other waves) ----
+    float wv = 0.f; int woff = -1;
+    if (tid < 512) {
+      const int q = qs + ql_s;
+      if (q < q1) {
+        const long pr = ((long)b * Lq + q) * M + m;
+        const float lx = loc[(pr * 4 + p_s) * 2], ly = loc[(pr * 4 + p_s) * 2 + 1];
+        const float a = attn[pr * 4 + p_s];
+        const float h = ly * Hs - 0.5f, w = lx * Ws - 0.5f;
+        if (h > -1.f && w > -1.f && h < (float)Hs && w < (float)Ws) {
+          const int h0 = (int)floorf(h), w0 = (int)floorf(w);
+          const float lh = h - h0, lw = w - w0;
+          const int hy = h0 + (corner >> 1), wx = w0 + (corner & 1);
+          if (hy >= 0 && hy < Hs && wx >= 0 && wx < Ws) {
+            const int pl = hy * Ws + wx - pix0;
+            if (pl >= 0 && pl < GV_PT) {
+              wv = ((corner >> 1) ? lh : 1.f - lh) * ((corner & 1) ? lw : 1.f - lw) * a;
+              woff = pl * GV_WLD + col;
+            }
+          }
+        }
+      }
+    }
+    bf16_t gval = (bf16_t)0.f;
+    {
+      const int q = qs + ql_g;
+      if (q < q1 && c_g < D) gval = gout[(((long)b * Lq + q) * M + m) * D + c_g];
+    }
+    // ---- clear this thread's non-zero of the previous step, then install the new column entries ----
+    if (my_off >= 0) Wl[my_off] = (bf16_t)0.f;
+    __syncthreads();
+    if (woff >= 0) Wl[woff] = (bf16_t)wv;
+    my_off = woff;
+    {
+      bf16x4 g4; g4[0] = gval; g4[1] = gval; g4[2] = gval; g4[3] = gval;
+      *(bf16x4*)(Gt + c_g * GV_GLD + ql_g * 4) = g4;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+      bf16x8 fa = *(const bf16x8*)(Wl + (wave * 32 + (lane & 31)) * GV_WLD + kk * 16 + (lane >> 5) * 8);
+      bf16x8 fb = *(const bf16x8*)(Gt + (lane & 31) * GV_GLD + kk * 16 + (lane >> 5) * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // lane: channel (lane & 31), pixels (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32-pixel block
+  const int c = lane & 31;
+  if (c < D) {
+    float* dst = gvalue + (long)blockIdx.x * chunk_stride;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int pix = pix0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (pix < S) dst[((long)b * S + pix) * ((long)M * D) + (long)m * D + c] = acc[r];
     }
   }
 }
@@ -328,9 +459,22 @@ int fwd_dispatch(const void* value, const int64_t* shapes, const int64_t* lsi, c
   return du_check_launch();
 }
 
+// query chunking of the LDS-resident backward: enough workgroups to fill 256 CUs; each chunk costs one S*D flush
+static void lds_chunking(int N, int M, int Lq, int LPP, int* nchunk_out, int* qpc_out) {
+  int nchunk = (int)((256 + (long)N * M - 1) / ((long)N * M));   // one 1024-thread workgroup (~130-150 KB LDS) per CU
+  if (nchunk < 1) nchunk = 1;
+  if (nchunk > 16) nchunk = 16;
+  int qpc = (Lq + nchunk - 1) / nchunk;
+  const int gq = 1024 / LPP;
+  qpc = ((qpc + gq - 1) / gq) * gq;
+  *nchunk_out = (Lq + qpc - 1) / qpc;
+  *qpc_out = qpc;
+}
+
 template <typename T, int CPT>
 int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn, const void* gout,
-               float* gv, float* gl, float* ga, int N, int S, int M, int D, int L, int Lq, int P, hipStream_t st) {
+               float* gv, float* gl, float* ga, int N, int S, int M, int D, int L, int Lq, int P, float* ws, long ws_elems,
+               hipStream_t st) {
   const int chunks = (D + CPT - 1) / CPT;
   int LPP = next_pow2(chunks);
   if (LPP > 64) LPP = 64;
@@ -340,27 +484,68 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
   if (blocks > 65535 * 8) blocks = 65535 * 8;
   const int LP = L * P;
   const size_t plane = (size_t)S * D * sizeof(float);
+  static const bool no_mfma = getenv("DU_MSDA_NO_MFMA") != nullptr;  // debugging / A-B aid
+  if constexpr (sizeof(T) == 2) {
+    if (!no_mfma && L == 1 && P == 4 && D <= 32 && LP <= 4) {
+      // (1) gather-only pass: grad_sampling_loc / grad_attn_weight (no atomics)
+      hipLaunchKernelGGL((msda_bwd_kernel<T, CPT, 4, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value, shapes, lsi, loc, attn,
+                         (const T*)gout, gv, gl, ga, N, S, M, D, L, Lq, P, LPP, npairs);
+      // (2) grad_value on the MFMA pipe
+      {
+        const int tiles = (S + GV_PT - 1) / GV_PT;
+        int nchunk = (int)((256 + (long)N * M * tiles - 1) / ((long)N * M * tiles));
+        if (nchunk < 1) nchunk = 1;
+        if (nchunk > 16) nchunk = 16;
+        int qpc = (Lq + nchunk - 1) / nchunk;
+        qpc = ((qpc + GV_KQ - 1) / GV_KQ) * GV_KQ;
+        nchunk = (Lq + qpc - 1) / qpc;
+        const long plane_all = (long)N * S * M * D;
+        float* dstp = gv; long cstride = 0;
+        if (nchunk > 1) {
+          if (ws && ws_elems >= (long)nchunk * plane_all && plane_all % 4 == 0) { dstp = ws; cstride = plane_all; }
+          else { nchunk = 1; qpc = ((Lq + GV_KQ - 1) / GV_KQ) * GV_KQ; }
+        }
+        const int lds_bytes = (GV_PT * GV_WLD + 32 * GV_GLD) * 2;
+        static bool attr_set = false;
+        if (!attr_set) {
+          if (hipFuncSetAttribute((const void*)msda_gv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return DU_ERR_LAUNCH;
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(msda_gv_mfma_kernel, dim3(nchunk, N * M * tiles), dim3(1024), lds_bytes, st, (const bf16_t*)gout, shapes, loc, attn,
+                           dstp, N, S, M, D, Lq, qpc, tiles, cstride);
+        if (nchunk > 1) {
+          const long n4 = plane_all / 4;
+          long g = (n4 + 255) / 256; if (g > 4096) g = 4096;
+          hipLaunchKernelGGL(msda_gv_finalize_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)ws, gv, nchunk, n4);
+        }
+        return du_check_launch();
+      }
+    }
+  }
   static const bool no_lds = getenv("DU_MSDA_NO_LDS") != nullptr;   // debugging aid: force the global-atomics kernel
   if (!no_lds && plane <= 144 * 1024 && LP <= 8 && LPP <= 64) {
-    // enough workgroups to fill 256 CUs; each chunk costs one S*D flush
-    int nchunk = (int)((512 + (long)N * M - 1) / ((long)N * M));
-    if (nchunk < 1) nchunk = 1;
-    if (nchunk > 16) nchunk = 16;
-    int qpc = (Lq + nchunk - 1) / nchunk;
-    const int gq = 1024 / LPP;
-    qpc = ((qpc + gq - 1) / gq) * gq;
-    nchunk = (Lq + qpc - 1) / qpc;
+    int nchunk, qpc;
+    lds_chunking(N, M, Lq, LPP, &nchunk, &qpc);
+    const long plane_all = (long)N * S * M * D;
+    const int PLD = ((size_t)S * (D + 4) * sizeof(float) <= 156 * 1024 && D % CPT == 0) ? D + 4 : D;
+    const size_t lds_bytes = (size_t)S * PLD * sizeof(float);
+    float* part = (ws && ws_elems >= (long)nchunk * plane_all && plane_all % 4 == 0 && nchunk > 1) ? ws : nullptr;
     dim3 grid(nchunk, N * M);
 #define MSDA_BWD_LDS(MAXLP) do { \
       auto kfn = msda_bwd_lds_kernel<T, CPT, MAXLP>; \
-      if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plane) != hipSuccess) return DU_ERR_LAUNCH; \
-      hipLaunchKernelGGL(kfn, grid, dim3(1024), plane, st, (const T*)value, shapes, lsi, loc, attn, (const T*)gout, gv, gl, ga, N, S, M, D, L, Lq, P, LPP, qpc); \
+      if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return DU_ERR_LAUNCH; \
+      hipLaunchKernelGGL(kfn, grid, dim3(1024), lds_bytes, st, (const T*)value, shapes, lsi, loc, attn, (const T*)gout, gv, gl, ga, N, S, M, D, L, Lq, P, LPP, qpc, part, PLD); \
     } while (0)
     if (LP <= 4) MSDA_BWD_LDS(4); else MSDA_BWD_LDS(8);
 #undef MSDA_BWD_LDS
+    if (part) {
+      const long n4 = plane_all / 4;
+      long g = (n4 + 255) / 256; if (g > 4096) g = 4096;
+      hipLaunchKernelGGL(msda_gv_finalize_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)part, gv, nchunk, n4);
+    }
     return du_check_launch();
   }
-#define MSDA_BWD(MAXLP) hipLaunchKernelGGL((msda_bwd_kernel<T, CPT, MAXLP>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value, shapes, lsi, loc, attn, (const T*)gout, gv, gl, ga, N, S, M, D, L, Lq, P, LPP, npairs)
+#define MSDA_BWD(MAXLP) hipLaunchKernelGGL((msda_bwd_kernel<T, CPT, MAXLP, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value, shapes, lsi, loc, attn, (const T*)gout, gv, gl, ga, N, S, M, D, L, Lq, P, LPP, npairs)
   if (LP <= 4) MSDA_BWD(4); else if (LP <= 8) MSDA_BWD(8); else if (LP <= 16) MSDA_BWD(16); else return DU_ERR_UNSUPPORTED;
 #undef MSDA_BWD
   return du_check_launch();
@@ -378,20 +563,36 @@ extern "C" int du_msda_forward(int dtype, const void* value, const int64_t* shap
   return DU_ERR_BAD_ARG;
 }
 
+extern "C" int64_t du_msda_bwd_ws_elems(int N, int S, int M, int D, int L, int Lq, int P) {
+  if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return 0;
+  const int cpt = D % 4 == 0 ? 4 : 1;
+  int LPP = next_pow2((D + cpt - 1) / cpt);
+  if (LPP > 64) LPP = 64;
+  if ((size_t)S * D * sizeof(float) > 144 * 1024 || L * P > 8) return 0;
+  int nchunk, qpc;
+  lds_chunking(N, M, Lq, LPP, &nchunk, &qpc);
+  // MFMA grad_value path (bf16, single level, 4 points): query chunks so that ~256 workgroups exist
+  const int tiles = (S + GV_PT - 1) / GV_PT;
+  int nc2 = (int)((256 + (long)N * M * tiles - 1) / ((long)N * M * tiles));
+  if (nc2 > 16) nc2 = 16;
+  if (nc2 > nchunk) nchunk = nc2;
+  return nchunk > 1 ? (int64_t)nchunk * N * S * M * D : 0;
+}
+
 extern "C" int du_msda_backward(int dtype, const void* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
                                 const float* attn, const void* gout, float* gv, float* gl, float* ga, int N, int S, int M, int D,
-                                int L, int Lq, int P, void* stream) {
+                                int L, int Lq, int P, float* ws, int64_t ws_elems, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!value || !shapes || !lsi || !loc || !attn || !gout || !gv || !gl || !ga || N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 ||
       Lq <= 0 || P <= 0)
     return DU_ERR_BAD_ARG;
   if (dtype == DU_F32) {
-    if (D % 4 == 0) return bwd_launch<float, 4>(value, shapes, lsi, loc, attn, gout, gv, gl, ga, N, S, M, D, L, Lq, P, st);
-    return bwd_launch<float, 1>(value, shapes, lsi, loc, attn, gout, gv, gl, ga, N, S, M, D, L, Lq, P, st);
+    if (D % 4 == 0) return bwd_launch<float, 4>(value, shapes, lsi, loc, attn, gout, gv, gl, ga, N, S, M, D, L, Lq, P, ws, ws_elems, st);
+    return bwd_launch<float, 1>(value, shapes, lsi, loc, attn, gout, gv, gl, ga, N, S, M, D, L, Lq, P, ws, ws_elems, st);
   }
   if (dtype == DU_BF16) {
-    if (D % 4 == 0) return bwd_launch<bf16_t, 4>(value, shapes, lsi, loc, attn, gout, gv, gl, ga, N, S, M, D, L, Lq, P, st);
-    return bwd_launch<bf16_t, 1>(value, shapes, lsi, loc, attn, gout, gv, gl, ga, N, S, M, D, L, Lq, P, st);
+    if (D % 4 == 0) return bwd_launch<bf16_t, 4>(value, shapes, lsi, loc, attn, gout, gv, gl, ga, N, S, M, D, L, Lq, P, ws, ws_elems, st);
+    return bwd_launch<bf16_t, 1>(value, shapes, lsi, loc, attn, gout, gv, gl, ga, N, S, M, D, L, Lq, P, ws, ws_elems, st);
   }
   return DU_ERR_BAD_ARG;
 }

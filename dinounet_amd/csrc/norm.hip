@@ -290,23 +290,29 @@ __global__ __launch_bounds__(256) void norm_act_bwd_dx_kernel(const T* __restric
   }
 }
 
-// out[g][c][j] = sum over the strips of group g of part[g*strips + s][c][j].  Workgroup = 32 columns x 8 strip lanes.
+// out[g][c][j] = sum over the strips of group g of part[g*strips + s][c][j].  Workgroup = COLS columns x (256 / COLS) strip
+// lanes; 4 independent partial sums per lane keep 4 loads in flight.
+template <int COLS>
 __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int strips, int C2) {
-  __shared__ float red[8][33];
-  const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int chunks = (C2 + 31) / 32;
-  const int g = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 32 + col;
-  float acc = 0.f;
+  constexpr int LANES = 256 / COLS;
+  __shared__ float red[LANES][COLS + 1];
+  const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+  const int chunks = (C2 + COLS - 1) / COLS;
+  const int g = blockIdx.x / chunks, c = (blockIdx.x % chunks) * COLS + col;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (c < C2) {
     const float* p = part + (long)g * strips * C2 + c;
-    for (int s = sl; s < strips; s += 8) acc += p[(long)s * C2];
+    int s = sl;
+    for (; s + 3 * LANES < strips; s += 4 * LANES) {
+      a0 += p[(long)s * C2]; a1 += p[(long)(s + LANES) * C2]; a2 += p[(long)(s + 2 * LANES) * C2]; a3 += p[(long)(s + 3 * LANES) * C2];
+    }
+    for (; s < strips; s += LANES) a0 += p[(long)s * C2];
   }
-  red[sl][col] = acc;
+  red[sl][col] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (sl == 0 && c < C2) {
     float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; q++) t += red[q][col];
+    for (int q = 0; q < LANES; q++) t += red[q][col];
     out[(long)g * C2 + c] = t;
   }
 }
@@ -318,8 +324,13 @@ int strip_launch(float* out, float* ws, long ws_elems, int G, long strips, int C
   float* part = (ws && ws_elems >= need && strips > 1) ? ws : nullptr;
   launch(part);
   if (part) {
-    const int chunks = (C * 2 + 31) / 32;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)(G * chunks)), dim3(256), 0, st, (const float*)part, out, G, (int)strips, C * 2);
+    if ((long)G * C * 2 >= 4096) {
+      const int chunks = (C * 2 + 31) / 32;
+      hipLaunchKernelGGL(finalize_kernel<32>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, (const float*)part, out, G, (int)strips, C * 2);
+    } else {
+      const int chunks = (C * 2 + 3) / 4;
+      hipLaunchKernelGGL(finalize_kernel<4>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, (const float*)part, out, G, (int)strips, C * 2);
+    }
   }
   return du_check_launch();
 }

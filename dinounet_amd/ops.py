@@ -580,8 +580,10 @@ def msda_backward_raw(value, shapes, lsi, loc, attn, grad_out):
     gv = torch.zeros((N, S, M, D), dtype=torch.float32, device=value.device)
     gl = torch.zeros(loc.shape, dtype=torch.float32, device=value.device)
     ga = torch.zeros(attn.shape, dtype=torch.float32, device=value.device)
+    n = int(_lib.lib().du_msda_bwd_ws_elems(N, S, M, D, L, Lq, P))
+    ws = torch.empty(max(n, 1), dtype=torch.float32, device=value.device)
     _lib.check(_lib.lib().du_msda_backward(_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(attn), _p(grad_out), _p(gv),
-                                           _p(gl), _p(ga), N, S, M, D, L, Lq, P, _st()), "du_msda_backward")
+                                           _p(gl), _p(ga), N, S, M, D, L, Lq, P, _p(ws), n, _st()), "du_msda_backward")
     return gv, gl, ga
 
 

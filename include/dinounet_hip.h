@@ -156,10 +156,14 @@ int du_msda_forward(int dtype, const void* value, const int64_t* spatial_shapes,
                     int Lq, int P, void* stream);
 /* grad_value (fp32, N,S,M,D), grad_sampling_loc, grad_attn_weight (fp32): zero-filled by the caller
    (the reference allocates them with at::zeros, ms_deform_attn_cuda.cu:126-128). */
+/* Optional scratch `ws` (du_msda_bwd_ws_elems floats, 0 = not needed for this shape): the LDS-resident kernel then writes one
+   partial grad_value plane per query chunk with plain stores and a second kernel sums them into grad_value (OVERWRITING it)
+   instead of flushing every chunk with global fp32 atomics. */
+int64_t du_msda_bwd_ws_elems(int N, int S, int M, int D, int L, int Lq, int P);
 int du_msda_backward(int dtype, const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                      const float* sampling_loc, const float* attn_weight, const void* grad_out, float* grad_value,
                      float* grad_sampling_loc, float* grad_attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
-                     void* stream);
+                     float* ws, int64_t ws_elems, void* stream);
 
 /* MSDeformAttn glue (ms_deform_attn.py:188-197, single level): raw (rows, M*P*2 + M*P) = [offsets | logits] from the
    fused sampling_offsets/attention_weights GEMM; ref (Lq, 2) reference points (x, y);

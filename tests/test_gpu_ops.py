@@ -253,6 +253,27 @@ def test_msda_production_shape(dt, Dh):
     assert rel(out, ref) < t and rel(gv, gvr) < t and rel(ga, gar) < t and rel(gl, glr) < 5 * t
 
 
+@pytest.mark.parametrize("N,Hs,Ws,Lq,Dh", [(1, 6, 4, 126, 24), (3, 20, 36, 700, 32), (1, 32, 32, 100, 8)])
+def test_msda_bf16_mfma_grad_value_odd_planes(N, Hs, Ws, Lq, Dh):
+    """bf16 backward = gather kernel + grad_value-as-GEMM on the MFMA pipe: non-square planes, planes larger than one 512-pixel
+    tile, ragged query counts, samples outside the plane (zero padding)."""
+    from dinounet_amd import ops
+    from oracle import dinounet_oracle as O
+    d = dev()
+    dt = torch.bfloat16
+    S, M, P = Hs * Ws, 16, 4
+    v = q(gen(N, S, M, Dh, seed=11), dt)
+    loc = torch.rand(N, Lq, M, 1, P, 2, generator=torch.Generator().manual_seed(12)) * 1.3 - 0.15
+    a = torch.softmax(gen(N, Lq, M, 1, P, seed=13), -1)
+    go = q(gen(N, Lq, M * Dh, seed=14), dt)
+    gvr, glr, gar = O.msda_backward(v, [(Hs, Ws)], loc, a, go)
+    shapes, lsi = torch.tensor([[Hs, Ws]], device=d), torch.zeros(1, dtype=torch.long, device=d)
+    vg, lg, ag = v.to(d, dt).requires_grad_(True), loc.to(d).requires_grad_(True), a.to(d).requires_grad_(True)
+    out = ops.msda(vg, shapes, lsi, lg, ag)
+    gv, gl, ga = torch.autograd.grad(out, (vg, lg, ag), go.to(d, dt))
+    assert rel(gv, gvr) < 2e-2 and rel(ga, gar) < 2e-2 and rel(gl, glr) < 1e-1
+
+
 def test_msda_prep_fwd_bwd():
     from dinounet_amd import ops
     d = dev()
