@@ -65,17 +65,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int H, int N,
                                                        int Npad) {
   constexpr int KT = 64;             // keys per tile
-  constexpr int KLD = DH + 8;        // Ks row stride (elements)
-  constexpr int VLD = KT + 8;        // Vt row stride
+  constexpr int KLD = DH + 8;        // K image [key][DH + 8]: 16-byte-padded rows, conflict-free ds_read_b128 fragments
+  constexpr int VLD = DH + 32;       // V image [key][DH + 32]: row pitch = 64 B (mod 256 B) so the 4 key rows of one LDS transpose
+                                     // read (ds_read_b64_tr_b16) fall on disjoint bank groups; V is stored as it lies in HBM
   constexpr int NKK = DH / 16;       // k-steps of the S^T product
   constexpr int NDB = DH / 32;       // 32-wide dv blocks of O^T
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[KT * KLD];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[DH * VLD];
+  constexpr int BUF = KT * KLD + KT * VLD;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BUF];   // two {K, V} buffers: one barrier per key tile
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4 lds_v4;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, ql = lane & 31;
   const int bh = blockIdx.y;
   const int q0 = blockIdx.x * 128 + wave * 32;
+  const bool active = q0 < N;        // wave-uniform: the last query tile of N = 1029 keeps only one wave busy
   const bf16_t* Qb = Q + (long)bh * Npad * DH;
   const bf16_t* Kb = K + (long)bh * Npad * DH;
   const bf16_t* Vb = V + (long)bh * Npad * DH;
@@ -111,89 +116,101 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       }
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf) {
+    bf16_t* Ks = smem + buf * BUF;
+    bf16_t* Vs = Ks + KT * KLD;
 #pragma unroll
     for (int i = 0; i < NVEC; i++) {
       int v = tid + i * 256;
       int key = v / (DH / 8), d8 = v % (DH / 8);
       *(uint4*)(Ks + key * KLD + d8 * 8) = kreg[i];
-      Vec16<bf16_t> e = as_vec<bf16_t>(vreg[i]);
-#pragma unroll
-      for (int j = 0; j < 8; j++) Vt[(d8 * 8 + j) * VLD + key] = e.v[j];
+      *(uint4*)(Vs + key * VLD + d8 * 8) = vreg[i];
     }
   };
 
   const int ntiles = (N + KT - 1) / KT;
   gload(0);
-  lstore();
+  lstore(0);
   __syncthreads();
   for (int kt = 0; kt < ntiles; kt++) {
     const bool more = kt + 1 < ntiles;
     if (more) gload(kt + 1);
+    const bf16_t* Ks = smem + (kt & 1) * BUF;
+    const bf16_t* Vs = Ks + KT * KLD;
+    if (active) {
+      // ---- S^T = K Q^T for the two 32-key blocks ----
+      f32x16 s[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < NKK; kk++) {
+          bf16x8 kf = *(const bf16x8*)(Ks + (kb * 32 + ql) * KLD + kk * 16 + half * 8);
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
+        }
+      }
+      // ---- mask the tail keys (last tile only), online softmax in base 2 (q was pre-scaled by Dh^-1/2 * log2 e) ----
+      if (!more) {
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int key = kt * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key >= N) s[kb][r] = -1e30f;
+          }
+      }
+      float mx = s[0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // deferred rescale: keep the old running max while the tile's max exceeds it by <= 8 (P <= 2^8, exact in the fp32
+      // accumulators, bf16 P keeps its relative precision); the branch is wave-uniform
+      if (!__all(mx - m_run <= 8.0f)) {
+        const float mn = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - mn);
+        m_run = mn;
+        l_part *= alpha;
+#pragma unroll
+        for (int d = 0; d < NDB; d++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc_o[d][r] *= alpha;
+      }
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          float p = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
+          s[kb][r] = p;
+          psum += p;
+        }
+      l_part += psum;
 
-    // ---- S^T = K Q^T for the two 32-key blocks ----
-    f32x16 s[2];
+      // ---- O^T += V^T P^T: B fragment of k-step st = accumulator registers 8st..8st+7 of s[kb] (keys kb*32 + 16st + 4half + {0..3, 8..11});
+      //      A fragment = the matching V rows, fetched with two LDS transpose reads ----
+      const int g = lane >> 4, p16 = lane & 15;
 #pragma unroll
-    for (int kb = 0; kb < 2; kb++) {
+      for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
+        for (int st = 0; st < 2; st++) {
+          bf16x8 pf;
 #pragma unroll
-      for (int kk = 0; kk < NKK; kk++) {
-        bf16x8 kf = *(const bf16x8*)(Ks + (kb * 32 + ql) * KLD + kk * 16 + half * 8);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
-      }
-    }
-    // ---- mask the tail keys, online softmax (scores are already in log2 units: q was pre-scaled) ----
-    float mx = m_run;
+          for (int e = 0; e < 8; e++) pf[e] = (bf16_t)s[kb][8 * st + e];
 #pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int key = kt * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (key >= N) s[kb][r] = -1e30f;
-        mx = fmaxf(mx, s[kb][r]);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float alpha = exp2f(m_run - mx);
-    m_run = mx;
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float p = exp2f(s[kb][r] - mx);
-        s[kb][r] = p;
-        psum += p;
-      }
-    l_part = l_part * alpha + psum;
-#pragma unroll
-    for (int d = 0; d < NDB; d++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc_o[d][r] *= alpha;
-
-    // ---- O^T += V^T P^T ----
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++) {
-#pragma unroll
-      for (int st = 0; st < 2; st++) {
-        bf16x8 pf;
-#pragma unroll
-        for (int e = 0; e < 8; e++) pf[e] = (bf16_t)s[kb][8 * st + e];
-#pragma unroll
-        for (int d = 0; d < NDB; d++) {
-          // A fragment element e of lane (dv, half) <-> key kb*32 + (e&3) + 8*(2*st + (e>>2)) + 4*half
-          const bf16_t* vp = Vt + (d * 32 + ql) * VLD + kb * 32 + 16 * st + 4 * half;
-          bf16x4 lo = *(const bf16x4*)(vp);
-          bf16x4 hi = *(const bf16x4*)(vp + 8);
-          bf16x8 vf;
-#pragma unroll
-          for (int e = 0; e < 4; e++) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
-          acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc_o[d], 0, 0, 0);
+          for (int d = 0; d < NDB; d++) {
+            const bf16_t* vp = Vs + (kb * 32 + 16 * st + 4 * (g >> 1) + (p16 >> 2)) * VLD + d * 32 + 16 * (g & 1) + 4 * (p16 & 3);
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)vp);
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(vp + 8 * VLD));
+            s16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf, acc_o[d], 0, 0, 0);
+          }
         }
       }
     }
-    __syncthreads();
-    if (more) lstore();
+    if (more) lstore((kt + 1) & 1);
     __syncthreads();
   }
 
@@ -207,11 +224,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int d = 0; d < NDB; d++)
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
+      for (int g4 = 0; g4 < 4; g4++) {
         bf16x4 o4;
 #pragma unroll
-        for (int e = 0; e < 4; e++) o4[e] = (bf16_t)(acc_o[d][g * 4 + e] * inv);
-        *(bf16x4*)(op + d * 32 + 8 * g + 4 * half) = o4;
+        for (int e = 0; e < 4; e++) o4[e] = (bf16_t)(acc_o[d][g4 * 4 + e] * inv);
+        *(bf16x4*)(op + d * 32 + 8 * g4 + 4 * half) = o4;
       }
   }
 }
