@@ -130,7 +130,14 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1 or force_pg:
-        dist.destroy_process_group()
+        # The captured step holds RCCL kernels; tearing the process group down while the graph objects are still alive made the
+        # watchdog thread abort at interpreter exit on some runs (observed once in three, after the JSON line was out).  Everything is
+        # synchronised and printed at this point, so leave without running the teardown.
+        torch.cuda.synchronize()
+        dist.barrier()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def cpu_baseline(net, a):

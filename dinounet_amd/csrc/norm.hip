@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
 template <typename L>
 int strip_launch(float* out, float* ws, long ws_elems, int G, long strips, int C, hipStream_t st, L launch) {
   const long need = (long)G * strips * C * 2;
-  float* part = (ws && ws_elems >= need && strips > 1) ? ws : nullptr;
+  float* part = (ws && ws_elems >= need) ? ws : nullptr;   // with scratch the result is always OVERWRITTEN (no zero-fill needed)
   launch(part);
   if (part) {
     if ((long)G * C * 2 >= 4096) {
@@ -333,6 +333,35 @@ int strip_launch(float* out, float* ws, long ws_elems, int G, long strips, int C
     }
   }
   return du_check_launch();
+}
+
+// mean / rstd from channel sums (biased variance, like InstanceNorm2d / BatchNorm2d forward); optional running-statistics
+// update of BatchNorm (momentum m, unbiased variance), G == 1 only.
+__global__ __launch_bounds__(256) void norm_stats_finalize_kernel(const float* __restrict__ sums, float inv_count, float eps,
+                                                                  float* __restrict__ mean, float* __restrict__ rstd, long n,
+                                                                  float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                  float momentum, float unbias) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float m = sums[i * 2] * inv_count;
+  float var = sums[i * 2 + 1] * inv_count - m * m;
+  var = var > 0.f ? var : 0.f;
+  mean[i] = m;
+  rstd[i] = rsqrtf(var + eps);
+  if (run_mean) {
+    run_mean[i] = (1.f - momentum) * run_mean[i] + momentum * m;
+    run_var[i] = (1.f - momentum) * run_var[i] + momentum * var * unbias;
+  }
+}
+
+// dw[c] = sum_g bs[g][c][1], db[c] = sum_g bs[g][c][0]
+__global__ __launch_bounds__(256) void norm_param_grads_kernel(const float* __restrict__ bs, float* __restrict__ dw, float* __restrict__ db,
+                                                               int G, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int g = 0; g < G; g++) { b += bs[((long)g * C + c) * 2]; a += bs[((long)g * C + c) * 2 + 1]; }
+  dw[c] = a; db[c] = b;
 }
 
 int grid_for(long total) { long g = (total + 255) / 256; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
@@ -428,6 +457,24 @@ extern "C" int du_chan_dot(int dtype, const void* a, int64_t lda, const void* b,
     if (dtype == DU_BF16) hipLaunchKernelGGL(chan_dot_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, sums, G, P, C, STRIP, part);
     else hipLaunchKernelGGL(chan_dot_kernel<float>, grid, block, 0, st, (const float*)a, lda, (const float*)b, ldb, sums, G, P, C, STRIP, part);
   });
+}
+
+extern "C" int du_norm_stats_finalize(const float* sums, float count, float eps, float* mean, float* rstd, int G, int C, float* run_mean,
+                                      float* run_var, float momentum, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!sums || !mean || !rstd || G <= 0 || C <= 0 || count <= 0.f || (run_mean && G != 1) || (!run_mean != !run_var)) return DU_ERR_BAD_ARG;
+  const long n = (long)G * C;
+  const float unbias = count > 1.f ? count / (count - 1.f) : 1.f;
+  hipLaunchKernelGGL(norm_stats_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sums, 1.f / count, eps, mean, rstd, n,
+                     run_mean, run_var, momentum, unbias);
+  return du_check_launch();
+}
+
+extern "C" int du_norm_param_grads(const float* bsums, float* dw, float* db, int G, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!bsums || !dw || !db || G <= 0 || C <= 0) return DU_ERR_BAD_ARG;
+  hipLaunchKernelGGL(norm_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, bsums, dw, db, G, C);
+  return du_check_launch();
 }
 
 extern "C" int du_norm_act_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* mean, const float* rstd,

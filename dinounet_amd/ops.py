@@ -218,7 +218,7 @@ def _reduce_ws(dt, G, P, Cc, device):
 def colsum(x2d):
     """sum over rows of a (rows, C) matrix -> fp32 (C,)   (bias gradients)."""
     rows, Cc, ld = _rows2d(x2d)
-    sums = torch.zeros((1, Cc, 2), dtype=torch.float32, device=x2d.device)
+    sums = torch.empty((1, Cc, 2), dtype=torch.float32, device=x2d.device)    # overwritten by the two-stage reduction
     ws, n = _reduce_ws(x2d.dtype, 1, rows, Cc, x2d.device)
     _lib.check(_lib.lib().du_chan_stats(_code(x2d.dtype), _p(x2d), ld, _p(sums), 1, rows, Cc, _p(ws), n, _st()), "du_chan_stats")
     return sums[0, :, 0].contiguous()
@@ -441,7 +441,7 @@ def chan_stats(x, G):
     """NHWC x -> (G, C, 2) fp32 sums (sum, sum of squares) over each group's pixels (G=B: InstanceNorm, G=1: BatchNorm)."""
     B, H, W, Cc, ld = _nhwc(x)
     P = (B // G) * H * W
-    sums = torch.zeros((G, Cc, 2), dtype=torch.float32, device=x.device)
+    sums = torch.empty((G, Cc, 2), dtype=torch.float32, device=x.device)
     ws, n = _reduce_ws(x.dtype, G, P, Cc, x.device)
     _lib.check(_lib.lib().du_chan_stats(_code(x.dtype), _p(x), ld, _p(sums), G, P, Cc, _p(ws), n, _st()), "du_chan_stats")
     return sums, P
@@ -476,13 +476,12 @@ class _NormAct(torch.autograd.Function):
                 sums = sums.clone()
                 torch.distributed.all_reduce(sums, group=group)   # equal per-rank batch (TRN:322-327 splits evenly)
                 count = count * torch.distributed.get_world_size(group)
-            mean = sums[..., 0] / count
-            var = (sums[..., 1] / count - mean * mean).clamp_min_(0.0)
-            rstd = torch.rsqrt(var + eps)
-            if kind == "bn" and running_mean is not None:
-                with torch.no_grad():
-                    running_mean.mul_(1 - momentum).add_(mean[0], alpha=momentum)
-                    running_var.mul_(1 - momentum).add_(var[0] * (count / max(count - 1.0, 1.0)), alpha=momentum)
+            mean = torch.empty((G, Cc), dtype=torch.float32, device=x.device)
+            rstd = torch.empty((G, Cc), dtype=torch.float32, device=x.device)
+            upd = kind == "bn" and running_mean is not None
+            _lib.check(_lib.lib().du_norm_stats_finalize(_p(sums), count, eps, _p(mean), _p(rstd), G, Cc,
+                                                         _p(running_mean) if upd else None, _p(running_var) if upd else None,
+                                                         float(momentum), _st()), "du_norm_stats_finalize")
         else:
             G, P = 1, B * H * W
             mean = running_mean.float().view(1, Cc)
@@ -500,12 +499,13 @@ class _NormAct(torch.autograd.Function):
         B, H, W, Cc, ld = _nhwc(x)
         dy = dy.contiguous()
         L = _lib.lib()
-        bs = torch.zeros((G, Cc, 2), dtype=torch.float32, device=x.device)
+        bs = torch.empty((G, Cc, 2), dtype=torch.float32, device=x.device)
         ws, n = _reduce_ws(x.dtype, G, P, Cc, x.device)
         _lib.check(L.du_norm_act_bwd_stats(_code(x.dtype), _p(x), ld, _p(dy), Cc, _p(mean), _p(rstd), _p(wf), _p(bf), _p(bs), G, P,
                                            Cc, act, _p(ws), n, _st()), "du_norm_act_bwd_stats")
-        dw = bs[..., 1].sum(0)
-        db = bs[..., 0].sum(0)
+        dw = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        db = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        _lib.check(L.du_norm_param_grads(_p(bs), _p(dw), _p(db), G, Cc, _st()), "du_norm_param_grads")
         bsr = bs
         if kind == "bn" and use_batch and group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
             bsr = bs.clone()
@@ -549,7 +549,7 @@ class _LayerNorm(torch.autograd.Function):
         D = xc.shape[-1]
         dyc = dy.contiguous()
         dx = torch.empty_like(xc)
-        dwdb = torch.zeros((D, 2), dtype=torch.float32, device=xc.device)
+        dwdb = torch.empty((D, 2), dtype=torch.float32, device=xc.device)
         ws, n = _reduce_ws(xc.dtype, 1, xc.numel() // D, D, xc.device)
         _lib.check(_lib.lib().du_layernorm_bwd(_code(xc.dtype), _p(xc), _p(dyc), _p(wf), _p(mean), _p(rstd), _p(dx), _p(dwdb),
                                                xc.numel() // D, D, _p(ws), n, _st()), "du_layernorm_bwd")
@@ -681,8 +681,8 @@ class _DWConvSegs(torch.autograd.Function):
         else:
             dz = dy
         dx = torch.empty_like(x)
-        dw = torch.zeros((Cc, 9), dtype=torch.float32, device=x.device)
-        db = torch.zeros(Cc, dtype=torch.float32, device=x.device) if has_bias else None
+        dw = torch.empty((Cc, 9), dtype=torch.float32, device=x.device)      # written by the first segment, accumulated by the rest
+        db = torch.empty(Cc, dtype=torch.float32, device=x.device) if has_bias else None
         for si, (off, B, h, ww, ld, bs) in enumerate(segs):
             _lib.check(L.du_dwconv3x3_bwd_data(code, C.c_void_p(dz.data_ptr() + off * es), ld, bs, _p(wf),
                                                C.c_void_p(dx.data_ptr() + off * es), ld, bs, B, h, ww, Cc, _st()),
@@ -793,7 +793,7 @@ class _SqueezeExcite(torch.autograd.Function):
         R = w1f.shape[0]
         L = _lib.lib()
         dy = dy.contiguous()
-        dsum = torch.zeros((B, Cc, 2), dtype=torch.float32, device=x.device)
+        dsum = torch.empty((B, Cc, 2), dtype=torch.float32, device=x.device)
         ws, n = _reduce_ws(x.dtype, B, P, Cc, x.device)
         _lib.check(L.du_chan_dot(_code(x.dtype), _p(dy), Cc, _p(x), ld, _p(dsum), B, P, Cc, _p(ws), n, _st()), "du_chan_dot")
         dpool = torch.empty((B, Cc), dtype=torch.float32, device=x.device)

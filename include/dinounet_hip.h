@@ -134,6 +134,12 @@ int du_chan_stats(int dtype, const void* x, int64_t ldx, float* sums, int G, int
 /* sums[g][c][0..1] += (sum a*b, sum a) over the pixels of group g (squeeze-excitation gate gradient, a = dy, b = x). */
 int du_chan_dot(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, float* sums, int G, int64_t pix_per_group, int C,
                 float* ws, int64_t ws_elems, void* stream);
+/* mean = sum/count, rstd = rsqrt(max(sumsq/count - mean^2, 0) + eps) for sums (G,C,2) -> (G,C); with run_mean/run_var (nullable, G = 1):
+   BatchNorm running-statistics update, momentum m, unbiased variance (torch semantics). */
+int du_norm_stats_finalize(const float* sums, float count, float eps, float* mean, float* rstd, int G, int C, float* run_mean,
+                           float* run_var, float momentum, void* stream);
+/* affine-parameter gradients from the backward sums: dw[c] = sum_g bsums[g][c][1], db[c] = sum_g bsums[g][c][0] */
+int du_norm_param_grads(const float* bsums, float* dw, float* db, int G, int C, void* stream);
 /* y = act((x - mean[g,c]) * rstd[g,c] * w[c] + b[c]); mean/rstd: (G, C) fp32. */
 int du_norm_act_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* mean, const float* rstd,
                     const float* w, const float* b, int G, int64_t pix_per_group, int C, int act, void* stream);
