@@ -14,80 +14,59 @@ __host__ int grid_1d(long total) {
 #define GRID_STRIDE(i, total) for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (total); i += (long)gridDim.x * 256)
 
 // ---------------- depthwise 3x3, stride 1, pad 1 (dinov3_adapter.py:94-109, dinounet_training.py:235) ----------------
-template <typename T>
-__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x, long ldx, long xbs, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, T* __restrict__ y, long ldy, long ybs,
-                                                         T* __restrict__ z, int B, int H, int W, int C, int act, long total) {
+// Thread = (pixel lane, 8/4-channel vector); a thread keeps the 9 x VEC filter taps of its channels in registers and walks
+// pixels (grid-stride over pixel lanes), so the inner loop is 9 vector loads + 9*VEC FMAs + 1-2 vector stores per pixel.
+// FLIP = true evaluates the data gradient: correlation of dy with the spatially flipped filter.
+template <typename T, bool FLIP>
+__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, long ldx, long xbs, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, T* __restrict__ y, long ldy, long ybs,
+                                                     T* __restrict__ z, int B, int H, int W, int C, int act, int lanes_per_block) {
   constexpr int V = Elem<T>::VEC;
   const int cvn = C / V;
-  GRID_STRIDE(i, total) {
-    const int c0 = (int)(i % cvn) * V;
-    long t = i / cvn;
-    const int xo = (int)(t % W); t /= W;
-    const int yo = (int)(t % H);
-    const int b = (int)(t / H);
-    float acc[V];
+  const int cvb = min(cvn, 256);
+  const int np = 256 / cvb;
+  const int tp = threadIdx.x / cvb, tcv = threadIdx.x % cvb;
+  if (tp >= np) return;
+  const long npix = (long)B * H * W;
+  for (int cv = tcv; cv < cvn; cv += cvb) {
+    const int c0 = cv * V;
+    float wt[9][V], bs[V];
 #pragma unroll
-    for (int j = 0; j < V; j++) acc[j] = bias ? bias[c0 + j] : 0.f;
+    for (int j = 0; j < V; j++) {
+      bs[j] = bias ? bias[c0 + j] : 0.f;
 #pragma unroll
-    for (int dy = 0; dy < 3; dy++) {
-      const int yi = yo + dy - 1;
-      if (yi < 0 || yi >= H) continue;
+      for (int t = 0; t < 9; t++) wt[t][j] = w[(c0 + j) * 9 + (FLIP ? 8 - t : t)];
+    }
+    for (long p = (long)blockIdx.x * np + tp; p < npix; p += (long)gridDim.x * np) {
+      const int xo = (int)(p % W); long t2 = p / W;
+      const int yo = (int)(t2 % H); const int b = (int)(t2 / H);
+      float acc[V];
 #pragma unroll
-      for (int dx = 0; dx < 3; dx++) {
-        const int xi = xo + dx - 1;
-        if (xi < 0 || xi >= W) continue;
-        Vec16<T> v = as_vec<T>(*(const uint4*)(x + (long)b * xbs + ((long)yi * W + xi) * ldx + c0));
+      for (int j = 0; j < V; j++) acc[j] = bs[j];
 #pragma unroll
-        for (int j = 0; j < V; j++) acc[j] += to_f32(v.v[j]) * w[(c0 + j) * 9 + dy * 3 + dx];
+      for (int dy = 0; dy < 3; dy++) {
+        const int yi = yo + dy - 1;
+        if (yi < 0 || yi >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+          const int xi = xo + dx - 1;
+          if (xi < 0 || xi >= W) continue;
+          Vec16<T> v = as_vec<T>(*(const uint4*)(x + (long)b * xbs + ((long)yi * W + xi) * ldx + c0));
+#pragma unroll
+          for (int j = 0; j < V; j++) acc[j] += to_f32(v.v[j]) * wt[dy * 3 + dx][j];
+        }
       }
-    }
-    const long off = (long)b * ybs + ((long)yo * W + xo) * ldy + c0;
-    Vec16<T> o;
-    if (z) {
+      const long off = (long)b * ybs + ((long)yo * W + xo) * ldy + c0;
+      Vec16<T> o;
+      if (z) {
 #pragma unroll
-      for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(acc[j]);
-      *(uint4*)(z + off) = as_u4(o);
-    }
-#pragma unroll
-    for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(apply_act(acc[j], act));
-    *(uint4*)(y + off) = as_u4(o);
-  }
-}
-
-// dx = correlation of dy with the flipped kernel
-template <typename T>
-__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const T* __restrict__ dy, long lddy, long dybs,
-                                                              const float* __restrict__ w, T* __restrict__ dx, long lddx,
-                                                              long dxbs, int B, int H, int W, int C, long total) {
-  constexpr int V = Elem<T>::VEC;
-  const int cvn = C / V;
-  GRID_STRIDE(i, total) {
-    const int c0 = (int)(i % cvn) * V;
-    long t = i / cvn;
-    const int xi = (int)(t % W); t /= W;
-    const int yi = (int)(t % H);
-    const int b = (int)(t / H);
-    float acc[V];
-#pragma unroll
-    for (int j = 0; j < V; j++) acc[j] = 0.f;
-#pragma unroll
-    for (int ky = 0; ky < 3; ky++) {
-      const int yo = yi - ky + 1;
-      if (yo < 0 || yo >= H) continue;
-#pragma unroll
-      for (int kx = 0; kx < 3; kx++) {
-        const int xo = xi - kx + 1;
-        if (xo < 0 || xo >= W) continue;
-        Vec16<T> v = as_vec<T>(*(const uint4*)(dy + (long)b * dybs + ((long)yo * W + xo) * lddy + c0));
-#pragma unroll
-        for (int j = 0; j < V; j++) acc[j] += to_f32(v.v[j]) * w[(c0 + j) * 9 + ky * 3 + kx];
+        for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(acc[j]);
+        *(uint4*)(z + off) = as_u4(o);
       }
-    }
-    Vec16<T> o;
 #pragma unroll
-    for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(acc[j]);
-    *(uint4*)(dx + (long)b * dxbs + ((long)yi * W + xi) * lddx + c0) = as_u4(o);
+      for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(apply_act(acc[j], act));
+      *(uint4*)(y + off) = as_u4(o);
+    }
   }
 }
 
@@ -532,15 +511,23 @@ __global__ __launch_bounds__(256) void se_scale_bwd_kernel(const T* __restrict__
 #define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
   if ((dtype) == DU_BF16) { CALL_BF16; } else if ((dtype) == DU_F32) { CALL_F32; } else return DU_ERR_BAD_ARG;
 
+static inline int dwconv_grid(long npix, int C, int v) {
+  const int cvb = (C / v) < 256 ? (C / v) : 256;
+  const int np = 256 / cvb;
+  long blocks = (npix + np - 1) / np;
+  if (blocks > 4096) blocks = 4096;          // >= 4 pixels per lane once the tensor is large: amortises the 9 x VEC tap loads
+  return (int)(blocks < 1 ? 1 : blocks);
+}
+
 extern "C" int du_dwconv3x3_fwd(int dtype, const void* x, int64_t ldx, int64_t xbs, const float* w, const float* bias, void* y,
                                 int64_t ldy, int64_t ybs, void* z, int B, int H, int W, int C, int act, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C % v || ldx % v || ldy % v || xbs % v || ybs % v) return DU_ERR_BAD_ARG;
-  long total = (long)B * H * W * (C / v);
+  const int grid = dwconv_grid((long)B * H * W, C, v);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(dwconv_fwd_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, (const bf16_t*)x, ldx, xbs, w, bias, (bf16_t*)y, ldy, ybs, (bf16_t*)z, B, H, W, C, act, total),
-             hipLaunchKernelGGL(dwconv_fwd_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, (const float*)x, ldx, xbs, w, bias, (float*)y, ldy, ybs, (float*)z, B, H, W, C, act, total));
+             hipLaunchKernelGGL((dwconv_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ldx, xbs, w, bias, (bf16_t*)y, ldy, ybs, (bf16_t*)z, B, H, W, C, act, 0),
+             hipLaunchKernelGGL((dwconv_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)x, ldx, xbs, w, bias, (float*)y, ldy, ybs, (float*)z, B, H, W, C, act, 0));
   return du_check_launch();
 }
 
@@ -549,10 +536,10 @@ extern "C" int du_dwconv3x3_bwd_data(int dtype, const void* dy, int64_t lddy, in
   hipStream_t st = (hipStream_t)stream;
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (!dy || !w || !dx || B <= 0 || C % v || lddy % v || lddx % v || dybs % v || dxbs % v) return DU_ERR_BAD_ARG;
-  long total = (long)B * H * W * (C / v);
+  const int grid = dwconv_grid((long)B * H * W, C, v);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(dwconv_bwd_data_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, (const bf16_t*)dy, lddy, dybs, w, (bf16_t*)dx, lddx, dxbs, B, H, W, C, total),
-             hipLaunchKernelGGL(dwconv_bwd_data_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, (const float*)dy, lddy, dybs, w, (float*)dx, lddx, dxbs, B, H, W, C, total));
+             hipLaunchKernelGGL((dwconv_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, lddy, dybs, w, (const float*)nullptr, (bf16_t*)dx, lddx, dxbs, (bf16_t*)nullptr, B, H, W, C, DU_ACT_NONE, 0),
+             hipLaunchKernelGGL((dwconv_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)dy, lddy, dybs, w, (const float*)nullptr, (float*)dx, lddx, dxbs, (float*)nullptr, B, H, W, C, DU_ACT_NONE, 0));
   return du_check_launch();
 }
 

@@ -17,7 +17,7 @@ from ._lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, DU_BF16, DU_F32, IM2
                    PLAIN_ROW, STORE_PIXEL_SHUFFLE2, ConvGeom, GemmArgs)
 
 __all__ = ["mm", "linear", "conv2d", "conv_transpose2x2", "norm_act", "layer_norm", "msda", "dwconv3x3",
-           "maxpool3x3s2", "bilinear_add", "squeeze_excite"]
+           "maxpool3x3s2", "bilinear_add", "squeeze_excite", "dice_ce_loss"]
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -810,6 +810,53 @@ class _SqueezeExcite(torch.autograd.Function):
 
 def squeeze_excite(x, w1, b1, w2, b2, shortcut=None):
     return _SqueezeExcite.apply(x, w1, b1, w2, b2, shortcut)
+
+
+class _DiceCE(torch.autograd.Function):
+    """DC_and_CE_loss of the reference trainer (compound_losses.py:8-56; MemoryEfficientSoftDiceLoss batch_dice, do_bg=False,
+    smooth, dice.py:58-119) on fp32 NCHW logits, fused: one pass for the softmax sums, one pass for d loss / d logits.
+    With a process group the three dice sums are all-reduced (AllGatherGrad + sum, utilities/ddp_allgather.py:25-48)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, smooth, group):
+        logits = logits.float().contiguous()
+        B, K, H, W = logits.shape
+        HW = H * W
+        tgt = target.reshape(B, HW)
+        if tgt.dtype != torch.int64:
+            tgt = tgt.long()
+        tgt = tgt.contiguous()
+        L = _lib.lib()
+        n = int(L.du_dice_ce_ws_elems(B, K, HW))
+        if n <= 0:
+            raise RuntimeError(f"dinounet_hip: fused Dice+CE supports 2..8 classes, got {K}")
+        ws = torch.empty(n, dtype=torch.float32, device=logits.device)
+        sums = torch.empty(1 + 3 * (K - 1), dtype=torch.float32, device=logits.device)
+        _lib.check(L.du_dice_ce_sums(_p(logits), _p(tgt), _p(sums), B, K, HW, _p(ws), n, _st()), "du_dice_ce_sums")
+        mult = 1.0
+        if group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+            torch.distributed.all_reduce(sums[1:], group=group)
+            mult = float(torch.distributed.get_world_size(group))
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        coef = torch.empty(2 * (K - 1), dtype=torch.float32, device=logits.device)
+        _lib.check(L.du_dice_ce_finish(_p(sums), _p(loss), _p(coef), K, B * HW, float(smooth), mult, _st()), "du_dice_ce_finish")
+        ctx.save_for_backward(logits, tgt, coef)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, go):
+        logits, tgt, coef = ctx.saved_tensors
+        B, K, H, W = logits.shape
+        dl = torch.empty_like(logits)
+        gof = go.float().contiguous()
+        _lib.check(_lib.lib().du_dice_ce_bwd(_p(logits), _p(tgt), _p(coef), _p(gof), _p(dl), B, K, H * W, _st()), "du_dice_ce_bwd")
+        return dl, None, None, None
+
+
+def dice_ce_loss(logits, target, smooth=1e-5, group=None):
+    """logits (B,K,H,W) fp32, target (B,1,H,W) integer labels -> scalar loss (CE - mean soft dice)."""
+    _req(logits, target)
+    return _DiceCE.apply(logits, target, smooth, group)
 
 
 # ----------------------------------------------------------------------------------------------------

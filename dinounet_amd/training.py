@@ -26,8 +26,15 @@ class _AllReduceSumGrad(torch.autograd.Function):
 
 def dc_and_ce_loss(logits, target, smooth=1e-5, ddp=None, group=None):
     """DC_and_CE_loss (compound_losses.py:8-56) with MemoryEfficientSoftDiceLoss(batch_dice=True, do_bg=False,
-    smooth=1e-5) (dice.py:58-119, trainer config nnUNetTrainer.py:363-365).  target (B,1,H,W) integer labels."""
+    smooth=1e-5) (dice.py:58-119, trainer config nnUNetTrainer.py:363-365).  target (B,1,H,W) integer labels.
+    On the GPU (2..8 classes) this is the fused HIP loss (ops.dice_ce_loss); the torch formula below is the CPU / many-class path
+    used by the gloo tests."""
     K = logits.shape[1]
+    if logits.is_cuda and 2 <= K <= 8:
+        from . import ops
+        if ddp is None:
+            ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        return ops.dice_ce_loss(logits, target, smooth, (group if group is not None else dist.group.WORLD) if ddp else None)
     lab = target[:, 0].long()
     ce = F.cross_entropy(logits, lab)
     prob = torch.softmax(logits, 1)

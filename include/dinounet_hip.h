@@ -29,6 +29,8 @@
  *   du_bilinear_add_*            <- F.interpolate(bilinear, align_corners=False)+add (dinov3_adapter.py:472-476)
  *   du_se_gate_* / du_se_scale_*  <- SqueezeExcitation + residual (dinounet_training.py:210-225,438)
  *   du_msda_prep / du_msda_prep_bwd <- ms_deform_attn.py:188-197
+ *   du_dice_ce_*                  <- DC_and_CE_loss (training/loss/compound_losses.py:8-56, dice.py:58-119), the loss nnUNetTrainer.train_step
+ *          applies to the logits (nnUNetTrainer.py:917); "next" row of the scope table
  */
 #ifndef DINOUNET_HIP_H
 #define DINOUNET_HIP_H
@@ -215,6 +217,19 @@ int du_se_gate_bwd(const float* dsum, const float* sums, float inv_count, const 
 /* dx = dy * gate[b][c] + dpool[b][c] */
 int du_se_scale_bwd(int dtype, const void* dy, int64_t lddy, const float* gate, const float* dpool, void* dx, int64_t lddx, int B,
                     int64_t P, int C, void* stream);
+
+/* ---- trainer loss: DC_and_CE_loss (training/loss/compound_losses.py:8-56, dice.py:58-119: batch dice, no background, smooth 1e-5) ---- */
+/* logits (B,K,H,W) fp32 NCHW, target (B,H*W) int64 labels, K in [2,8].  sums: 1 + 3(K-1) floats = [sum -log p_t, (I_c, P_c, G_c) c>=1].
+   scratch: du_dice_ce_ws_elems floats.  Under data parallelism the caller all-reduces sums[1:] between _sums and _finish. */
+int64_t du_dice_ce_ws_elems(int B, int K, int64_t HW);
+int du_dice_ce_sums(const float* logits, const int64_t* target, float* sums, int B, int K, int64_t HW, float* ws, int64_t ws_elems,
+                    void* stream);
+/* loss (1 float) = CE - mean_c dice_c; coef (2(K-1)) = backward coefficients; npix = this rank's pixel count; grad_mult = world size
+   when the dice sums were all-reduced, else 1 */
+int du_dice_ce_finish(const float* sums, float* loss, float* coef, int K, int64_t npix, float smooth, float grad_mult, void* stream);
+/* dlogits (B,K,H,W) fp32 = grad_out[0] * d loss / d logits (grad_out: device scalar or NULL for 1) */
+int du_dice_ce_bwd(const float* logits, const int64_t* target, const float* coef, const float* grad_out, float* dlogits, int B, int K,
+                   int64_t HW, void* stream);
 
 /* ---- elementwise helpers --------------------------------------------------------------------------- */
 int du_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);

@@ -406,6 +406,24 @@ def test_squeeze_excite_fwd_bwd(dt, B, H, W, C, with_sc):
         assert rel(got.grad, want.grad) < tol * 2, (got.shape, rel(got.grad, want.grad))
 
 
+@pytest.mark.parametrize("B,K,H,W", [(2, 2, 64, 64), (3, 4, 48, 40), (8, 2, 512, 512), (1, 8, 32, 32)])
+def test_fused_dice_ce_loss(B, K, H, W):
+    """Fused DC+CE (loss + d loss / d logits) vs the reference formula (oracle restatement of compound_losses.py / dice.py)."""
+    from dinounet_amd import ops
+    from oracle import dinounet_oracle as O
+    d = dev()
+    logits = gen(B, K, H, W, seed=21, scale=2.0)
+    tgt = torch.randint(0, K, (B, 1, H, W), generator=torch.Generator().manual_seed(22))
+    lr = logits.clone().requires_grad_(True)
+    ref = O.dc_and_ce_loss(lr, tgt)
+    (ref * 1.7).backward()
+    lg = logits.to(d).requires_grad_(True)
+    out = ops.dice_ce_loss(lg, tgt.to(d))
+    (out * 1.7).backward()
+    assert abs(float(out) - float(ref)) < 2e-5 * max(1.0, abs(float(ref)))
+    assert rel(lg.grad, lr.grad) < 2e-4
+
+
 def test_train_step_hipgraph_matches_eager():
     """A hipGraph-captured TrainStep (training.TrainStep, what bench.py times) must reproduce eager steps: same losses over several
     replays, finite gradients (regression test: library reductions/GEMMs inside the captured region went non-finite on the 2nd replay)."""
