@@ -209,85 +209,149 @@ __global__ __launch_bounds__(256) void chan_dot_kernel(const T* __restrict__ a_,
   });
 }
 
+// The three norm+activation kernels share one decomposition: workgroup (blockIdx.y = group g, blockIdx.x = pixel-lane slot),
+// thread = (pixel lane, channel vector).  A thread's per-channel constants (scale / shift / sums) live in registers and it walks the
+// pixels of its group, so the inner loop is 1-2 vector loads + VEC FMAs (+ activation) + 1 vector store -- the first version
+// re-read mean/rstd/w/b per element (32 scalar loads per 16-byte vector) and ran at ~0.9 TB/s.
 template <typename T>
 __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ w, const float* __restrict__ b, long P,
-                                                           int C, int act, long total_vec) {
+                                                           int C, int act) {
   constexpr int V = Elem<T>::VEC;
-  const int cvn = C / V;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (long)gridDim.x * 256) {
-    const long pix = i / cvn;
-    const int c0 = (int)(i % cvn) * V;
-    const int g = (int)(pix / P);
-    Vec16<T> t = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
-    Vec16<T> o;
+  const int cvn = C / V, cvb = min(cvn, 256), np = 256 / cvb;
+  const int tp = threadIdx.x / cvb, tcv = threadIdx.x % cvb;
+  if (tp >= np) return;
+  const int g = blockIdx.y;
+  for (int cv = tcv; cv < cvn; cv += cvb) {
+    const int c0 = cv * V;
+    float sc[V], sh[V];
 #pragma unroll
     for (int j = 0; j < V; j++) {
-      const int c = c0 + j;
-      float z = (to_f32(t.v[j]) - mean[(long)g * C + c]) * rstd[(long)g * C + c] * w[c] + b[c];
-      o.v[j] = from_f32<T>(apply_act(z, act));
+      sc[j] = rstd[(long)g * C + c0 + j] * w[c0 + j];
+      sh[j] = b[c0 + j] - mean[(long)g * C + c0 + j] * sc[j];
     }
-    *(uint4*)(y + pix * ldy + c0) = as_u4(o);
+    for (long p = (long)blockIdx.x * np + tp; p < P; p += (long)gridDim.x * np) {
+      const long pix = (long)g * P + p;
+      Vec16<T> t = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(apply_act(to_f32(t.v[j]) * sc[j] + sh[j], act));
+      *(uint4*)(y + pix * ldy + c0) = as_u4(o);
+    }
   }
 }
 
+// backward pass 1: per-(g,c) sums of dz = dy * act'(z) and dz * xhat over this workgroup's pixels -> partial (or atomics)
 template <typename T>
 __global__ __launch_bounds__(256) void norm_act_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                                  long lddy, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const float* __restrict__ w,
                                                                  const float* __restrict__ b, float* __restrict__ bsums, int G,
-                                                                 long P, int C, int act, int strip, float* part) {
+                                                                 long P, int C, int act, int STRIP, float* part) {
   constexpr int V = Elem<T>::VEC;
-  strip_reduce<T>(G, P, C, strip, bsums, part, [&](long pix, int g, int c0, float* a, float* bb) {
-    Vec16<T> tx = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
-    Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + pix * lddy + c0));
+  __shared__ float red[2][256 * V];
+  const int cv_total = C / V;
+  const long strips = (P + STRIP - 1) / STRIP;
+  const int g = blockIdx.x / strips;
+  const long p0 = (long)(blockIdx.x % strips) * STRIP;
+  const long p1 = min(P, p0 + STRIP);
+  const int cvb = min(cv_total, 256);
+  const int tp = threadIdx.x / cvb, tcv = threadIdx.x % cvb;
+  const int np = 256 / cvb;
+  for (int cv0 = 0; cv0 < cv_total; cv0 += cvb) {
+    const int cv = cv0 + tcv;
+    float a[V], bb[V];
 #pragma unroll
-    for (int j = 0; j < V; j++) {
-      const int c = c0 + j;
-      float xh = (to_f32(tx.v[j]) - mean[(long)g * C + c]) * rstd[(long)g * C + c];
-      float z = xh * w[c] + b[c];
-      float dz = to_f32(tg.v[j]) * act_grad(z, act);
-      a[j] += dz;
-      bb[j] += dz * xh;
+    for (int j = 0; j < V; j++) { a[j] = 0.f; bb[j] = 0.f; }
+    if (cv < cv_total && tp < np) {
+      const int c0 = cv * V;
+      float mu[V], rs[V], wc[V], bc[V];
+#pragma unroll
+      for (int j = 0; j < V; j++) { mu[j] = mean[(long)g * C + c0 + j]; rs[j] = rstd[(long)g * C + c0 + j]; wc[j] = w[c0 + j]; bc[j] = b[c0 + j]; }
+#pragma unroll 2
+      for (long p = p0 + tp; p < p1; p += np) {
+        const long pix = (long)g * P + p;
+        Vec16<T> tx = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
+        Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + pix * lddy + c0));
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+          const float xh = (to_f32(tx.v[j]) - mu[j]) * rs[j];
+          const float dz = to_f32(tg.v[j]) * act_grad(xh * wc[j] + bc[j], act);
+          a[j] += dz;
+          bb[j] += dz * xh;
+        }
+      }
     }
-  });
+#pragma unroll
+    for (int j = 0; j < V; j++) { red[0][threadIdx.x * V + j] = a[j]; red[1][threadIdx.x * V + j] = bb[j]; }
+    __syncthreads();
+    if (tp == 0 && cv < cv_total) {
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        float sa = 0.f, sb = 0.f;
+        for (int q = 0; q < np; q++) { sa += red[0][(q * cvb + tcv) * V + j]; sb += red[1][(q * cvb + tcv) * V + j]; }
+        if (part) {
+          part[((long)blockIdx.x * C + cv * V + j) * 2 + 0] = sa;
+          part[((long)blockIdx.x * C + cv * V + j) * 2 + 1] = sb;
+        } else {
+          atomic_add_f32(bsums + ((long)g * C + cv * V + j) * 2 + 0, sa);
+          atomic_add_f32(bsums + ((long)g * C + cv * V + j) * 2 + 1, sb);
+        }
+      }
+    }
+    __syncthreads();
+  }
 }
 
+// backward pass 2: dx = w*rstd*(dz - s1/n - xhat*s2/n)   (use_batch_stats = 0: dx = dz*w*rstd)
 template <typename T>
 __global__ __launch_bounds__(256) void norm_act_bwd_dx_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                               long lddy, T* __restrict__ dx, long lddx,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ w, const float* __restrict__ b,
                                                               const float* __restrict__ bsums, long P, int C, int act,
-                                                              float inv_count, int use_batch_stats, long total_vec) {
+                                                              float inv_count, int use_batch_stats) {
   constexpr int V = Elem<T>::VEC;
-  const int cvn = C / V;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (long)gridDim.x * 256) {
-    const long pix = i / cvn;
-    const int c0 = (int)(i % cvn) * V;
-    const int g = (int)(pix / P);
-    Vec16<T> tx = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
-    Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + pix * lddy + c0));
-    Vec16<T> o;
+  const int cvn = C / V, cvb = min(cvn, 256), np = 256 / cvb;
+  const int tp = threadIdx.x / cvb, tcv = threadIdx.x % cvb;
+  if (tp >= np) return;
+  const int g = blockIdx.y;
+  for (int cv = tcv; cv < cvn; cv += cvb) {
+    const int c0 = cv * V;
+    float mu[V], rs[V], wc[V], bc[V], k1[V], k2[V];
 #pragma unroll
     for (int j = 0; j < V; j++) {
-      const int c = c0 + j;
-      const float rs = rstd[(long)g * C + c];
-      float xh = (to_f32(tx.v[j]) - mean[(long)g * C + c]) * rs;
-      float z = xh * w[c] + b[c];
-      float dz = to_f32(tg.v[j]) * act_grad(z, act);
-      float r;
-      if (use_batch_stats) {
-        float s1 = bsums[((long)g * C + c) * 2 + 0], s2 = bsums[((long)g * C + c) * 2 + 1];
-        r = w[c] * rs * (dz - s1 * inv_count - xh * s2 * inv_count);
-      } else {
-        r = w[c] * rs * dz;
-      }
-      o.v[j] = from_f32<T>(r);
+      mu[j] = mean[(long)g * C + c0 + j]; rs[j] = rstd[(long)g * C + c0 + j]; wc[j] = w[c0 + j]; bc[j] = b[c0 + j];
+      k1[j] = use_batch_stats ? bsums[((long)g * C + c0 + j) * 2 + 0] * inv_count : 0.f;
+      k2[j] = use_batch_stats ? bsums[((long)g * C + c0 + j) * 2 + 1] * inv_count : 0.f;
     }
-    *(uint4*)(dx + pix * lddx + c0) = as_u4(o);
+    for (long p = (long)blockIdx.x * np + tp; p < P; p += (long)gridDim.x * np) {
+      const long pix = (long)g * P + p;
+      Vec16<T> tx = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
+      Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + pix * lddy + c0));
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        const float xh = (to_f32(tx.v[j]) - mu[j]) * rs[j];
+        const float dz = to_f32(tg.v[j]) * act_grad(xh * wc[j] + bc[j], act);
+        o.v[j] = from_f32<T>(wc[j] * rs[j] * (dz - k1[j] - xh * k2[j]));
+      }
+      *(uint4*)(dx + pix * lddx + c0) = as_u4(o);
+    }
   }
+}
+
+// pixel-lane slots per group for the two elementwise kernels: ~4096 workgroups in total, >= 4 pixels per lane
+static inline int norm_slots(int G, long P, int C, int vec) {
+  const int cvb = (C / vec) < 256 ? (C / vec) : 256;
+  const int np = 256 / (cvb > 0 ? cvb : 1);
+  long s = (P + (long)np * 4 - 1) / ((long)np * 4);
+  long cap = 4096 / (G > 0 ? G : 1);
+  if (cap < 1) cap = 1;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  return (int)s;
 }
 
 // out[g][c][j] = sum over the strips of group g of part[g*strips + s][c][j].  Workgroup = COLS columns x (256 / COLS) strip
@@ -482,10 +546,9 @@ extern "C" int du_norm_act_fwd(int dtype, const void* x, int64_t ldx, void* y, i
   hipStream_t st = (hipStream_t)stream;
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (G <= 0 || P <= 0 || C % v || ldx % v || ldy % v) return DU_ERR_BAD_ARG;
-  long total = (long)G * P * (C / v);
-  dim3 grid(grid_for(total)), block(256);
-  if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, mean, rstd, w, b, P, C, act, total);
-  else if (dtype == DU_F32) hipLaunchKernelGGL(norm_act_fwd_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (float*)y, ldy, mean, rstd, w, b, P, C, act, total);
+  dim3 grid(norm_slots(G, P, C, v), G), block(256);
+  if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, mean, rstd, w, b, (long)P, C, act);
+  else if (dtype == DU_F32) hipLaunchKernelGGL(norm_act_fwd_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (float*)y, ldy, mean, rstd, w, b, (long)P, C, act);
   else return DU_ERR_BAD_ARG;
   return du_check_launch();
 }
@@ -512,11 +575,10 @@ extern "C" int du_norm_act_bwd_dx(int dtype, const void* x, int64_t ldx, const v
   hipStream_t st = (hipStream_t)stream;
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (G <= 0 || P <= 0 || C % v || ldx % v || lddy % v || lddx % v) return DU_ERR_BAD_ARG;
-  long total = (long)G * P * (C / v);
-  dim3 grid(grid_for(total)), block(256);
+  dim3 grid(norm_slots(G, P, C, v), G), block(256);
   const float inv = count > 0 ? 1.0f / count : 0.f;
-  if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_bwd_dx_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, mean, rstd, w, b, bsums, P, C, act, inv, use_batch_stats, total);
-  else if (dtype == DU_F32) hipLaunchKernelGGL(norm_act_bwd_dx_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, (float*)dx, lddx, mean, rstd, w, b, bsums, P, C, act, inv, use_batch_stats, total);
+  if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_bwd_dx_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, mean, rstd, w, b, bsums, (long)P, C, act, inv, use_batch_stats);
+  else if (dtype == DU_F32) hipLaunchKernelGGL(norm_act_bwd_dx_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, (float*)dx, lddx, mean, rstd, w, b, bsums, (long)P, C, act, inv, use_batch_stats);
   else return DU_ERR_BAD_ARG;
   return du_check_launch();
 }
