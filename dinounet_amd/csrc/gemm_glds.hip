@@ -13,8 +13,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_EL = BM * BK;          // elements per operand tile (16 KB)
+constexpr int BM = 128, BN = 128;
 constexpr int STG_LD = BN + 4;
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -39,8 +38,15 @@ template <> struct Out4g<bf16_t> {
   }
 };
 
-template <typename TC>
+// BK = 64, NST = 2: two buffers, vmcnt(0) + barrier per K step (64 KB LDS, 2 workgroups / CU).
+// BK = 32, NST = 3: three buffers, tile t+2 is issued while tile t is multiplied and only tile t+1 is waited for (counted
+//                   vmcnt, raw s_barrier: a plain __syncthreads() would drain the DMA queue); 48 KB LDS, 3 workgroups / CU.
+template <typename TC, int BK, int NST>
 __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
+  constexpr int TILE_EL = BM * BK;        // elements per operand tile
+  constexpr int CH = BK / 8;              // 16-byte chunks per tile row
+  constexpr int RPW = 64 / CH;            // tile rows covered by one wave-level global_load_lds (64 lanes x 16 B)
+  constexpr int ROUNDS = BM / (4 * RPW);  // staging rounds per operand
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* smem = (bf16_t*)smem_raw;       // buffer b: A tile at b*2*TILE_EL, B tile at b*2*TILE_EL + TILE_EL
 
@@ -58,13 +64,15 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
   const bf16_t* Ag = (const bf16_t*)P.a.p + (long)batch * P.a.bstride;
   const bf16_t* Bg = (const bf16_t*)P.b.p + (long)batch * P.b.bstride;
 
-  // per-lane source rows of the 4 staging rounds: round r covers tile rows r*32 + wave*8 + lane/8, physical chunk lane%8
-  const bf16_t* asrc[4];
-  const bf16_t* bsrc[4];
+  // per-lane source rows of the staging rounds: round r covers tile rows (r*4 + wave)*RPW + lane/CH, physical chunk lane%CH.
+  // Swizzle: physical chunk pc of row r holds logical chunk pc ^ swz(r); swz spreads the 16 rows of a ds_read_b128 lane group over
+  // the 16 16-byte slots of a 256-byte bank row (BK = 64: 2 rows per bank row, BK = 32: 4 rows per bank row).
+  const bf16_t* asrc[ROUNDS];
+  const bf16_t* bsrc[ROUNDS];
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int row = r * 32 + wave * 8 + (lane >> 3);
-    const int lc = (lane & 7) ^ ((row >> 1) & 7);
+  for (int r = 0; r < ROUNDS; r++) {
+    const int row = (r * 4 + wave) * RPW + lane / CH;
+    const int lc = (lane % CH) ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
     int ma = m0 + row; if (ma > P.M - 1) ma = P.M - 1;
     int nb = n0 + row; if (nb > P.N - 1) nb = P.N - 1;
     asrc[r] = Ag + (long)ma * P.a.ld + lc * 8;
@@ -74,8 +82,8 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
     bf16_t* At = smem + buf * 2 * TILE_EL;
     bf16_t* Bt = At + TILE_EL;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int rowbase = r * 32 + wave * 8;           // wave-uniform LDS destination (lane l lands at + l * 16 B)
+    for (int r = 0; r < ROUNDS; r++) {
+      const int rowbase = (r * 4 + wave) * RPW;        // wave-uniform LDS destination (lane l lands at + l * 16 B)
       __builtin_amdgcn_global_load_lds((gbl_void*)(asrc[r] + kt * BK), (lds_void*)(At + rowbase * BK), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_void*)(bsrc[r] + kt * BK), (lds_void*)(Bt + rowbase * BK), 16, 0, 0);
     }
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
   // fragment of the 32-row block at tile row i0, k-step kk: lane l <-> row i0 + (l & 31), logical chunk kk*2 + (l >> 5)
   auto frag = [&](const bf16_t* T, int i0, int kk) -> bf16x8 {
     const int row = i0 + (lane & 31);
-    const int pc = (kk * 2 + (lane >> 5)) ^ ((row >> 1) & 7);
+    const int pc = (kk * 2 + (lane >> 5)) ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
     return *(const bf16x8*)(T + row * BK + pc * 8);
   };
 
@@ -96,13 +104,8 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int nk = P.K / BK;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of tile 0 has landed (this wave's share); barrier = everyone's
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt++) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const bf16_t* Ac = smem + cur * 2 * TILE_EL;
+  auto compute = [&](int buf) {
+    const bf16_t* Ac = smem + buf * 2 * TILE_EL;
     const bf16_t* Bc = Ac + TILE_EL;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; kk++) {
@@ -116,7 +119,36 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  if constexpr (NST == 2) {
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of tile 0 has landed (this wave's share); barrier = everyone's
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+      compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // 3-stage ring: ROUNDS*2 DMA instructions per tile per thread; "vmcnt(ROUNDS*2)" = everything but the newest tile has landed
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ROUNDS * 2) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kt = 0; kt < nk; kt++) {
+      int nxt2 = cur + 2; if (nxt2 >= 3) nxt2 -= 3;
+      if (kt + 2 < nk) stage(nxt2, kt + 2);      // buffer last read in step kt-1 (everyone passed that step's barrier)
+      compute(cur);
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ROUNDS * 2) : "memory");   // tile kt+1 landed, kt+2 may be in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = cur + 1; if (cur >= 3) cur -= 3;
+    }
     __syncthreads();
   }
 
@@ -179,14 +211,14 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
   }
 }
 
-template <typename TC>
+template <typename TC, int BK, int NST>
 int launch(const du_gemm_args& a, hipStream_t st) {
-  constexpr int MAIN_BYTES = 2 * 2 * TILE_EL * 2;      // 64 KB
+  constexpr int MAIN_BYTES = NST * 2 * BM * BK * 2;    // 64 KB (BK 64, 2 stages) / 48 KB (BK 32, 3 stages)
   constexpr int STG_BYTES = 64 * STG_LD * 4;
   constexpr int LDS_BYTES = MAIN_BYTES > STG_BYTES ? MAIN_BYTES : STG_BYTES;
   GemmParams P = make_params(a, DU_PLAIN_ROW, DU_PLAIN_ROW, BM, BN, BK);
   dim3 grid(((a.M + BM - 1) / BM) * P.tiles_n, a.batch < 1 ? 1 : a.batch);
-  auto kfn = gemm_nt_glds_kernel<TC>;
+  auto kfn = gemm_nt_glds_kernel<TC, BK, NST>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return DU_ERR_LAUNCH;
@@ -201,9 +233,17 @@ int launch(const du_gemm_args& a, hipStream_t st) {
 // returns DU_ERR_UNSUPPORTED when the shape / mode is not served by this kernel (caller falls back to gemm_bf16.hip)
 int du_gemm_nt_glds(const du_gemm_args& a, hipStream_t st) {
   if (a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.dtype != DU_BF16) return DU_ERR_UNSUPPORTED;
-  if (a.K % BK || a.split_k > 1 || a.N < 96 || a.M < 64) return DU_ERR_UNSUPPORTED;
+  if (a.K % 64 || a.split_k > 1 || a.N < 96 || a.M < 64) return DU_ERR_UNSUPPORTED;
   static const bool off = getenv("DU_GEMM_NO_GLDS") != nullptr;   // debugging / A-B aid
   if (off) return DU_ERR_UNSUPPORTED;
-  if (a.out_dtype == DU_BF16) return launch<bf16_t>(a, st);
-  return launch<float>(a, st);
+  static const char* var = getenv("DU_GLDS_VARIANT");             // "3": force the 3-stage BK=32 ring, "2": force the 2-stage BK=64 kernel
+  // measured (tools/gemm_bench.py): the 3-stage BK=32 ring wins for short contractions (K <= 512: +8..20 %, more workgroups per
+  // CU and a deeper DMA queue), the 2-stage BK=64 kernel for K >= 1024 (fewer barriers per flop)
+  const bool ring = var ? var[0] == '3' : a.K <= 512;
+  if (ring) {
+    if (a.out_dtype == DU_BF16) return launch<bf16_t, 32, 3>(a, st);
+    return launch<float, 32, 3>(a, st);
+  }
+  if (a.out_dtype == DU_BF16) return launch<bf16_t, 64, 2>(a, st);
+  return launch<float, 64, 2>(a, st);
 }

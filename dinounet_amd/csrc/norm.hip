@@ -121,6 +121,51 @@ static inline int pick_strip(int G, long P, int C, int vec) {
 template <typename T, int KIND>
 struct StatOp;
 
+// Sum the per-thread partials a[V], b[V] over the pixel lanes of a workgroup (thread = tp * cvb + tcv).  When several pixel lanes
+// share a wave (cvb < 64, power of two) they are first combined with xor shuffles, so at most 4 values per channel reach LDS;
+// the first version let cvb*V threads walk np <= 64 LDS entries serially, which dominated the small-C statistics kernels.
+// emit(cv_local_channel_index j, sum_a, sum_b) is called by the threads holding final sums (tp == 0 lanes).
+template <int V, typename E>
+__device__ __forceinline__ void lane_reduce(float* a, float* b, int cvb, int np, int tp, int tcv, float (*red)[256 * V], bool valid, E emit) {
+  const bool pow2 = (cvb & (cvb - 1)) == 0;
+  if (pow2 && cvb < 64) {
+    // lanes of one wave: tp spans 64 / cvb values; xor offsets cvb, 2 cvb, ... < 64 stay inside the wave
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      for (int o = cvb; o < 64; o <<= 1) { a[j] += __shfl_xor(a[j], o, 64); b[j] += __shfl_xor(b[j], o, 64); }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < cvb) {
+#pragma unroll
+      for (int j = 0; j < V; j++) { red[0][(wave * cvb + lane) * V + j] = a[j]; red[1][(wave * cvb + lane) * V + j] = b[j]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < cvb && valid) {
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { sa += red[0][(q * cvb + threadIdx.x) * V + j]; sb += red[1][(q * cvb + threadIdx.x) * V + j]; }
+        emit(j, sa, sb);
+      }
+    }
+    __syncthreads();
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < V; j++) { red[0][threadIdx.x * V + j] = a[j]; red[1][threadIdx.x * V + j] = b[j]; }
+  __syncthreads();
+  if (tp == 0 && valid) {
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      float sa = 0.f, sb = 0.f;
+      for (int q = 0; q < np; q++) { sa += red[0][(q * cvb + tcv) * V + j]; sb += red[1][(q * cvb + tcv) * V + j]; }
+      emit(j, sa, sb);
+    }
+  }
+  __syncthreads();
+}
+
 // generic strip reducer: F(xvec, dyvec, g, c0) -> (a[VEC], b[VEC]) accumulated per channel, then written with atomics
 template <typename T, typename F>
 __device__ __forceinline__ void strip_reduce(int G, long P, int C, int STRIP, float* out /*[G][C][2]*/, float* part, F f) {
@@ -144,24 +189,15 @@ __device__ __forceinline__ void strip_reduce(int G, long P, int C, int STRIP, fl
 #pragma unroll 4
       for (long p = p0 + tp; p < p1; p += np) f((long)g * P + p, g, cv * V, a, b);
     }
-#pragma unroll
-    for (int j = 0; j < V; j++) { red[0][threadIdx.x * V + j] = a[j]; red[1][threadIdx.x * V + j] = b[j]; }
-    __syncthreads();
-    if (tp == 0 && cv < cv_total) {
-#pragma unroll
-      for (int j = 0; j < V; j++) {
-        float sa = 0.f, sb = 0.f;
-        for (int q = 0; q < np; q++) { sa += red[0][(q * cvb + tcv) * V + j]; sb += red[1][(q * cvb + tcv) * V + j]; }
-        if (part) {   // two-stage: this strip's partial goes to part[blockIdx.x][C][2]; finalize_kernel sums the strips
-          part[((long)blockIdx.x * C + cv * V + j) * 2 + 0] = sa;
-          part[((long)blockIdx.x * C + cv * V + j) * 2 + 1] = sb;
-        } else {
-          atomic_add_f32(out + ((long)g * C + cv * V + j) * 2 + 0, sa);
-          atomic_add_f32(out + ((long)g * C + cv * V + j) * 2 + 1, sb);
-        }
+    lane_reduce<V>(a, b, cvb, np, tp, tcv, red, cv < cv_total, [&](int j, float sa, float sb) {
+      if (part) {   // two-stage: this strip's partial goes to part[blockIdx.x][C][2]; finalize_kernel sums the strips
+        part[((long)blockIdx.x * C + cv * V + j) * 2 + 0] = sa;
+        part[((long)blockIdx.x * C + cv * V + j) * 2 + 1] = sb;
+      } else {
+        atomic_add_f32(out + ((long)g * C + cv * V + j) * 2 + 0, sa);
+        atomic_add_f32(out + ((long)g * C + cv * V + j) * 2 + 1, sb);
       }
-    }
-    __syncthreads();
+    });
   }
 }
 
@@ -283,24 +319,15 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stats_kernel(const T* __rest
         }
       }
     }
-#pragma unroll
-    for (int j = 0; j < V; j++) { red[0][threadIdx.x * V + j] = a[j]; red[1][threadIdx.x * V + j] = bb[j]; }
-    __syncthreads();
-    if (tp == 0 && cv < cv_total) {
-#pragma unroll
-      for (int j = 0; j < V; j++) {
-        float sa = 0.f, sb = 0.f;
-        for (int q = 0; q < np; q++) { sa += red[0][(q * cvb + tcv) * V + j]; sb += red[1][(q * cvb + tcv) * V + j]; }
-        if (part) {
-          part[((long)blockIdx.x * C + cv * V + j) * 2 + 0] = sa;
-          part[((long)blockIdx.x * C + cv * V + j) * 2 + 1] = sb;
-        } else {
-          atomic_add_f32(bsums + ((long)g * C + cv * V + j) * 2 + 0, sa);
-          atomic_add_f32(bsums + ((long)g * C + cv * V + j) * 2 + 1, sb);
-        }
+    lane_reduce<V>(a, bb, cvb, np, tp, tcv, red, cv < cv_total, [&](int j, float sa, float sb) {
+      if (part) {
+        part[((long)blockIdx.x * C + cv * V + j) * 2 + 0] = sa;
+        part[((long)blockIdx.x * C + cv * V + j) * 2 + 1] = sb;
+      } else {
+        atomic_add_f32(bsums + ((long)g * C + cv * V + j) * 2 + 0, sa);
+        atomic_add_f32(bsums + ((long)g * C + cv * V + j) * 2 + 1, sb);
       }
-    }
-    __syncthreads();
+    });
   }
 }
 

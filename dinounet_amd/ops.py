@@ -9,6 +9,7 @@ parity mode); statistics, MSDA locations/weights, weight gradients and the ViT r
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -189,8 +190,15 @@ def mm_dgrad(dy, w, out=None):
     return out
 
 
-def _split_for(tiles, kdim):
-    s = max(1, min(1024 // max(tiles, 1), kdim // 256))
+# split-K of the weight gradients: workgroups aimed for / minimum contraction rows per split.  Swept on the dinounet_l shapes
+# (tools/gemm_bench.py, profiles/r01_splitk_sweep.txt): 512 x 1024 for the linear layers (2 workgroups per CU, fewer fp32 atomics),
+# 1024 x 1024 for the convolutions (their M = Cout <= 128 tiles are small).
+_SPLIT_TARGET = int(os.environ.get("DU_SPLIT_TARGET", "0"))
+_SPLIT_MINK = int(os.environ.get("DU_SPLIT_MINK", "1024"))
+
+
+def _split_for(tiles, kdim, target=512):
+    s = max(1, min((_SPLIT_TARGET or target) // max(tiles, 1), kdim // _SPLIT_MINK))
     return max(1, s)
 
 
@@ -295,7 +303,7 @@ def conv_wgrad(x, dy, KH, KW, stride, pad, x2=None):
     tiles = ((Cout + 127) // 128) * ((Ncol + 127) // 128)
     gemm_raw(dtype=_code(x.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=IM2COL_COL, M=Cout, N=Ncol, K=npix,
              A=dy.data_ptr(), lda=lddy, B=x.data_ptr(), ldb=ld, Cmat=out.data_ptr(), ldc=Ncol,
-             split_k=_split_for(tiles, npix), geom=g)
+             split_k=_split_for(tiles, npix, 1024), geom=g)
     return out
 
 
@@ -422,7 +430,7 @@ class _ConvT2x2(torch.autograd.Function):
             tiles = ((Cin + 127) // 128) * ((4 * Cout + 127) // 128)
             gemm_raw(dtype=_code(dy.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=IM2COL_COL, M=Cin, N=4 * Cout,
                      K=npix, A=x.data_ptr(), lda=ld, B=dy.data_ptr(), ldb=lddy, Cmat=gw.data_ptr(), ldc=4 * Cout,
-                     split_k=_split_for(tiles, npix), geom=g)
+                     split_k=_split_for(tiles, npix, 1024), geom=g)
             dw = gw.view(Cin, 2, 2, Cout).permute(0, 3, 1, 2).contiguous()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             Bo, Ho, Wo, Co, ldo = _nhwc(dy)
