@@ -1,0 +1,251 @@
+// LDS-tiled direct 3x3 convolution (stride 1, pad 1) on NHWC bf16 for the U-Net decoder / FAPM / SPM-stem convolutions
+// (dinounet_training.py:581-592 via StackedConvBlocks, dinov3_adapter.py:243-249) and -- with spatially flipped, transposed
+// weights -- their data gradients.
+//
+// Why not the implicit-GEMM kernel (gemm_bf16.hip, IM2COL_ROW): it re-gathers every input pixel once per filter tap (9x the L1/TA
+// traffic) and, with Cout = 32/64, has only 4-8 MFMAs of work per barrier.  Here a workgroup stages the (8+2) x (16+2) input halo
+// of an 8 x 16 output tile ONCE per channel chunk and the 9 taps read their MFMA A fragments from it at shifted pixel addresses;
+// the chunk's weights for all 9 taps sit in LDS too (for Cin <= 64 they are loaded once per workgroup: workgroups are persistent
+// and walk tiles), so one staging step feeds 9 * CK/16 * Cout/32 MFMAs per wave.  The next halo (and weight chunk) is prefetched
+// into registers while the current one is multiplied.  The fp32 tile goes through LDS so every output pixel is written as one
+// contiguous Cout-channel row; the per-channel sums / sums of squares of the tile (InstanceNorm / BatchNorm statistics of the
+// following norm layer) fall out of the same staged tile and are written as partials (no second pass over the output).
+//
+// Roofline: HBM for Cout <= 64 at 256^2 / 512^2 (algorithmic bytes = (Cin + Cout) * 2 per pixel), MFMA for the 128-channel layers.
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;              // output tile (128 pixels = 4 waves x 32)
+constexpr int HW_ = (TH + 2) * (TW + 2);    // 180 halo pixels
+constexpr int HXW = TW + 2;
+
+struct HaloParams {
+  const bf16_t* x; long ldx;                // channels [0, C1)
+  const bf16_t* x2; long ldx2;              // channels [C1, Cin) (fused concat) or null
+  int C1, Cin, Cout;
+  int B, H, W;
+  const bf16_t* w;                          // [Cout][9 * Cin], (tap, ci) column order
+  const float* bias;                        // [Cout] or null
+  bf16_t* y; long ldy;
+  float* stats_part;                        // [ntiles][Cout][2] partial (sum, sum of squares) or null
+  int tilesX, tilesY, ntiles;
+};
+
+template <int CK, int TN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
+  constexpr int COUT = TN * 32;
+  constexpr int LD = CK + 8;                            // LDS pixel / weight-row pitch (bf16): 16-byte padded
+  constexpr int CV = CK / 8;                            // 16-byte vectors per pixel per chunk
+  constexpr int HV = (HW_ * CV + 255) / 256;            // halo vectors per thread
+  constexpr int WV = (9 * COUT * CV + 255) / 256;       // weight vectors per thread
+  constexpr int W_EL = 9 * COUT * LD, H_EL = HW_ * LD;
+  constexpr int STG_LD = COUT + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Ws = (bf16_t*)smem_raw;                       // [9][COUT][LD]
+  bf16_t* Hs = Ws + W_EL;                               // [180][LD]
+  const int nch = P.Cin / CK;
+  // fp32 staging tile [128][COUT + 4]: behind the halo when the weights stay resident (one chunk), else over the weights
+  float* stg = (nch == 1) ? (float*)(smem_raw + (size_t)(W_EL + H_EL) * 2) : (float*)smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5;
+  const int py = 2 * wave + ((lane & 31) >> 4), px = lane & 15;   // this lane's output pixel inside the tile (A-fragment row)
+
+  uint4 hreg[HV], wreg[WV];
+  auto halo_load = [&](int tile, int ch) {
+    const int tx0 = (tile % P.tilesX) * TW;
+    const int t2 = tile / P.tilesX;
+    const int ty0 = (t2 % P.tilesY) * TH, b = t2 / P.tilesY;
+    const int c0 = ch * CK;
+    const bf16_t* src = P.x; long ld = P.ldx; int cofs = c0;
+    if (c0 >= P.C1) { src = P.x2; ld = P.ldx2; cofs = c0 - P.C1; }
+#pragma unroll
+    for (int i = 0; i < HV; i++) {
+      const int v = tid + i * 256;
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (v < HW_ * CV) {
+        const int pix = v / CV, cv = v % CV;
+        const int gy = ty0 + pix / HXW - 1, gx = tx0 + pix % HXW - 1;
+        if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W)
+          r = *(const uint4*)(src + (((long)b * P.H + gy) * P.W + gx) * ld + cofs + cv * 8);
+      }
+      hreg[i] = r;
+    }
+  };
+  auto halo_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < HV; i++) {
+      const int v = tid + i * 256;
+      if (v < HW_ * CV) *(uint4*)(Hs + (v / CV) * LD + (v % CV) * 8) = hreg[i];
+    }
+  };
+  auto w_load = [&](int ch) {
+#pragma unroll
+    for (int i = 0; i < WV; i++) {
+      const int v = tid + i * 256;
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (v < 9 * COUT * CV) {
+        const int cv = v % CV, row = v / CV;            // row = tap * COUT + co
+        const int tap = row / COUT, co = row % COUT;
+        r = *(const uint4*)(P.w + (long)co * 9 * P.Cin + (long)tap * P.Cin + ch * CK + cv * 8);
+      }
+      wreg[i] = r;
+    }
+  };
+  auto w_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < WV; i++) {
+      const int v = tid + i * 256;
+      if (v < 9 * COUT * CV) *(uint4*)(Ws + (v / CV) * LD + (v % CV) * 8) = wreg[i];
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= P.ntiles) return;
+  w_load(0);
+  halo_load(tile, 0);
+  bool w_pending = true;
+  while (tile < P.ntiles) {
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    for (int ch = 0; ch < nch; ch++) {
+      // ---- install the staged chunk, prefetch the next one ----
+      halo_store();
+      if (w_pending) w_store();
+      __syncthreads();
+      {
+        int ntile = tile, nchk = ch + 1;
+        if (nchk == nch) { nchk = 0; ntile = tile + gridDim.x; }
+        if (ntile < P.ntiles) {
+          halo_load(ntile, nchk);
+          if (nch > 1) w_load(nchk);
+        }
+        w_pending = nch > 1;
+      }
+      // ---- 9 taps x CK/16 k-steps ----
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const int dy = tap / 3, dx = tap % 3;
+        const bf16_t* arow = Hs + ((py + dy) * HXW + px + dx) * LD + half * 8;
+        const bf16_t* brow = Ws + (tap * COUT + (lane & 31)) * LD + half * 8;
+#pragma unroll
+        for (int kk = 0; kk < CK / 16; kk++) {
+          const bf16x8 fa = *(const bf16x8*)(arow + kk * 16);
+#pragma unroll
+          for (int j = 0; j < TN; j++) {
+            const bf16x8 fb = *(const bf16x8*)(brow + j * 32 * LD + kk * 16);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();       // everyone is done with Hs / Ws before the next chunk (or the staging tile) overwrites them
+    }
+    // ---- epilogue: stage the 128 x COUT fp32 tile, add bias, row stores, per-channel statistics ----
+    // accumulator register r of lane l: output pixel (wave*32 + (r&3) + 8*(r>>2) + 4*(l>>5)), channel j*32 + (l&31)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const float bv = P.bias ? P.bias[j * 32 + (lane & 31)] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        stg[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * STG_LD + j * 32 + (lane & 31)] = acc[j][r] + bv;
+    }
+    __syncthreads();
+    {
+      const int tx0 = (tile % P.tilesX) * TW;
+      const int t2 = tile / P.tilesX;
+      const int ty0 = (t2 % P.tilesY) * TH, b = t2 / P.tilesY;
+      constexpr int C8 = COUT / 8;                     // 16-byte channel vectors per output pixel (4 / 8 / 16)
+      // thread = (pixel, channel vector); 256 % C8 == 0, so a thread keeps the same channel vector for all its pixels and can
+      // accumulate that vector's statistics (of the bf16-rounded values the norm layer will read) in registers on the way
+      float s1[8], s2[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) { s1[e] = 0.f; s2[e] = 0.f; }
+      const int c8 = tid % C8;
+      for (int v = tid; v < 128 * C8; v += 256) {
+        const int p = v / C8;
+        // tile pixel p: wave = p / 32, (p % 32) / 16 = row inside the wave's 2 rows, p % 16 = x
+        const int oy = ty0 + 2 * (p >> 5) + ((p & 31) >> 4), ox = tx0 + (p & 15);
+        const float4 a0 = *(const float4*)(stg + p * STG_LD + c8 * 8);
+        const float4 a1 = *(const float4*)(stg + p * STG_LD + c8 * 8 + 4);
+        const float f[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        Vec16<bf16_t> o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          o.v[e] = (bf16_t)f[e];
+          const float vq = (float)o.v[e];
+          s1[e] += vq; s2[e] += vq * vq;
+        }
+        *(uint4*)(P.y + (((long)b * P.H + oy) * P.W + ox) * P.ldy + c8 * 8) = as_u4(o);
+      }
+      if (P.stats_part) {
+        float* red = stg + 128 * STG_LD;               // [4 waves][COUT][2]
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          for (int o2 = C8; o2 < 64; o2 <<= 1) { s1[e] += __shfl_xor(s1[e], o2, 64); s2[e] += __shfl_xor(s2[e], o2, 64); }
+        if (lane < C8) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            red[((wave * COUT) + lane * 8 + e) * 2] = s1[e];
+            red[((wave * COUT) + lane * 8 + e) * 2 + 1] = s2[e];
+          }
+        }
+        __syncthreads();
+        if (tid < COUT) {
+          float t1 = 0.f, t2s = 0.f;
+#pragma unroll
+          for (int q2 = 0; q2 < 4; q2++) { t1 += red[(q2 * COUT + tid) * 2]; t2s += red[(q2 * COUT + tid) * 2 + 1]; }
+          P.stats_part[((long)tile * COUT + tid) * 2] = t1;
+          P.stats_part[((long)tile * COUT + tid) * 2 + 1] = t2s;
+        }
+      }
+    }
+    __syncthreads();
+    tile += gridDim.x;
+  }
+}
+
+template <int CK, int TN>
+int launch(const HaloParams& P, hipStream_t st) {
+  constexpr int COUT = TN * 32, LD = CK + 8;
+  const int nch = P.Cin / CK;
+  const size_t main_bytes = (size_t)(9 * COUT * LD + HW_ * LD) * 2;
+  const size_t stg_bytes = (size_t)128 * (COUT + 4) * 4 + (size_t)4 * COUT * 2 * 4;   // fp32 tile + statistics scratch [4][COUT][2]
+  const size_t lds = nch == 1 ? main_bytes + stg_bytes : (main_bytes > stg_bytes ? main_bytes : stg_bytes);
+  if (lds > 160 * 1024) return DU_ERR_UNSUPPORTED;
+  auto kfn = conv3x3_halo_kernel<CK, TN>;
+  if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DU_ERR_LAUNCH;
+  const int per_cu = (int)((160 * 1024) / lds);
+  int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+  if (grid > P.ntiles) grid = P.ntiles;
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, P);
+  return du_check_launch();
+}
+
+}  // namespace
+
+// x (B,H,W,C1) [+ x2 (B,H,W,Cin-C1)] NHWC bf16 with pixel strides ldx/ldx2; w bf16 [Cout][9*Cin] in (tap, ci) column order;
+// y (B,H,W,Cout) bf16, pixel stride ldy.  stats_part (nullable): (B * (H/8) * (W/16), Cout, 2) fp32 per-tile partial sums.
+// Returns DU_ERR_UNSUPPORTED for shapes this kernel does not serve (caller falls back to the implicit-GEMM path).
+extern "C" int du_conv3x3_halo(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int C1, int Cin, int Cout, int B, int H, int W,
+                               const void* w, const float* bias, void* y, int64_t ldy, float* stats_part, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DU_ERR_BAD_ARG;
+  if (H % TH || W % TW || ldx % 8 || ldy % 8 || (x2 && (ldx2 % 8 || C1 % 8)) || Cin % 8) return DU_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)x2)) & 15) return DU_ERR_UNSUPPORTED;
+  if (!x2) C1 = Cin;
+  HaloParams P{};
+  P.x = (const bf16_t*)x; P.ldx = ldx; P.x2 = (const bf16_t*)x2; P.ldx2 = ldx2; P.C1 = C1; P.Cin = Cin; P.Cout = Cout;
+  P.B = B; P.H = H; P.W = W; P.w = (const bf16_t*)w; P.bias = bias; P.y = (bf16_t*)y; P.ldy = ldy; P.stats_part = stats_part;
+  P.tilesX = W / TW; P.tilesY = H / TH; P.ntiles = B * P.tilesX * P.tilesY;
+  // channel chunk: 64 when both sources split on 64-channel boundaries, else 32
+  const bool c64 = Cin % 64 == 0 && C1 % 64 == 0;
+  const bool c32 = Cin % 32 == 0 && C1 % 32 == 0;
+  if (Cout == 32) { if (c64) return launch<64, 1>(P, st); if (c32) return launch<32, 1>(P, st); }
+  if (Cout == 64) { if (c64) return launch<64, 2>(P, st); if (c32) return launch<32, 2>(P, st); }
+  if (Cout == 128) { if (c32) return launch<32, 4>(P, st); }
+  return DU_ERR_UNSUPPORTED;
+}

@@ -502,6 +502,19 @@ extern "C" int du_layernorm_fwd(int in_dtype, int out_dtype, const void* x, int6
   return DU_ERR_BAD_ARG;
 }
 
+extern "C" int du_strip_finalize(const float* part, float* out, int G, int strips, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!part || !out || G <= 0 || strips <= 0 || C <= 0) return DU_ERR_BAD_ARG;
+  if ((long)G * C * 2 >= 4096) {
+    const int chunks = (C * 2 + 31) / 32;
+    hipLaunchKernelGGL(finalize_kernel<32>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, part, out, G, strips, C * 2);
+  } else {
+    const int chunks = (C * 2 + 3) / 4;
+    hipLaunchKernelGGL(finalize_kernel<4>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, part, out, G, strips, C * 2);
+  }
+  return du_check_launch();
+}
+
 extern "C" int64_t du_reduce_ws_elems(int dtype, int G, int64_t P, int C) {
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (G <= 0 || P <= 0 || C <= 0 || C % v) return 0;

@@ -199,8 +199,8 @@ class SpatialPriorModule(nn.Module):
         w = conv.weight
         if w.shape[1] % 8:                                   # 3-channel stem: image is zero-padded to 8 channels
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 8 - w.shape[1] % 8))
-        y = ops.conv2d(x, w, None, stride=stride, pad=1)
-        return bn_act(y, bn, ACT_RELU, self.training, group)
+        y, st = ops.conv2d_stats(x, w, None, stride=stride, pad=1)
+        return bn_act(y, bn, ACT_RELU, self.training, group, st)
 
     def forward(self, x8, level_embed, group=None):
         """x8: NHWC image zero-padded to 8 channels.  Returns c1 (B,H/4,W/4,D) and token tensors c2,c3,c4 with the level
@@ -220,11 +220,11 @@ class SpatialPriorModule(nn.Module):
         return c1, tok(c2), tok(c3), tok(c4)
 
 
-def bn_act(x, bn, act, training, group):
+def bn_act(x, bn, act, training, group, stats_part=None):
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return ops.norm_act(x, bn.weight, bn.bias, "bn", act, bn.eps, training, bn.running_mean, bn.running_var,
-                        bn.momentum if bn.momentum is not None else 0.1, group)
+                        bn.momentum if bn.momentum is not None else 0.1, group, stats_part=stats_part if training else None)
 
 
 def get_reference_points(spatial_shapes, device):

@@ -53,15 +53,16 @@ def _act_code(nonlin, nonlin_kwargs):
     raise NotImplementedError(f"activation {nonlin}")
 
 
-def _norm_act(x, norm_mod, act, training):
-    """InstanceNorm2d (plans default) or BatchNorm2d container -> fused norm+activation kernel."""
+def _norm_act(x, norm_mod, act, training, stats_part=None):
+    """InstanceNorm2d (plans default) or BatchNorm2d container -> fused norm+activation kernel.  stats_part: partial channel
+    statistics emitted by the producing convolution (ops.conv2d_stats), saves the statistics pass."""
     if isinstance(norm_mod, nn.InstanceNorm2d):
         if not norm_mod.affine:
             raise NotImplementedError("non-affine InstanceNorm")
-        return ops.norm_act(x, norm_mod.weight, norm_mod.bias, "in", act, norm_mod.eps, True)
+        return ops.norm_act(x, norm_mod.weight, norm_mod.bias, "in", act, norm_mod.eps, True, stats_part=stats_part)
     if isinstance(norm_mod, nn.modules.batchnorm._BatchNorm):
         return ops.norm_act(x, norm_mod.weight, norm_mod.bias, "bn", act, norm_mod.eps, training, norm_mod.running_mean,
-                            norm_mod.running_var, norm_mod.momentum or 0.1, None)
+                            norm_mod.running_var, norm_mod.momentum or 0.1, None, stats_part=stats_part if training else None)
     raise NotImplementedError(f"norm {type(norm_mod)}")
 
 
@@ -238,9 +239,9 @@ class ConvDropoutNormReLU(nn.Module):
 
     def forward(self, x, x2=None):
         k, s = self.conv.kernel_size[0], self.conv.stride[0]
-        y = ops.conv2d(x, self.conv.weight, self.conv.bias, stride=s, pad=(k - 1) // 2, x2=x2)
+        y, st = ops.conv2d_stats(x, self.conv.weight, self.conv.bias, stride=s, pad=(k - 1) // 2, x2=x2)
         if hasattr(self, "norm"):
-            return _norm_act(y, self.norm, self._act, self.training)
+            return _norm_act(y, self.norm, self._act, self.training, st)
         raise NotImplementedError("conv block without norm")
 
 

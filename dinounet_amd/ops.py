@@ -261,8 +261,51 @@ def pack_conv_weight_dgrad(w, dt):
     return w.permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(dt).contiguous()
 
 
+def pack_conv_weight_dgrad_flipped(w, dt):
+    """(Cout,Cin,3,3) -> (Cin, 9*Cout): the stride-1 data gradient is the 3x3 convolution of dY with the spatially flipped,
+    transposed filter, [ci][(ky,kx,co)] = w[co][ci][2-ky][2-kx]."""
+    return w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(dt).contiguous()
+
+
+def conv3x3_halo(x, wp, bias, x2=None, want_stats=False):
+    """LDS-tiled direct 3x3 / stride 1 / pad 1 convolution (du_conv3x3_halo).  Returns (y, stats_partial or None), or None when the
+    kernel does not serve the shape (caller falls back to the implicit GEMM)."""
+    if x.dtype != torch.bfloat16:
+        return None
+    B, H, W, C1, ld = _nhwc(x)
+    Cout, Kc, ldb = _rows2d(wp)
+    Cin = Kc // 9
+    if H % 8 or W % 16 or Cout not in (32, 64, 128) or ldb != Kc or Cin % 32:
+        return None
+    ld2, p2 = 0, None
+    if x2 is not None:
+        B2, H2, W2, C2, ld2 = _nhwc(x2)
+        if (B2, H2, W2) != (B, H, W) or C1 + C2 != Cin or C1 % 32:
+            return None
+        p2 = _p(x2)
+    elif C1 != Cin:
+        return None
+    y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
+    # the epilogue statistics pay off from 64 output channels up (measured: +35 us on the 32-channel 512^2 layers, where the separate
+    # statistics pass costs ~30 us; -10 us on the 64/128-channel ones)
+    part = torch.empty((B * (H // 8) * (W // 16), Cout, 2), dtype=torch.float32, device=x.device) if (want_stats and Cout >= 64) else None
+    e0 = PROFILE.start() if PROFILE is not None else None
+    rc = _lib.lib().du_conv3x3_halo(_p(x), ld, p2, ld2, C1, Cin, Cout, B, H, W, _p(wp), _p(bias), _p(y), Cout, _p(part), _st())
+    if rc == -2:                                  # DU_ERR_UNSUPPORTED
+        return None
+    _lib.check(rc, "du_conv3x3_halo")
+    if PROFILE is not None:
+        PROFILE.stop("conv3x3_halo_kernel<bf16>" + (f" {H}x{W} {Cin}->{Cout}" if PROFILE.detail else ""), e0,
+                     2.0 * B * H * W * Cin * Cout * 9, 2.0 * B * H * W * (Cin + Cout))
+    return y, part
+
+
 def conv_fwd(x, wp, bias, KH, KW, stride, pad, x2=None, out=None, act=ACT_NONE):
     _req(x, wp)
+    if KH == 3 and KW == 3 and stride == 1 and pad == 1 and out is None and act == ACT_NONE:
+        r = conv3x3_halo(x, wp, bias, x2)
+        if r is not None:
+            return r[0]
     B, Hi, Wi, _, _ = _nhwc(x)
     Ho = (Hi + 2 * pad - KH) // stride + 1
     Wo = (Wi + 2 * pad - KW) // stride + 1
@@ -308,19 +351,31 @@ def conv_wgrad(x, dy, KH, KW, stride, pad, x2=None):
 
 
 class _Conv2d(torch.autograd.Function):
-    """Conv2d on NHWC, optional second input = fused channel concat (dinounet_training.py:614)."""
+    """Conv2d on NHWC, optional second input = fused channel concat (dinounet_training.py:614).  With want_stats the forward also
+    returns the per-tile partial channel statistics of the output (emitted by the LDS-tiled kernel's epilogue) so the following
+    InstanceNorm / BatchNorm needs no extra pass; None when the shape went through the implicit-GEMM path."""
 
     @staticmethod
-    def forward(ctx, x, x2, w, bias, stride, pad):
+    def forward(ctx, x, x2, w, bias, stride, pad, want_stats):
         KH, KW = w.shape[2], w.shape[3]
         wp = pack_conv_weight(w, x.dtype)
-        y = conv_fwd(x, wp, _f32(bias), KH, KW, stride, pad, x2)
+        part = None
+        r = None
+        if KH == 3 and KW == 3 and stride == 1 and pad == 1:
+            r = conv3x3_halo(x, wp, _f32(bias), x2, want_stats)
+        if r is not None:
+            y, part = r
+        else:
+            y = conv_fwd(x, wp, _f32(bias), KH, KW, stride, pad, x2)
         ctx.save_for_backward(x, x2, w)
         ctx.conf = (KH, KW, stride, pad, bias is not None)
-        return y
+        if part is None:
+            part = torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(part)
+        return y, part
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpart):
         x, x2, w = ctx.saved_tensors
         KH, KW, stride, pad, has_bias = ctx.conf
         dy = dy.contiguous()
@@ -328,22 +383,41 @@ class _Conv2d(torch.autograd.Function):
         dx = dx2 = dw = db = None
         need_dx = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
         if need_dx:
-            wd = pack_conv_weight_dgrad(w, dy.dtype)
-            dfull = conv_dgrad(dy, wd, KH, KW, stride, pad, Hi, Wi)
-            if x2 is None:
-                dx = dfull
-            else:
-                dx, dx2 = dfull[..., :C1], dfull[..., C1:]
+            done = False
+            if KH == 3 and KW == 3 and stride == 1 and pad == 1 and dy.dtype == torch.bfloat16:
+                wf = pack_conv_weight_dgrad_flipped(w, dy.dtype)          # (Cin_total, 9*Cout)
+                if x2 is None:
+                    r = conv3x3_halo(dy, wf, None)
+                    if r is not None:
+                        dx, done = r[0], True
+                else:
+                    r1 = conv3x3_halo(dy, wf[:C1], None)
+                    r2 = conv3x3_halo(dy, wf[C1:], None) if r1 is not None else None
+                    if r1 is not None and r2 is not None:
+                        dx, dx2, done = r1[0], r2[0], True
+            if not done:
+                wd = pack_conv_weight_dgrad(w, dy.dtype)
+                dfull = conv_dgrad(dy, wd, KH, KW, stride, pad, Hi, Wi)
+                if x2 is None:
+                    dx = dfull
+                else:
+                    dx, dx2 = dfull[..., :C1], dfull[..., C1:]
         if ctx.needs_input_grad[2]:
             g = conv_wgrad(x, dy, KH, KW, stride, pad, x2)
             dw = g.view(w.shape[0], KH, KW, w.shape[1]).permute(0, 3, 1, 2).contiguous()
         if has_bias and ctx.needs_input_grad[3]:
             db = colsum(dy.view(-1, dy.shape[-1]))
-        return dx, dx2, dw, db, None, None
+        return dx, dx2, dw, db, None, None, None
 
 
 def conv2d(x, w, bias=None, stride=1, pad=1, x2=None):
-    return _Conv2d.apply(x, x2, w, bias, stride, pad)
+    return _Conv2d.apply(x, x2, w, bias, stride, pad, False)[0]
+
+
+def conv2d_stats(x, w, bias=None, stride=1, pad=1, x2=None):
+    """conv2d that also hands back the output's partial channel statistics (or None) for norm_act(..., stats_part=...)."""
+    y, part = _Conv2d.apply(x, x2, w, bias, stride, pad, True)
+    return y, (part if part.numel() else None)
 
 
 class _Linear(torch.autograd.Function):
@@ -471,14 +545,21 @@ class _NormAct(torch.autograd.Function):
                dinov3_adapter.py:242,361) and running-stat update (momentum 0.1, unbiased var); eval -> running stats."""
 
     @staticmethod
-    def forward(ctx, x, w, b, kind, act, eps, training, running_mean, running_var, momentum, group):
+    def forward(ctx, x, w, b, kind, act, eps, training, running_mean, running_var, momentum, group, stats_part=None):
         B, H, W, Cc, ld = _nhwc(x)
         wf, bf = _f32(w), _f32(b)
         use_batch = (kind == "in") or training
         count = None
         if use_batch:
             G = B if kind == "in" else 1
-            sums, P = chan_stats(x, G)
+            if stats_part is not None:
+                # per-tile partials from the producing convolution's epilogue (tiles of one image are contiguous)
+                P = (B // G) * H * W
+                sums = torch.empty((G, Cc, 2), dtype=torch.float32, device=x.device)
+                _lib.check(_lib.lib().du_strip_finalize(_p(stats_part), _p(sums), G, stats_part.shape[0] // G, Cc, _st()),
+                           "du_strip_finalize")
+            else:
+                sums, P = chan_stats(x, G)
             count = float(P)
             if kind == "bn" and group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
                 sums = sums.clone()
@@ -522,12 +603,12 @@ class _NormAct(torch.autograd.Function):
         _lib.check(L.du_norm_act_bwd_dx(_code(x.dtype), _p(x), ld, _p(dy), Cc, _p(dx), Cc, _p(mean), _p(rstd), _p(wf), _p(bf),
                                         _p(bsr), G, P, Cc, act, float(count or 0.0), 1 if use_batch else 0, _st()),
                    "du_norm_act_bwd_dx")
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 def norm_act(x, w, b, kind, act=ACT_NONE, eps=1e-5, training=True, running_mean=None, running_var=None, momentum=0.1,
-             group=None):
-    return _NormAct.apply(x, w, b, kind, act, eps, training, running_mean, running_var, momentum, group)
+             group=None, stats_part=None):
+    return _NormAct.apply(x, w, b, kind, act, eps, training, running_mean, running_var, momentum, group, stats_part)
 
 
 def layernorm_raw(x2d, w, b, eps, out_dtype, want_stats=False):

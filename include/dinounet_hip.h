@@ -103,6 +103,17 @@ typedef struct {
 
 int du_gemm(const du_gemm_args* args, void* stream);
 
+/* ---- LDS-tiled direct 3x3 convolution (stride 1, pad 1), bf16 NHWC: decoder / FAPM / SPM-stem convs (dinounet_training.py:581-592,
+        dinov3_adapter.py:243-249) and, with flipped + transposed weights, their data gradients --------------------------------------- */
+/* x (B,H,W,C1) [+ x2 (B,H,W,Cin-C1): fused concat, nullable]; w bf16 [Cout][9*Cin] in (tap, ci) column order; y (B,H,W,Cout).
+   stats_part (nullable): (B*(H/8)*(W/16), Cout, 2) fp32 per-tile (sum, sum of squares) of the stored outputs, tiles of one image
+   contiguous -- feed to du_strip_finalize(G = B).  Returns DU_ERR_UNSUPPORTED for shapes it does not serve (H%8, W%16, Cout not in
+   {32,64,128}, channel counts not multiples of 32): the caller then uses du_gemm's implicit-GEMM path. */
+int du_conv3x3_halo(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int C1, int Cin, int Cout, int B, int H, int W,
+                    const void* w, const float* bias, void* y, int64_t ldy, float* stats_part, void* stream);
+/* out[g][c][j] = sum_s part[g*strips + s][c][j]: second stage of the column reductions, exposed for producers that emit partials */
+int du_strip_finalize(const float* part, float* out, int G, int strips, int C, void* stream);
+
 /* ---- ViT attention -------------------------------------------------------------------------- */
 /* qkv: (B, N, 3, H, Dh) as produced by the fused QKV GEMM.  Writes q (scaled by `qscale`), k, v as
    (B, H, Npad, Dh) (rows >= N untouched: the caller zero-fills once); RoPE (rotate-half form, fp32 math) is

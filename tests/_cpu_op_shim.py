@@ -61,11 +61,16 @@ def conv2d(x, w, bias=None, stride=1, pad=1, x2=None):
     return _nhwc(F.conv2d(_nchw(xin), w.to(x.dtype), None if bias is None else bias.to(x.dtype), stride, pad))
 
 
+def conv2d_stats(x, w, bias=None, stride=1, pad=1, x2=None):
+    return conv2d(x, w, bias, stride, pad, x2), None
+
+
 def conv_transpose2x2(x, w, bias=None):
     return _nhwc(F.conv_transpose2d(_nchw(x), w.to(x.dtype), None if bias is None else bias.to(x.dtype), stride=2))
 
 
-def norm_act(x, w, b, kind, act=ACT_NONE, eps=1e-5, training=True, running_mean=None, running_var=None, momentum=0.1, group=None):
+def norm_act(x, w, b, kind, act=ACT_NONE, eps=1e-5, training=True, running_mean=None, running_var=None, momentum=0.1, group=None,
+             stats_part=None):
     xc = _nchw(x).float()
     if kind == "in":
         y = F.instance_norm(xc, None, None, w, b, True, 0.0, eps)
@@ -161,7 +166,7 @@ def attention(qkv, sin, cos, B, N, H, Dh, prefix, workspace):
     return o.transpose(1, 2).reshape(B * N, H * Dh).to(qkv.dtype)
 
 
-_NAMES = ["mm", "linear", "conv1x1", "conv2d", "conv_transpose2x2", "norm_act", "layer_norm", "layernorm_raw", "msda_prep", "msda",
+_NAMES = ["mm", "linear", "conv1x1", "conv2d", "conv2d_stats", "conv_transpose2x2", "norm_act", "layer_norm", "layernorm_raw", "msda_prep", "msda",
           "dwconv3x3", "dwconv_tokens", "maxpool3x3s2", "bilinear_add", "squeeze_excite", "nchw_to_nhwc", "nhwc_to_nchw_f32", "patchify16", "cast",
           "attention"]
 

@@ -376,6 +376,52 @@ def test_vit_attention(dt, B, H, N, Dh):
     assert rel(out, ref) < (2e-4 if dt == torch.float32 else 3e-2)
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout", [(2, 16, 32, 64, 0, 32), (1, 24, 16, 32, 32, 32), (2, 8, 16, 64, 64, 64), (1, 16, 16, 128, 128, 128),
+                                              (1, 32, 48, 32, 0, 64), (3, 8, 16, 128, 0, 64)])
+def test_conv3x3_halo_kernel_fwd_bwd_stats(B, H, W, C1, C2, Cout):
+    """LDS-tiled direct conv (bf16): forward (+fused concat), flipped-weight data gradient, weight gradient, and the per-tile channel
+    statistics it emits, vs torch conv2d / the separate statistics kernel."""
+    from dinounet_amd import ops
+    d = dev()
+    dt = torch.bfloat16
+    Cin = C1 + C2
+    x = q(gen(B, H, W, C1, seed=31), dt)
+    x2 = q(gen(B, H, W, C2, seed=32), dt) if C2 else None
+    w = gen(Cout, Cin, 3, 3, seed=33, scale=0.1)
+    bias = gen(Cout, seed=34, scale=0.1)
+    go = q(gen(B, H, W, Cout, seed=35), dt)
+    xin = torch.cat([x, x2], -1) if C2 else x
+    xr = xin.clone().requires_grad_(True)
+    wr = q(w, dt).clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    yr = F.conv2d(xr.permute(0, 3, 1, 2), wr, br, 1, 1).permute(0, 2, 3, 1)
+    yr.backward(go)
+    xg = x.to(d, dt).requires_grad_(True)
+    x2g = x2.to(d, dt).requires_grad_(True) if C2 else None
+    wg, bg = w.to(d).requires_grad_(True), bias.to(d).requires_grad_(True)
+    y, part = ops.conv2d_stats(xg, wg, bg, 1, 1, x2g)
+    if Cout < 64:
+        assert part is None
+        from dinounet_amd import ops as _o
+        part = _o.conv3x3_halo(xg.detach(), _o.pack_conv_weight(wg.detach(), dt), bg.detach(), None if x2g is None else x2g.detach(), True)
+        assert part is not None
+    assert part is not None, "shape should be served by the halo kernel"
+    y.backward(go.to(d, dt))
+    tol = TOL[dt]
+    assert rel(y, yr) < tol
+    assert rel(wg.grad, wr.grad) < tol and rel(bg.grad, br.grad) < tol
+    gx = torch.cat([xg.grad, x2g.grad], -1) if C2 else xg.grad
+    assert rel(gx, xr.grad) < tol
+    # statistics: finalize the partials and compare with the stand-alone statistics kernel on the same output
+    sums_ref, _ = ops.chan_stats(y.detach(), B)
+    sums = torch.empty_like(sums_ref)
+    from dinounet_amd import _lib
+    import ctypes as C
+    _lib.check(_lib.lib().du_strip_finalize(C.c_void_p(part.data_ptr()), C.c_void_p(sums.data_ptr()), B, part.shape[0] // B, Cout,
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "du_strip_finalize")
+    assert rel(sums, sums_ref) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ squeeze-excitation
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("B,H,W,C,with_sc", [(2, 16, 16, 32, True), (3, 8, 8, 256, False), (8, 32, 32, 128, True)])

@@ -58,7 +58,12 @@ def main():
         fl = 2.0 * B * H * H * Cin * Cout * 9
         by = B * H * H * (Cin + Cout) * 2
         rows.append((f"conv3x3 fwd   {H}^2 {Cin}->{Cout}", timeit(lambda: ops.conv_fwd(x, wp, None, 3, 3, 1, 1), reps), fl, by))
-        rows.append((f"conv3x3 dgrad {H}^2 {Cin}->{Cout}", timeit(lambda: ops.conv_dgrad(dy, wd, 3, 3, 1, 1, H, H), reps), fl, by))
+        rows.append((f"conv3x3 dgrad {H}^2 {Cin}->{Cout} (implicit GEMM)", timeit(lambda: ops.conv_dgrad(dy, wd, 3, 3, 1, 1, H, H), reps), fl, by))
+        wf = ops.pack_conv_weight_dgrad_flipped(w, bf)
+        if ops.conv3x3_halo(dy, wf, None) is not None:
+            rows.append((f"conv3x3 dgrad {H}^2 {Cin}->{Cout} (halo)", timeit(lambda: ops.conv3x3_halo(dy, wf, None), reps), fl, by))
+        if ops.conv3x3_halo(x, wp, None, None, True) is not None:
+            rows.append((f"conv3x3 fwd+stats {H}^2 {Cin}->{Cout} (halo)", timeit(lambda: ops.conv3x3_halo(x, wp, None, None, True), reps), fl, by))
         rows.append((f"conv3x3 wgrad {H}^2 {Cin}->{Cout}", timeit(lambda: ops.conv_wgrad(x, dy, 3, 3, 1, 1), reps), fl, by))
     for B, H, Cin, Cout in [(8, 64, 1024, 1024), (8, 256, 64, 32), (8, 256, 32, 32)]:
         x = rnd(B, H, H, Cin).requires_grad_(True)
