@@ -744,3 +744,63 @@ extern "C" int du_device_ok(void) {
   const char* a = p.gcnArchName;
   return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
 }
+
+// ---------------- per-step weight packing: every trainable fp32 weight -> its kernel-ready bf16 / fp32 forms, ONE launch -------------
+// Replaces ~300 tiny cast / permute / cat launches per train step (each >= 5 us inside a hipGraph).  Table row (8 x int64):
+//   [src ptr, dst ptr, kind | dst_f32 << 8, A, B, T, Cp, n_out];  bprefix[i] = first workgroup of row i (4096 outputs per workgroup).
+//   kind 0 CAST        dst[e] = src[e]
+//        1 CONV_FWD    src (A=Cout, B=Cin, T taps) -> dst (Cout, T*Cp), (tap, ci) columns, ci >= Cin zero     (F.conv2d weight)
+//        2 CONV_DGRAD  -> dst (Cin, T*Cout), [ci][(t, co)] = src[co][ci][t]
+//        3 CONV_DGRAD_FLIP  same with t -> T-1-t (stride-1 data gradient as a convolution with the flipped filter)
+//        4 CONVT_FWD   src (A=Cin, B=Cout, 2, 2) -> dst (4*Cout, Cin), [(q, co)][ci] = src[ci][co][q]       (ConvTranspose2d k2 s2)
+//        5 CONVT_DGRAD -> dst (Cin, 4*Cout), [ci][(q, co)] = src[ci][co][q]
+namespace {
+constexpr int PACK_CHUNK = 4096;   // output elements per workgroup
+__global__ __launch_bounds__(256) void pack_weights_kernel(const int64_t* __restrict__ table, const int64_t* __restrict__ bprefix, int n) {
+  // workgroup -> (table row, chunk of the row): bprefix[i] = first workgroup of row i (uniform binary search, scalar loads)
+  int lo = 0, hi = n;
+  const long bid = blockIdx.x;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bprefix[mid] <= bid) lo = mid; else hi = mid; }
+  const int64_t* r = table + (long)lo * 8;
+  const float* src = (const float*)r[0];
+  const int kind = (int)(r[2] & 0xff);
+  const bool f32 = (r[2] >> 8) & 1;
+  const int A = (int)r[3], B = (int)r[4], T = (int)r[5], Cp = (int)r[6];
+  const int nout = (int)r[7];
+  const int e0 = (int)(bid - bprefix[lo]) * PACK_CHUNK;
+  const int e1 = min(nout, e0 + PACK_CHUNK);
+  float* df = (float*)r[1];
+  bf16_t* db = (bf16_t*)r[1];
+  if (kind == 0 && !f32 && (nout & 3) == 0 && ((((uintptr_t)src) & 15) == 0) && ((((uintptr_t)db) & 7) == 0)) {
+    for (int e = e0 + threadIdx.x * 4; e < e1; e += 1024) {
+      const float4 v = *(const float4*)(src + e);
+      bf16x4 o; o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+      *(uint2*)(db + e) = __builtin_bit_cast(uint2, o);
+    }
+    return;
+  }
+  for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+    float v;
+    switch (kind) {
+      case 1: { const int co = e / (T * Cp); const int rr = e - co * (T * Cp); const int t = rr / Cp, ci = rr - t * Cp;
+                v = ci < B ? src[((long)co * B + ci) * T + t] : 0.f; break; }
+      case 2: case 3: { const int ci = e / (T * A); const int rr = e - ci * (T * A); int t = rr / A; const int co = rr - t * A;
+                if (kind == 3) t = T - 1 - t;
+                v = src[((long)co * B + ci) * T + t]; break; }
+      case 4: { const int row = e / A; const int ci = e - row * A; const int q = row / B, co = row - q * B;
+                v = src[((long)ci * B + co) * 4 + q]; break; }
+      case 5: { const int ci = e / (4 * B); const int rr = e - ci * (4 * B); const int q = rr / B, co = rr - q * B;
+                v = src[((long)ci * B + co) * 4 + q]; break; }
+      default: v = src[e];
+    }
+    if (f32) df[e] = v; else db[e] = (bf16_t)v;
+  }
+}
+}  // namespace
+
+extern "C" int du_pack_weights(const int64_t* table, const int64_t* bprefix, int n, int64_t nblocks, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!table || !bprefix || n <= 0 || nblocks <= 0) return DU_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, table, bprefix, n);
+  return du_check_launch();
+}

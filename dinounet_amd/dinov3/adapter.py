@@ -68,9 +68,8 @@ class MSDeformAttn(nn.Module):
         M, P = self.n_heads, self.n_points
         value = ops.linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         value = value.view(N, S, M, value.shape[-1] // M)
-        w_cat = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
-        b_cat = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
-        raw = ops.linear(query, w_cat, b_cat, out_dtype=torch.float32).view(N * Lq, M * P * 3)   # MSA:188-189, kept fp32 (MSA:30)
+        raw = ops.linear_cat(query, self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias,
+                             self.attention_weights.bias, out_dtype=torch.float32).view(N * Lq, M * P * 3)   # MSA:188-189, fp32 (MSA:30)
         loc, attn = ops.msda_prep(raw, reference_points, Lq, M, P, Hs, Ws)                   # MSA:190-197
         shapes, lsi = _level_tensors(Hs, Ws, query.device)   # cached: no host->device copy (sync) per call
         out = ops.msda(value, shapes, lsi, loc.view(N, Lq, M, 1, P, 2), attn.view(N, Lq, M, 1, P))   # MSA:207-214

@@ -149,9 +149,7 @@ class FAPM(nn.Module):
         for i, x in enumerate(x_list):
             # shared + specific bases read the same D-channel input: one GEMM with 2*rank output columns (DT:423-424)
             sb, sp = self.shared_basis, self.specific_bases[i]
-            w = torch.cat([sb.weight, sp.weight], 0)
-            b = torch.cat([sb.bias, sp.bias], 0) if sb.bias is not None else None
-            z2 = ops.conv1x1(x, w, b)
+            z2 = ops.conv1x1_cat(x, sb.weight, sp.weight, sb.bias, sp.bias)
             z_shared, z_specific = z2[..., :rank], z2[..., rank:]
             fg = self.film_generators[i]
             gb = ops.conv1x1(z_shared, fg.weight, fg.bias)                                     # DT:427
@@ -397,6 +395,7 @@ class DinoUNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("DinoUNet (dinounet_amd) runs on the MI355X through libdinounet_hip.so; move the module and "
                                "its input to the GPU (there is no CPU fallback)")
+        ops.PACK.refresh()          # one launch: kernel-ready bf16 forms of every trainable weight for this step
         return self.decoder(self.encoder(x.float()))
 
     def compute_conv_feature_map_size(self, input_size):

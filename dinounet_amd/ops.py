@@ -10,6 +10,7 @@ parity mode); statistics, MSDA locations/weights, weight gradients and the ViT r
 import ctypes as C
 import math
 import os
+import weakref
 
 import torch
 
@@ -152,6 +153,136 @@ def _dp(t):
     return None if t is None else t.data_ptr()
 
 
+
+# ----------------------------------------------------------------------------------------------------
+# per-step weight packing
+# ----------------------------------------------------------------------------------------------------
+PK_CAST, PK_CONV_FWD, PK_CONV_DGRAD, PK_CONV_DGRAD_FLIP, PK_CONVT_FWD, PK_CONVT_DGRAD = 0, 1, 2, 3, 4, 5
+
+
+class WeightPack:
+    """Kernel-ready copies of the trainable weights (bf16 cast, im2col column order, flipped data-gradient order, ConvTranspose
+    layouts, concatenations), refreshed by ONE du_pack_weights launch at the start of every DinoUNet forward instead of ~300 tiny
+    cast / permute / cat launches spread over the step.
+
+    get() registers a (weight, kind) pair the first time it is asked for and returns None (the caller packs with torch ops, as before);
+    from the next refresh() on it returns the packed buffer, valid as long as the source's autograd version counter is unchanged
+    (i.e. through the forward and backward of the step; an optimizer step invalidates it until the next refresh).  The device-side
+    table is rebuilt only outside stream capture, so the eager warm-up steps of TrainStep settle it before the hipGraph is recorded."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("DINOUNET_WEIGHT_PACK", "1") != "0"
+        self.entries = {}
+        self.order = []
+        self.dirty = False
+        self.table = None
+        self.prefix = None
+        self.total = 0
+        self.nbuilt = 0
+
+    @staticmethod
+    def _shape(srcs, kind, cp):
+        w = srcs[0]
+        if kind == PK_CAST:
+            rows = sum(t.shape[0] for t in srcs)
+            return (rows,) + tuple(w.flatten(1).shape[1:]) if w.dim() > 1 else (rows,)
+        if kind == PK_CONV_FWD:
+            return (w.shape[0], w.shape[2] * w.shape[3] * cp)
+        if kind in (PK_CONV_DGRAD, PK_CONV_DGRAD_FLIP):
+            return (w.shape[1], w.shape[2] * w.shape[3] * w.shape[0])
+        if kind == PK_CONVT_FWD:
+            return (4 * w.shape[1], w.shape[0])
+        if kind == PK_CONVT_DGRAD:
+            return (w.shape[0], 4 * w.shape[1])
+        raise ValueError(kind)
+
+    @staticmethod
+    def _base(t):
+        return t._base if t._base is not None else t
+
+    def get(self, srcs, kind, dt=torch.bfloat16, cp=0):
+        """srcs: weight tensor or tuple of tensors to concatenate along dim 0 (PK_CAST only).  Only (views of) leaf Parameters
+        are packed; temporaries (padded / concatenated copies made by the caller) are declined."""
+        if not self.enabled:
+            return None
+        if torch.is_tensor(srcs):
+            srcs = (srcs,)
+        w = srcs[0]
+        if not w.is_cuda or w.dtype != torch.float32 or dt not in (torch.bfloat16, torch.float32):
+            return None
+        for t in srcs:
+            bt = self._base(t)
+            if not (t.is_contiguous() and bt.is_leaf and isinstance(bt, torch.nn.Parameter)):
+                return None
+        if kind == PK_CONV_FWD and cp == 0:
+            cp = w.shape[1]
+        key = (tuple(t.data_ptr() for t in srcs), tuple(w.shape), kind, dt, cp)
+        e = self.entries.get(key)
+        if e is not None and any(r() is None for r in e["refs"]):     # a source parameter died and its address was recycled
+            self._drop(key)
+            e = None
+        if e is None:
+            dst = torch.zeros(self._shape(srcs, kind, cp), dtype=dt, device=w.device)
+            e = {"key": key, "refs": [weakref.ref(self._base(t)) for t in srcs], "ptrs": [t.data_ptr() for t in srcs],
+                 "nels": [t.numel() for t in srcs], "wshape": tuple(w.shape), "dst": dst, "kind": kind, "cp": cp, "vers": None,
+                 "built": False}
+            self.entries[key] = e
+            self.order.append(e)
+            self.dirty = True
+            return None
+        if not e["built"] or e["vers"] != tuple(r()._version for r in e["refs"]):
+            return None
+        return e["dst"]
+
+    def _drop(self, key):
+        e = self.entries.pop(key, None)
+        if e is not None:
+            self.order = [x for x in self.order if x is not e]
+            self.dirty = True
+
+    def refresh(self):
+        if not self.enabled or not self.order:
+            return
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            for e in [x for x in self.order if any(r() is None for r in x["refs"])]:
+                self._drop(e["key"])
+        if self.dirty and not capturing:
+            if not self.order:
+                self.table = None
+                return
+            rows, prefix, tot = [], [0], 0
+            dev = self.order[0]["dst"].device
+            for e in self.order:
+                off = 0
+                k = e["kind"]
+                ws = e["wshape"]
+                for ptr, nel in zip(e["ptrs"], e["nels"]):
+                    if k == PK_CAST:
+                        A, B, T, Cp, n = 0, 0, 0, 0, nel
+                    elif k in (PK_CONV_FWD, PK_CONV_DGRAD, PK_CONV_DGRAD_FLIP):
+                        A, B, T, Cp, n = ws[0], ws[1], ws[2] * ws[3], e["cp"], e["dst"].numel()
+                    else:
+                        A, B, T, Cp, n = ws[0], ws[1], 4, 0, e["dst"].numel()
+                    rows.append([ptr, e["dst"].data_ptr() + off * e["dst"].element_size(),
+                                 k | ((1 if e["dst"].dtype == torch.float32 else 0) << 8), A, B, T, Cp, n])
+                    off += n
+                    tot += (n + 4095) // 4096          # workgroups of this row (PACK_CHUNK outputs each)
+                    prefix.append(tot)
+                e["built"] = True
+            self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self.prefix = torch.tensor(prefix, dtype=torch.int64).to(dev)
+            self.total, self.nbuilt, self.dirty = tot, len(rows), False
+        if self.table is None:
+            return
+        _lib.check(_lib.lib().du_pack_weights(_p(self.table), _p(self.prefix), self.nbuilt, self.total, _st()), "du_pack_weights")
+        for e in self.order:
+            if e["built"]:
+                e["vers"] = tuple((r()._version if r() is not None else -1) for r in e["refs"])
+
+
+PACK = WeightPack()
+
 # ----------------------------------------------------------------------------------------------------
 # dense products
 # ----------------------------------------------------------------------------------------------------
@@ -286,9 +417,7 @@ def conv3x3_halo(x, wp, bias, x2=None, want_stats=False):
     elif C1 != Cin:
         return None
     y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
-    # the epilogue statistics pay off from 64 output channels up (measured: +35 us on the 32-channel 512^2 layers, where the separate
-    # statistics pass costs ~30 us; -10 us on the 64/128-channel ones)
-    part = torch.empty((B * (H // 8) * (W // 16), Cout, 2), dtype=torch.float32, device=x.device) if (want_stats and Cout >= 64) else None
+    part = torch.empty((B * (H // 8) * (W // 16), Cout, 2), dtype=torch.float32, device=x.device) if want_stats else None
     e0 = PROFILE.start() if PROFILE is not None else None
     rc = _lib.lib().du_conv3x3_halo(_p(x), ld, p2, ld2, C1, Cin, Cout, B, H, W, _p(wp), _p(bias), _p(y), Cout, _p(part), _st())
     if rc == -2:                                  # DU_ERR_UNSUPPORTED
@@ -358,11 +487,15 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x2, w, bias, stride, pad, want_stats):
         KH, KW = w.shape[2], w.shape[3]
-        wp = pack_conv_weight(w, x.dtype)
+        wp = PACK.get(w, PK_CONV_FWD, x.dtype)
+        if wp is None:
+            wp = pack_conv_weight(w, x.dtype)
         part = None
         r = None
         if KH == 3 and KW == 3 and stride == 1 and pad == 1:
-            r = conv3x3_halo(x, wp, _f32(bias), x2, want_stats)
+            # the epilogue statistics pay off from 64 output channels up (measured: +35 us on the 32-channel 512^2 layers, where the
+            # separate statistics pass costs ~30 us; -10 us on the 64/128-channel ones)
+            r = conv3x3_halo(x, wp, _f32(bias), x2, want_stats and w.shape[0] >= 64)
         if r is not None:
             y, part = r
         else:
@@ -385,7 +518,9 @@ class _Conv2d(torch.autograd.Function):
         if need_dx:
             done = False
             if KH == 3 and KW == 3 and stride == 1 and pad == 1 and dy.dtype == torch.bfloat16:
-                wf = pack_conv_weight_dgrad_flipped(w, dy.dtype)          # (Cin_total, 9*Cout)
+                wf = PACK.get(w, PK_CONV_DGRAD_FLIP, dy.dtype)            # (Cin_total, 9*Cout)
+                if wf is None:
+                    wf = pack_conv_weight_dgrad_flipped(w, dy.dtype)
                 if x2 is None:
                     r = conv3x3_halo(dy, wf, None)
                     if r is not None:
@@ -396,7 +531,9 @@ class _Conv2d(torch.autograd.Function):
                     if r1 is not None and r2 is not None:
                         dx, dx2, done = r1[0], r2[0], True
             if not done:
-                wd = pack_conv_weight_dgrad(w, dy.dtype)
+                wd = PACK.get(w, PK_CONV_DGRAD, dy.dtype)
+                if wd is None:
+                    wd = pack_conv_weight_dgrad(w, dy.dtype)
                 dfull = conv_dgrad(dy, wd, KH, KW, stride, pad, Hi, Wi)
                 if x2 is None:
                     dx = dfull
@@ -425,7 +562,13 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, residual, row_scale, rs_rows, out_dtype):
-        wq = w.to(x.dtype) if w.dtype != x.dtype else w
+        wq = w
+        if w.dtype != x.dtype:
+            wq = PACK.get(w, PK_CAST, x.dtype)
+            if wq is None:
+                wq = w.to(x.dtype)
+            elif wq.dim() != 2:
+                wq = wq.view(w.shape[0], -1)
         y = mm(x, wq, bias=_f32(bias), residual=residual, row_scale=row_scale, rs_rows=rs_rows, out_dtype=out_dtype)
         ctx.save_for_backward(x, wq, row_scale)
         ctx.rs_rows = rs_rows
@@ -457,6 +600,58 @@ def linear(x, w, bias=None, residual=None, row_scale=None, rs_rows=0, out_dtype=
     return y.view(*shp[:-1], w.shape[0])
 
 
+class _LinearCat(torch.autograd.Function):
+    """y = x [w1; w2]^T + [b1; b2]: two linear layers reading the same input as ONE product (MSDeformAttn's sampling_offsets +
+    attention_weights, ms_deform_attn.py:188-189; FAPM's shared + specific bases, dinounet_training.py:423-424).  The concatenated
+    bf16 weight comes from the per-step weight pack; the gradients are split back to the four parameters."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, b1, b2, out_dtype):
+        n1 = w1.shape[0]
+        wq = PACK.get((w1.reshape(n1, -1), w2.reshape(w2.shape[0], -1)), PK_CAST, x.dtype)
+        if wq is None:
+            wq = torch.cat([w1.reshape(n1, -1), w2.reshape(w2.shape[0], -1)], 0).to(x.dtype)
+        bq = None
+        if b1 is not None:
+            bq = PACK.get((b1, b2), PK_CAST, torch.float32)
+            if bq is None:
+                bq = torch.cat([b1, b2], 0).float()
+        y = mm(x, wq, bias=bq, out_dtype=out_dtype)
+        ctx.save_for_backward(x, wq)
+        ctx.conf = (n1, tuple(w1.shape), tuple(w2.shape), b1 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq = ctx.saved_tensors
+        n1, s1, s2, has_bias = ctx.conf
+        dyc = dy if dy.stride(1) == 1 else dy.contiguous()
+        if dyc.dtype != x.dtype:
+            dyc = cast(dyc, x.dtype)
+        dx = mm_dgrad(dyc, wq) if ctx.needs_input_grad[0] else None
+        dw = mm_wgrad(dyc, x)
+        db1 = db2 = None
+        if has_bias:
+            db = colsum(dyc)
+            db1, db2 = db[:n1], db[n1:]
+        return dx, dw[:n1].view(s1), dw[n1:].view(s2), db1, db2, None
+
+
+def linear_cat(x, w1, w2, b1=None, b2=None, out_dtype=None):
+    """x (..., K) -> (..., N1 + N2)."""
+    shp = x.shape
+    y = _LinearCat.apply(x.reshape(-1, shp[-1]), w1, w2, b1, b2, out_dtype)
+    return y.view(*shp[:-1], y.shape[-1])
+
+
+def conv1x1_cat(x, w1, w2, b1=None, b2=None, out_dtype=None):
+    """two 1x1 convolutions of the same NHWC input as one product; w (Cout_i, Cin, 1, 1)."""
+    B, H, W, Cc, ld = _nhwc(x)
+    xm = x.as_strided((B * H * W, Cc), (ld, 1), x.storage_offset())
+    y = _LinearCat.apply(xm, w1, w2, b1, b2, out_dtype)
+    return y.view(B, H, W, y.shape[-1])
+
+
 def conv1x1(x, w, bias=None, out_dtype=None):
     """1x1 conv on NHWC = linear over pixels.  w (Cout, Cin, 1, 1)."""
     B, H, W, Cc, ld = _nhwc(x)
@@ -472,7 +667,9 @@ class _ConvT2x2(torch.autograd.Function):
     def forward(ctx, x, w, bias):
         B, H, W, Cin, ld = _nhwc(x)
         Cout = w.shape[1]
-        wp = w.permute(2, 3, 1, 0).reshape(4 * Cout, Cin).to(x.dtype).contiguous()
+        wp = PACK.get(w, PK_CONVT_FWD, x.dtype)
+        if wp is None:
+            wp = w.permute(2, 3, 1, 0).reshape(4 * Cout, Cin).to(x.dtype).contiguous()
         out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
         _, _, _, _, ldc = _nhwc(out)
         b4 = _f32(bias).repeat(4) if bias is not None else None
@@ -493,7 +690,9 @@ class _ConvT2x2(torch.autograd.Function):
         dx = dw = db = None
         g, _, lddy, _ = _geom(dy, 2, 2, 2, 0, H, W, 0)
         if ctx.needs_input_grad[0]:
-            wd = w.permute(0, 2, 3, 1).reshape(Cin, 4 * Cout).to(dy.dtype).contiguous()
+            wd = PACK.get(w, PK_CONVT_DGRAD, dy.dtype)
+            if wd is None:
+                wd = w.permute(0, 2, 3, 1).reshape(Cin, 4 * Cout).to(dy.dtype).contiguous()
             dx = torch.empty((B, H, W, Cin), dtype=dy.dtype, device=dy.device)
             gemm_raw(dtype=_code(dy.dtype), out_dtype=_code(dx.dtype), a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * H * W,
                      N=Cin, K=4 * Cout, A=dy.data_ptr(), lda=lddy, B=wd.data_ptr(), ldb=4 * Cout, Cmat=dx.data_ptr(),

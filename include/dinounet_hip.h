@@ -251,6 +251,11 @@ int du_nhwc_to_nchw_f32(int src_dtype, const void* src, int64_t ld, float* dst, 
 /* 16x16/s16 patch gather: NCHW fp32 image -> (B*h*w, C*256) rows ordered (c, dy, dx) like Conv2d weight.flatten(1) */
 int du_patchify16(int dst_dtype, const float* src, void* dst, int B, int C, int H, int W, void* stream);
 
+/* One launch that turns every trainable fp32 weight into its kernel-ready form (bf16 cast / im2col column order / flipped data-gradient
+   order / ConvTranspose layouts / concatenations).  table: n rows of 8 int64 on the DEVICE [src, dst, kind | dst_is_f32 << 8, A, B, T,
+   Cp, n_out] (kinds: see elementwise.hip), bprefix: n+1 exclusive prefix sums of ceil(n_out / 4096) = workgroups per row. */
+int du_pack_weights(const int64_t* table, const int64_t* bprefix, int n, int64_t nblocks, void* stream);
+
 /* library self-description */
 const char* du_version(void);
 int du_device_ok(void); /* 1 if the current device is gfx950 */

@@ -44,6 +44,16 @@ def linear(x, w, bias=None, residual=None, row_scale=None, rs_rows=0, out_dtype=
     return y.to(out_dtype) if out_dtype is not None else y
 
 
+def linear_cat(x, w1, w2, b1=None, b2=None, out_dtype=None):
+    w = torch.cat([w1.reshape(w1.shape[0], -1), w2.reshape(w2.shape[0], -1)], 0)
+    b = torch.cat([b1, b2], 0) if b1 is not None else None
+    return linear(x, w, b, out_dtype=out_dtype)
+
+
+def conv1x1_cat(x, w1, w2, b1=None, b2=None, out_dtype=None):
+    return linear_cat(x, w1, w2, b1, b2, out_dtype)
+
+
 def conv1x1(x, w, bias=None, out_dtype=None):
     return linear(x, w.view(w.shape[0], -1), bias, out_dtype=out_dtype)
 
@@ -166,7 +176,7 @@ def attention(qkv, sin, cos, B, N, H, Dh, prefix, workspace):
     return o.transpose(1, 2).reshape(B * N, H * Dh).to(qkv.dtype)
 
 
-_NAMES = ["mm", "linear", "conv1x1", "conv2d", "conv2d_stats", "conv_transpose2x2", "norm_act", "layer_norm", "layernorm_raw", "msda_prep", "msda",
+_NAMES = ["mm", "linear", "linear_cat", "conv1x1_cat", "conv1x1", "conv2d", "conv2d_stats", "conv_transpose2x2", "norm_act", "layer_norm", "layernorm_raw", "msda_prep", "msda",
           "dwconv3x3", "dwconv_tokens", "maxpool3x3s2", "bilinear_add", "squeeze_excite", "nchw_to_nhwc", "nhwc_to_nchw_f32", "patchify16", "cast",
           "attention"]
 

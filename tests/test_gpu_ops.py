@@ -403,8 +403,9 @@ def test_conv3x3_halo_kernel_fwd_bwd_stats(B, H, W, C1, C2, Cout):
     if Cout < 64:
         assert part is None
         from dinounet_amd import ops as _o
-        part = _o.conv3x3_halo(xg.detach(), _o.pack_conv_weight(wg.detach(), dt), bg.detach(), None if x2g is None else x2g.detach(), True)
-        assert part is not None
+        r_ = _o.conv3x3_halo(xg.detach(), _o.pack_conv_weight(wg.detach(), dt), bg.detach(), None if x2g is None else x2g.detach(), True)
+        assert r_ is not None
+        part = r_[1]
     assert part is not None, "shape should be served by the halo kernel"
     y.backward(go.to(d, dt))
     tol = TOL[dt]
