@@ -249,3 +249,203 @@ extern "C" int du_conv3x3_halo(const void* x, int64_t ldx, const void* x2, int64
   if (Cout == 128) { if (c32) return launch<32, 4>(P, st); }
   return DU_ERR_UNSUPPORTED;
 }
+
+// =====================================================================================================================
+// Weight gradient of the same convolution:  dW[co][tap][ci] = sum_pix dY[pix][co] * X[pix + tap][ci]
+//
+// As an MFMA product the contraction runs over PIXELS, the slow index of both NHWC operands, so both fragments are fetched with the
+// LDS transpose read (ds_read_b64_tr_b16) from images that are stored exactly as they lie in HBM: the (8+2) x (16+2) input halo
+// [pixel][ci] (staged once per tile and chunk; the 9 taps read it at shifted pixel addresses) and the dY tile [pixel][co].
+// A k-step = the 16 pixels of one tile row.  The 9 * (Cout/32) * (CK/32) accumulator tiles of a channel chunk are dealt round-robin
+// to the 4 waves and stay in registers while the (persistent) workgroup walks its tiles; each workgroup then writes ONE fp32 partial
+// of dW and a finalize kernel adds the partials (no atomics).  The implicit-GEMM path re-gathered X nine times and had 4 MFMAs per
+// barrier (633 us for the 512^2 64->32 layer).
+// =====================================================================================================================
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_v4;
+
+__host__ __device__ constexpr int tr_pitch(int n) { return (n * 2) % 256 == 64 || (n * 2) % 256 == 192 ? n : n + 32; }
+
+struct WgradParams {
+  const bf16_t* x; long ldx; const bf16_t* x2; long ldx2; int C1, Cin, Cout;
+  const bf16_t* dy; long lddy;
+  int B, H, W;
+  float* part;              // [gridDim.x][Cout][9 * Cin] fp32
+  int tilesX, tilesY, ntiles;
+};
+
+template <int CK, int MT>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_halo_kernel(WgradParams P) {
+  constexpr int COUT = MT * 32;
+  constexpr int NB = CK / 32;                           // 32-wide ci blocks per chunk
+  constexpr int NTL = 9 * MT * NB;                      // accumulator tiles per chunk
+  constexpr int TPW = (NTL + 3) / 4;                    // per wave
+  constexpr int PX = tr_pitch(CK), PD = tr_pitch(COUT);
+  constexpr int CV = CK / 8, DV = COUT / 8;
+  constexpr int HV = (HW_ * CV + 255) / 256, YV = (128 * DV + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Xs = (bf16_t*)smem_raw;                       // [180][PX]
+  bf16_t* Ys = Xs + HW_ * PX;                           // [128][PD]   (tile pixel = ty * 16 + tx)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, p16 = lane & 15;
+  const int txk = 8 * (g >> 1) + (p16 >> 2);            // pixel column this lane addresses in a transpose read (second read: + 4)
+  const int oc = 16 * (g & 1) + 4 * (p16 & 3);          // outer-index offset inside a 32-wide block
+  const int nch = P.Cin / CK;
+
+  uint4 hreg[HV], yreg[YV];
+  auto tile_origin = [&](int tile, int& b, int& ty0, int& tx0) {
+    tx0 = (tile % P.tilesX) * TW;
+    const int t2 = tile / P.tilesX;
+    ty0 = (t2 % P.tilesY) * TH; b = t2 / P.tilesY;
+  };
+  auto loads = [&](int tile, int ch) {
+    int b, ty0, tx0;
+    tile_origin(tile, b, ty0, tx0);
+    const int c0 = ch * CK;
+    const bf16_t* src = P.x; long ld = P.ldx; int cofs = c0;
+    if (c0 >= P.C1) { src = P.x2; ld = P.ldx2; cofs = c0 - P.C1; }
+#pragma unroll
+    for (int i = 0; i < HV; i++) {
+      const int v = tid + i * 256;
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (v < HW_ * CV) {
+        const int pix = v / CV, cv = v % CV;
+        const int gy = ty0 + pix / HXW - 1, gx = tx0 + pix % HXW - 1;
+        if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W)
+          r = *(const uint4*)(src + (((long)b * P.H + gy) * P.W + gx) * ld + cofs + cv * 8);
+      }
+      hreg[i] = r;
+    }
+#pragma unroll
+    for (int i = 0; i < YV; i++) {
+      const int v = tid + i * 256;
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (v < 128 * DV) {
+        const int pix = v / DV, dv = v % DV;
+        r = *(const uint4*)(P.dy + (((long)b * P.H + ty0 + (pix >> 4)) * P.W + tx0 + (pix & 15)) * P.lddy + dv * 8);
+      }
+      yreg[i] = r;
+    }
+  };
+  auto stores = [&]() {
+#pragma unroll
+    for (int i = 0; i < HV; i++) {
+      const int v = tid + i * 256;
+      if (v < HW_ * CV) *(uint4*)(Xs + (v / CV) * PX + (v % CV) * 8) = hreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < YV; i++) {
+      const int v = tid + i * 256;
+      if (v < 128 * DV) *(uint4*)(Ys + (v / DV) * PD + (v % DV) * 8) = yreg[i];
+    }
+  };
+  auto trfrag = [&](const bf16_t* q, int pitch) -> bf16x8 {      // q: this lane's address of the first 4-pixel read
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)q);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(q + 4 * pitch));
+    s16x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, r);
+  };
+
+  if ((int)blockIdx.x >= P.ntiles) return;
+  for (int ch = 0; ch < nch; ch++) {
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+    // this wave's accumulator tiles: t = wave + 4 i  ->  (tap, mt, nb)
+    int xoff[TPW], yoff[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; i++) {
+      const int t = wave + 4 * i;
+      const int nb = t % NB, mt = (t / NB) % MT, tap = t / (NB * MT);
+      const int dy_ = tap / 3, dx_ = tap % 3;
+      xoff[i] = (dy_ * HXW + txk + dx_) * PX + nb * 32 + oc;      // + ty * HXW * PX per k-step
+      yoff[i] = txk * PD + mt * 32 + oc;                          // + ty * 16 * PD per k-step
+    }
+    int tile = blockIdx.x;
+    loads(tile, ch);
+    while (tile < P.ntiles) {
+      stores();
+      __syncthreads();
+      const int ntile = tile + gridDim.x;
+      if (ntile < P.ntiles) loads(ntile, ch);
+#pragma unroll
+      for (int ty = 0; ty < TH; ty++) {
+#pragma unroll
+        for (int i = 0; i < TPW; i++) {
+          if (wave + 4 * i < NTL) {
+            const bf16x8 fa = trfrag(Ys + ty * 16 * PD + yoff[i], PD);
+            const bf16x8 fb = trfrag(Xs + ty * HXW * PX + xoff[i], PX);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+      tile = ntile;
+    }
+    // flush this chunk's tiles: part[block][co][tap * Cin + ch * CK + ci]
+    float* dst = P.part + (long)blockIdx.x * COUT * 9 * P.Cin;
+#pragma unroll
+    for (int i = 0; i < TPW; i++) {
+      const int t = wave + 4 * i;
+      if (t < NTL) {
+        const int nb = t % NB, mt = (t / NB) % MT, tap = t / (NB * MT);
+        const int ci = ch * CK + nb * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          dst[((long)co * 9 + tap) * P.Cin + ci] = acc[i][r];
+        }
+      }
+    }
+  }
+}
+
+template <int CK, int MT>
+int launch_wgrad(WgradParams& P, int max_blocks, hipStream_t st) {
+  constexpr int COUT = MT * 32;
+  const size_t lds = (size_t)(HW_ * tr_pitch(CK) + 128 * tr_pitch(COUT)) * 2;
+  auto kfn = conv3x3_wgrad_halo_kernel<CK, MT>;
+  if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DU_ERR_LAUNCH;
+  int grid = max_blocks < P.ntiles ? max_blocks : P.ntiles;
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, P);
+  return du_check_launch();
+}
+
+}  // namespace
+
+// number of workgroups (= partial dW slabs) the weight-gradient kernel uses for this shape; 0 = shape not served
+extern "C" int du_conv3x3_wgrad_halo_blocks(int C1, int Cin, int Cout, int B, int H, int W) {
+  if (H % TH || W % TW || B <= 0) return 0;
+  if (!(Cout == 32 || Cout == 64) || Cin % 32 || C1 % 32) return 0;   // 128 output channels: 9 accumulator tiles per wave spill
+  if ((long)Cout * 9 * Cin > 80L * 1024) return 0;                 // larger filters: MFMA-bound anyway, partial slabs too big
+  const int ntiles = B * (H / TH) * (W / TW);
+  return ntiles < 256 ? ntiles : 256;
+}
+
+// x / x2 as in du_conv3x3_halo, dy (B,H,W,Cout) bf16; part: du_conv3x3_wgrad_halo_blocks(...) x Cout x 9*Cin fp32 scratch;
+// dw (Cout, 9*Cin) fp32 in (tap, ci) column order is OVERWRITTEN (sum of the partial slabs, via du_strip_finalize).
+extern "C" int du_conv3x3_wgrad_halo(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int C1, int Cin, int Cout, int B, int H,
+                                     int W, const void* dy, int64_t lddy, float* part, float* dw, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!x || !dy || !part || !dw) return DU_ERR_BAD_ARG;
+  if (!x2) C1 = Cin;
+  const int blocks = du_conv3x3_wgrad_halo_blocks(C1, Cin, Cout, B, H, W);
+  if (blocks <= 0 || ldx % 8 || lddy % 8 || (x2 && ldx2 % 8)) return DU_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)x2)) & 15) return DU_ERR_UNSUPPORTED;
+  WgradParams P{};
+  P.x = (const bf16_t*)x; P.ldx = ldx; P.x2 = (const bf16_t*)x2; P.ldx2 = ldx2; P.C1 = C1; P.Cin = Cin; P.Cout = Cout;
+  P.dy = (const bf16_t*)dy; P.lddy = lddy; P.B = B; P.H = H; P.W = W; P.part = part;
+  P.tilesX = W / TW; P.tilesY = H / TH; P.ntiles = B * P.tilesX * P.tilesY;
+  const bool c64 = Cin % 64 == 0 && C1 % 64 == 0;
+  int rc = DU_ERR_UNSUPPORTED;
+  if (Cout == 32) rc = c64 ? launch_wgrad<64, 1>(P, blocks, st) : launch_wgrad<32, 1>(P, blocks, st);
+  else if (Cout == 64) rc = launch_wgrad<32, 2>(P, blocks, st);        // 32-channel chunks: 5 accumulator tiles per wave, no spills
+  if (rc != DU_OK) return rc;
+  return du_strip_finalize(part, dw, 1, blocks, Cout * 9 * Cin / 2, stream);   // finalize works on (C, 2) pairs: C = elements / 2
+}

@@ -140,7 +140,14 @@ def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat,
         es = 2 if dtype == DU_BF16 else 4
         eo = 2 if out_dtype == DU_BF16 else 4
         kin = K if geom is None else K // max(geom.KH * geom.KW, 1) if a_mode == IM2COL_ROW else K
-        tag = f"gemm_kernel<{'bf16' if dtype == DU_BF16 else 'f32'},{_MODE_NAMES.get((a_mode, b_mode), 'other')}>"
+        # mirror of the C-side dispatch (gemm.hip -> gemm_bf16.hip -> gemm_glds.hip) so the bench names the kernel that actually ran
+        if dtype != DU_BF16:
+            kname = "gemm_kernel"
+        elif a_mode == PLAIN_ROW and b_mode == PLAIN_ROW and K % 64 == 0 and N >= 96 and M >= 64 and split_k <= 1:
+            kname = "gemm_nt_glds_kernel"
+        else:
+            kname = "gemm_bf16_kernel"
+        tag = f"{kname}<{'bf16' if dtype == DU_BF16 else 'f32'},{_MODE_NAMES.get((a_mode, b_mode), 'other')}>"
         if PROFILE.detail:
             tag += f" M{M} N{N} K{K} b{batch} sk{split_k}" + (f" k{geom.KH}s{geom.stride}t{geom.transposed}" if geom is not None else "")
         PROFILE.stop(tag, e0,
@@ -464,9 +471,40 @@ def conv_dgrad(dy, wd, KH, KW, stride, pad, Hin, Win, out=None):
     return out
 
 
+def conv3x3_wgrad_halo(x, dy, x2=None):
+    """LDS-tiled 3x3 / stride 1 / pad 1 weight gradient (du_conv3x3_wgrad_halo) -> fp32 (Cout, 9*Cin), or None if not served."""
+    if x.dtype != torch.bfloat16:
+        return None
+    B, H, W, C1, ld = _nhwc(x)
+    Bo, Ho, Wo, Cout, lddy = _nhwc(dy)
+    Cin, ld2, p2 = C1, 0, None
+    if x2 is not None:
+        _, _, _, C2, ld2 = _nhwc(x2)
+        Cin, p2 = C1 + C2, _p(x2)
+    L = _lib.lib()
+    blocks = int(L.du_conv3x3_wgrad_halo_blocks(C1, Cin, Cout, B, H, W))
+    if blocks <= 0 or (Ho, Wo) != (H, W):
+        return None
+    part = torch.empty((blocks, Cout, 9 * Cin), dtype=torch.float32, device=x.device)
+    dw = torch.empty((Cout, 9 * Cin), dtype=torch.float32, device=x.device)
+    e0 = PROFILE.start() if PROFILE is not None else None
+    rc = L.du_conv3x3_wgrad_halo(_p(x), ld, p2, ld2, C1, Cin, Cout, B, H, W, _p(dy), lddy, _p(part), _p(dw), _st())
+    if rc == -2:
+        return None
+    _lib.check(rc, "du_conv3x3_wgrad_halo")
+    if PROFILE is not None:
+        PROFILE.stop("conv3x3_wgrad_halo_kernel<bf16>" + (f" {H}x{W} {Cin}->{Cout}" if PROFILE.detail else ""), e0,
+                     2.0 * B * H * W * Cin * Cout * 9, 2.0 * B * H * W * (Cin + Cout))
+    return dw
+
+
 def conv_wgrad(x, dy, KH, KW, stride, pad, x2=None):
     """-> fp32 (Cout, KH*KW*C) in (tap, ci) column order."""
     _req(x, dy)
+    if KH == 3 and KW == 3 and stride == 1 and pad == 1:
+        r = conv3x3_wgrad_halo(x, dy, x2)
+        if r is not None:
+            return r
     Bo, Ho, Wo, Cout, lddy = _nhwc(dy)
     g, B, ld, Ct = _geom(x, KH, KW, stride, pad, Ho, Wo, 0, x2)
     Ncol = KH * KW * Ct

@@ -111,6 +111,11 @@ int du_gemm(const du_gemm_args* args, void* stream);
    {32,64,128}, channel counts not multiples of 32): the caller then uses du_gemm's implicit-GEMM path. */
 int du_conv3x3_halo(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int C1, int Cin, int Cout, int B, int H, int W,
                     const void* w, const float* bias, void* y, int64_t ldy, float* stats_part, void* stream);
+/* Weight gradient of the same convolution, dw (Cout, 9*Cin) fp32 in (tap, ci) column order (OVERWRITTEN).  part: scratch of
+   du_conv3x3_wgrad_halo_blocks(...) * Cout * 9*Cin floats (0 blocks = shape not served -> use du_gemm's IM2COL_COL path). */
+int du_conv3x3_wgrad_halo_blocks(int C1, int Cin, int Cout, int B, int H, int W);
+int du_conv3x3_wgrad_halo(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int C1, int Cin, int Cout, int B, int H, int W,
+                          const void* dy, int64_t lddy, float* part, float* dw, void* stream);
 /* out[g][c][j] = sum_s part[g*strips + s][c][j]: second stage of the column reductions, exposed for producers that emit partials */
 int du_strip_finalize(const float* part, float* out, int G, int strips, int C, void* stream);
 
