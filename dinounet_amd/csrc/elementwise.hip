@@ -754,6 +754,7 @@ extern "C" int du_device_ok(void) {
 //        3 CONV_DGRAD_FLIP  same with t -> T-1-t (stride-1 data gradient as a convolution with the flipped filter)
 //        4 CONVT_FWD   src (A=Cin, B=Cout, 2, 2) -> dst (4*Cout, Cin), [(q, co)][ci] = src[ci][co][q]       (ConvTranspose2d k2 s2)
 //        5 CONVT_DGRAD -> dst (Cin, 4*Cout), [ci][(q, co)] = src[ci][co][q]
+//        6 TRANSPOSE   src (A, B) -> dst (B, A)   (linear-layer data gradient as an "NT" product: dX = dY . (W^T)^T)
 namespace {
 constexpr int PACK_CHUNK = 4096;   // output elements per workgroup
 __global__ __launch_bounds__(256) void pack_weights_kernel(const int64_t* __restrict__ table, const int64_t* __restrict__ bprefix, int n) {
@@ -791,6 +792,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const int64_t* __rest
                 v = src[((long)ci * B + co) * 4 + q]; break; }
       case 5: { const int ci = e / (4 * B); const int rr = e - ci * (4 * B); const int q = rr / B, co = rr - q * B;
                 v = src[((long)ci * B + co) * 4 + q]; break; }
+      case 6: { const int k = e / A; const int nn = e - k * A; v = src[(long)nn * B + k]; break; }   // TRANSPOSE: src (A, B) -> dst (B, A)
       default: v = src[e];
     }
     if (f32) df[e] = v; else db[e] = (bf16_t)v;

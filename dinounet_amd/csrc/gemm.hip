@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams P) {
         } else {
           off = (long)m * P.ldc + n;
         }
-        if (Rb) v += to_f32(Rb[(long)m * P.ldr + n]);
+        if (Rb) v += to_f32(Rb[P.store_mode == DU_STORE_PIXEL_SHUFFLE2 ? (off / P.ldc) * P.ldr + ps_co : (long)m * P.ldr + n]);
         Cb[off] = from_f32<TC>(v);
       }
     }
@@ -322,6 +322,7 @@ extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
     if (b_i2c && a.N != g.KH * g.KW * g.C) return DU_ERR_BAD_ARG;
   }
   if (a.split_k > 1 && (a.out_dtype != DU_F32 || a.bias || a.act || a.gamma || a.row_scale || a.residual || a.store_mode)) return DU_ERR_BAD_ARG;
+  if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && a.residual && a.ldc % 1) return DU_ERR_BAD_ARG;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && (a.ps_C <= 0 || a.N != 4 * a.ps_C || a.M % (a.ps_H * a.ps_W))) return DU_ERR_BAD_ARG;
   if (a.dtype == DU_BF16) {
     static const bool generic_only = getenv("DU_GEMM_GENERIC") != nullptr;   // debugging aid: force the generic kernel

@@ -285,19 +285,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
 #pragma unroll
         for (int e = 0; e < 4; e++) o[e] *= rs;
       }
-      if (Rb) {
-        float rr[4];
-        Out4<TC>::load(Rb + (long)m * P.ldr + n, rr);
-#pragma unroll
-        for (int e = 0; e < 4; e++) o[e] += rr[e];
-      }
-      long off;
+      long off, offr;
       if (P.store_mode == DU_STORE_PIXEL_SHUFFLE2) {
         const int ps_q = n / P.ps_C, ps_co = n - ps_q * P.ps_C;
         int x = m % P.ps_W; int t2 = m / P.ps_W; int y = t2 % P.ps_H; int b = t2 / P.ps_H;
-        off = (((long)b * 2 * P.ps_H + 2 * y + (ps_q >> 1)) * (2 * P.ps_W) + 2 * x + (ps_q & 1)) * P.ldc + ps_co;
+        const long opix = ((long)b * 2 * P.ps_H + 2 * y + (ps_q >> 1)) * (2 * P.ps_W) + 2 * x + (ps_q & 1);
+        off = opix * P.ldc + ps_co;
+        offr = opix * P.ldr + ps_co;      // the residual is laid out like the OUTPUT (pixel-shuffled), not like the GEMM
       } else {
         off = (long)m * P.ldc + n;
+        offr = (long)m * P.ldr + n;
+      }
+      if (Rb) {
+        float rr[4];
+        Out4<TC>::load(Rb + offr, rr);
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] += rr[e];
       }
       Out4<TC>::store(Cb + off, o);
     }

@@ -318,7 +318,7 @@ class DINOv3_Adapter(nn.Module):
         c2 = c[:, :n2].contiguous().view(B, H_c * 2, W_c * 2, D)                            # ADP:460-466
         c3 = c[:, n2:n2 + n3].contiguous().view(B, H_c, W_c, D)
         c4 = c[:, n2 + n3:].contiguous().view(B, H_c // 2, W_c // 2, D)
-        c1 = ops.conv_transpose2x2(c2, self.up.weight, self.up.bias) + c1                  # ADP:467
+        c1 = ops.conv_transpose2x2(c2, self.up.weight, self.up.bias, residual=c1)          # ADP:467 (add fused in the epilogue)
         cs = [c1, c2, c3, c4]
         if self.add_vit_feature:                                                            # ADP:469-476
             cs = [ops.bilinear_add(layers[j][0].view(B, H_t, W_t, D), cs[j]) for j in range(4)]

@@ -164,7 +164,7 @@ def _dp(t):
 # ----------------------------------------------------------------------------------------------------
 # per-step weight packing
 # ----------------------------------------------------------------------------------------------------
-PK_CAST, PK_CONV_FWD, PK_CONV_DGRAD, PK_CONV_DGRAD_FLIP, PK_CONVT_FWD, PK_CONVT_DGRAD = 0, 1, 2, 3, 4, 5
+PK_CAST, PK_CONV_FWD, PK_CONV_DGRAD, PK_CONV_DGRAD_FLIP, PK_CONVT_FWD, PK_CONVT_DGRAD, PK_TRANSPOSE = 0, 1, 2, 3, 4, 5, 6
 
 
 class WeightPack:
@@ -201,6 +201,8 @@ class WeightPack:
             return (4 * w.shape[1], w.shape[0])
         if kind == PK_CONVT_DGRAD:
             return (w.shape[0], 4 * w.shape[1])
+        if kind == PK_TRANSPOSE:                       # (rows of all sources, K) -> (K, rows)
+            return (w.flatten(1).shape[1], sum(t.shape[0] for t in srcs))
         raise ValueError(kind)
 
     @staticmethod
@@ -223,6 +225,8 @@ class WeightPack:
                 return None
         if kind == PK_CONV_FWD and cp == 0:
             cp = w.shape[1]
+        if kind == PK_TRANSPOSE and len(srcs) != 1:
+            return None
         key = (tuple(t.data_ptr() for t in srcs), tuple(w.shape), kind, dt, cp)
         e = self.entries.get(key)
         if e is not None and any(r() is None for r in e["refs"]):     # a source parameter died and its address was recycled
@@ -267,6 +271,8 @@ class WeightPack:
                 for ptr, nel in zip(e["ptrs"], e["nels"]):
                     if k == PK_CAST:
                         A, B, T, Cp, n = 0, 0, 0, 0, nel
+                    elif k == PK_TRANSPOSE:
+                        A, B, T, Cp, n = ws[0], nel // ws[0], 0, 0, nel
                     elif k in (PK_CONV_FWD, PK_CONV_DGRAD, PK_CONV_DGRAD_FLIP):
                         A, B, T, Cp, n = ws[0], ws[1], ws[2] * ws[3], e["cp"], e["dst"].numel()
                     else:
@@ -608,6 +614,8 @@ class _Linear(torch.autograd.Function):
             elif wq.dim() != 2:
                 wq = wq.view(w.shape[0], -1)
         y = mm(x, wq, bias=_f32(bias), residual=residual, row_scale=row_scale, rs_rows=rs_rows, out_dtype=out_dtype)
+        # W^T (K, N) from the weight pack turns the data gradient into a contraction-contiguous product (direct-to-LDS kernel)
+        ctx.wT = PACK.get(w, PK_TRANSPOSE, x.dtype) if (w.dtype != x.dtype and w.shape[0] % 64 == 0) else None
         ctx.save_for_backward(x, wq, row_scale)
         ctx.rs_rows = rs_rows
         ctx.has_bias = bias is not None
@@ -623,7 +631,9 @@ class _Linear(torch.autograd.Function):
             dyc = cast(dyc, x.dtype)
         if row_scale is not None:
             dyc = (dyc.view(row_scale.numel(), ctx.rs_rows, -1) * row_scale.view(-1, 1, 1).to(dyc.dtype)).view(dyc.shape)
-        dx = mm_dgrad(dyc, wq) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = mm(dyc, ctx.wT) if ctx.wT is not None else mm_dgrad(dyc, wq)
         dw = mm_wgrad(dyc, x) if ctx.needs_input_grad[1] else None
         db = colsum(dyc) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, dres, None, None, None
@@ -702,7 +712,7 @@ class _ConvT2x2(torch.autograd.Function):
     """ConvTranspose2d(k=2, s=2) on NHWC as GEMM [pixels x Cin] . [Cin x 4 Cout] + pixel-shuffle store."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, residual=None):
         B, H, W, Cin, ld = _nhwc(x)
         Cout = w.shape[1]
         wp = PACK.get(w, PK_CONVT_FWD, x.dtype)
@@ -711,11 +721,16 @@ class _ConvT2x2(torch.autograd.Function):
         out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
         _, _, _, _, ldc = _nhwc(out)
         b4 = _f32(bias).repeat(4) if bias is not None else None
+        ldr = 0
+        if residual is not None:                       # tensor of the output shape added in the epilogue (dinov3_adapter.py:467)
+            Br, Hr, Wr, Cr, ldr = _nhwc(residual)
+            assert (Br, Hr, Wr, Cr) == (B, 2 * H, 2 * W, Cout) and residual.dtype == x.dtype
         gemm_raw(dtype=_code(x.dtype), out_dtype=_code(out.dtype), a_mode=PLAIN_ROW, b_mode=PLAIN_ROW, M=B * H * W,
                  N=4 * Cout, K=Cin, A=x.data_ptr(), lda=ld, B=wp.data_ptr(), ldb=Cin, Cmat=out.data_ptr(), ldc=ldc,
-                 bias=_dp(b4), store_mode=STORE_PIXEL_SHUFFLE2, ps=(H, W, Cout))
+                 bias=_dp(b4), residual=_dp(residual), ldr=ldr, store_mode=STORE_PIXEL_SHUFFLE2, ps=(H, W, Cout))
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
         return out
 
     @staticmethod
@@ -746,11 +761,12 @@ class _ConvT2x2(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             Bo, Ho, Wo, Co, ldo = _nhwc(dy)
             db = colsum(dy.as_strided((Bo * Ho * Wo, Co), (ldo, 1), dy.storage_offset()))
-        return dx, dw, db
+        return dx, dw, db, (dy if ctx.has_res else None)
 
 
-def conv_transpose2x2(x, w, bias=None):
-    return _ConvT2x2.apply(x, w, bias)
+def conv_transpose2x2(x, w, bias=None, residual=None):
+    """ConvTranspose2d(k=2, s=2) on NHWC [+ residual of the output shape, fused into the epilogue]."""
+    return _ConvT2x2.apply(x, w, bias, residual)
 
 
 # ----------------------------------------------------------------------------------------------------

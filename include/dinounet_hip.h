@@ -95,7 +95,8 @@ typedef struct {
   int32_t act;
   const float* gamma; /* [N] fp32 or NULL: per-column scale applied after act (LayerScale) */
   const float* row_scale; int32_t rs_rows; /* optional per-row-block scale v *= row_scale[m / rs_rows] (DropPath) */
-  const void* residual; int64_t ldr; /* added last, NULL for none; may alias C */
+  const void* residual; int64_t ldr; /* added last, NULL for none; may alias C.  Indexed like C: with DU_STORE_PIXEL_SHUFFLE2 it is a
+                                        tensor of the OUTPUT shape (pixel stride ldr), e.g. the skip added to a ConvTranspose result */
   int32_t store_mode;
   int32_t ps_H, ps_W, ps_C; /* pixel-shuffle geometry: input grid H x W, Cout */
   du_conv_geom geom;  /* used by the IM2COL operand (at most one operand is IM2COL) */

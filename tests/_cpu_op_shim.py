@@ -75,8 +75,9 @@ def conv2d_stats(x, w, bias=None, stride=1, pad=1, x2=None):
     return conv2d(x, w, bias, stride, pad, x2), None
 
 
-def conv_transpose2x2(x, w, bias=None):
-    return _nhwc(F.conv_transpose2d(_nchw(x), w.to(x.dtype), None if bias is None else bias.to(x.dtype), stride=2))
+def conv_transpose2x2(x, w, bias=None, residual=None):
+    y = _nhwc(F.conv_transpose2d(_nchw(x), w.to(x.dtype), None if bias is None else bias.to(x.dtype), stride=2))
+    return y if residual is None else y + residual
 
 
 def norm_act(x, w, b, kind, act=ACT_NONE, eps=1e-5, training=True, running_mean=None, running_var=None, momentum=0.1, group=None,

@@ -159,6 +159,65 @@ def test_conv_transpose2x2_fwd_bwd(dt, B, H, W, Cin, Cout):
     assert rel(gg[2], gr[2]) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", DTS)
+def test_conv_transpose2x2_fused_residual(dt):
+    """ConvTranspose + skip add in the epilogue (dinov3_adapter.py:467): the residual has the OUTPUT (pixel-shuffled) layout."""
+    from dinounet_amd import ops
+    d = dev()
+    B, H, W, Cin, Cout = 2, 8, 12, 64, 64
+    x, w, b = q(gen(B, Cin, H, W, seed=1), dt), gen(Cin, Cout, 2, 2, seed=2, scale=Cin ** -0.5), gen(Cout, seed=3)
+    res = q(gen(B, Cout, 2 * H, 2 * W, seed=5), dt)
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, q(w, dt), b, stride=2) + rr
+    go = q(gen(*yr.shape, seed=4), dt)
+    gr = torch.autograd.grad(yr, (xr, rr), go)
+    xg, rg = nhwc(x).to(d, dt).requires_grad_(True), nhwc(res).to(d, dt).requires_grad_(True)
+    y = ops.conv_transpose2x2(xg, w.to(d), b.to(d), residual=rg)
+    gg = torch.autograd.grad(y, (xg, rg), nhwc(go).to(d, dt))
+    assert rel(y.permute(0, 3, 1, 2), yr) < TOL[dt]
+    assert rel(gg[0].permute(0, 3, 1, 2), gr[0]) < TOL[dt]
+    assert rel(gg[1].permute(0, 3, 1, 2), gr[1]) < 1e-6
+
+
+def test_weight_pack_matches_torch_packing():
+    """du_pack_weights (one launch per step) must reproduce every torch-side packing it replaces, and go stale when a source changes."""
+    from dinounet_amd import ops
+    d = dev()
+    bf = torch.bfloat16
+    P = ops.WeightPack()
+    lin = torch.nn.Parameter(gen(192, 96, seed=1).to(d))
+    lin2 = torch.nn.Parameter(gen(64, 96, seed=2).to(d))
+    b1, b2 = torch.nn.Parameter(gen(192, seed=3).to(d)), torch.nn.Parameter(gen(64, seed=4).to(d))
+    cw = torch.nn.Parameter(gen(32, 24, 3, 3, seed=5).to(d))
+    stem = torch.nn.Parameter(gen(16, 3, 3, 3, seed=6).to(d))
+    tw = torch.nn.Parameter(gen(40, 24, 2, 2, seed=7).to(d))
+    c11 = torch.nn.Parameter(gen(48, 32, 1, 1, seed=8).to(d))
+    reqs = [((lin,), ops.PK_CAST, bf, 0, lambda: lin.to(bf)),
+            ((lin, lin2), ops.PK_CAST, bf, 0, lambda: torch.cat([lin, lin2], 0).to(bf)),
+            ((b1, b2), ops.PK_CAST, torch.float32, 0, lambda: torch.cat([b1, b2], 0)),
+            ((lin,), ops.PK_TRANSPOSE, bf, 0, lambda: lin.t().contiguous().to(bf)),
+            ((c11.view(48, 32),), ops.PK_CAST, bf, 0, lambda: c11.view(48, 32).to(bf)),
+            ((cw,), ops.PK_CONV_FWD, bf, 0, lambda: ops.pack_conv_weight(cw, bf)),
+            ((stem,), ops.PK_CONV_FWD, bf, 8, lambda: ops.pack_conv_weight(F.pad(stem, (0, 0, 0, 0, 0, 5)), bf)),
+            ((cw,), ops.PK_CONV_DGRAD, bf, 0, lambda: ops.pack_conv_weight_dgrad(cw, bf)),
+            ((cw,), ops.PK_CONV_DGRAD_FLIP, bf, 0, lambda: ops.pack_conv_weight_dgrad_flipped(cw, bf)),
+            ((tw,), ops.PK_CONVT_FWD, bf, 0, lambda: tw.permute(2, 3, 1, 0).reshape(4 * 24, 40).to(bf)),
+            ((tw,), ops.PK_CONVT_DGRAD, bf, 0, lambda: tw.permute(0, 2, 3, 1).reshape(40, 4 * 24).to(bf))]
+    for srcs, kind, dt, cp, _ in reqs:
+        assert P.get(srcs, kind, dt, cp) is None        # first request only registers
+    P.refresh()
+    for srcs, kind, dt, cp, ref in reqs:
+        got = P.get(srcs, kind, dt, cp)
+        assert got is not None and got.dtype == dt
+        assert torch.equal(got.float().cpu(), ref().float().cpu()), kind
+    with torch.no_grad():
+        lin.add_(1.0)                                   # in-place update (optimizer step): packed copy must be declined until refreshed
+    assert P.get((lin,), ops.PK_CAST, bf) is None
+    P.refresh()
+    assert torch.equal(P.get((lin,), ops.PK_CAST, bf).float().cpu(), lin.to(bf).float().cpu())
+    assert P.get(torch.cat([lin, lin2], 0), ops.PK_CAST, bf) is None     # temporaries are never packed
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("kind,C,H,W", [("in", 32, 64, 64), ("in", 256, 8, 8), ("bn", 64, 32, 32), ("bn", 384, 16, 16)])
