@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                const float* __restrict__ w, const float* __restrict__ mean,
-                                                               const float* __restrict__ rstd, T* __restrict__ dx, long rows, int D) {
+                                                               const float* __restrict__ rstd, T* __restrict__ dx, long rows, int D,
+                                                               const T* __restrict__ dres) {
+  // dres (nullable): gradient arriving on the residual branch that by-passes the norm (y = x + f(LN(x))): dx = LN-path + dres,
+  // fused here instead of a separate full-size add in the autograd engine
   constexpr int VI = Elem<T>::VEC;
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -92,8 +95,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const T* __restri
     int vi = lane + i * 64;
     if (vi < nvec) {
       Vec16<T> o;
+      if (dres) {
+        Vec16<T> tr = as_vec<T>(*(const uint4*)(dres + row * (long)D + (long)vi * VI));
 #pragma unroll
-      for (int j = 0; j < VI; j++) o.v[j] = from_f32<T>(rs * (g[i][j] - c1 - xh[i][j] * c2));
+        for (int j = 0; j < VI; j++) o.v[j] = from_f32<T>(rs * (g[i][j] - c1 - xh[i][j] * c2) + to_f32(tr.v[j]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < VI; j++) o.v[j] = from_f32<T>(rs * (g[i][j] - c1 - xh[i][j] * c2));
+      }
       *(uint4*)(dx + row * (long)D + (long)vi * VI) = as_u4(o);
     }
   }
@@ -472,11 +481,11 @@ int ln_fwd_dispatch(const void* x, long ldx, const float* w, const float* b, voi
 
 template <typename T>
 int ln_bwd_dispatch(const void* x, const void* dy, const float* w, const float* mean, const float* rstd, void* dx, float* dwdb,
-                    long rows, int D, float* ws, long ws_elems, hipStream_t st) {
+                    long rows, int D, float* ws, long ws_elems, const void* dres, hipStream_t st) {
   const int nvec = D / Elem<T>::VEC;
   const int maxv = (nvec + 63) / 64;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define LNB_LAUNCH(MV) hipLaunchKernelGGL((layernorm_bwd_dx_kernel<T, MV>), grid, block, 0, st, (const T*)x, (const T*)dy, w, mean, rstd, (T*)dx, rows, D)
+#define LNB_LAUNCH(MV) hipLaunchKernelGGL((layernorm_bwd_dx_kernel<T, MV>), grid, block, 0, st, (const T*)x, (const T*)dy, w, mean, rstd, (T*)dx, rows, D, (const T*)dres)
   if (maxv <= 1) LNB_LAUNCH(1); else if (maxv <= 2) LNB_LAUNCH(2); else if (maxv <= 4) LNB_LAUNCH(4);
   else if (maxv <= 8) LNB_LAUNCH(8); else if (maxv <= 16) LNB_LAUNCH(16); else return DU_ERR_UNSUPPORTED;
 #undef LNB_LAUNCH
@@ -523,13 +532,13 @@ extern "C" int64_t du_reduce_ws_elems(int dtype, int G, int64_t P, int C) {
 }
 
 extern "C" int du_layernorm_bwd(int dtype, const void* x, const void* dy, const float* w, const float* mean, const float* rstd,
-                                void* dx, float* dwdb, int64_t rows, int D, float* ws, int64_t ws_elems, void* stream) {
+                                void* dx, float* dwdb, int64_t rows, int D, float* ws, int64_t ws_elems, const void* dres, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (rows <= 0 || D <= 0 || !x || !dy || !dx || !dwdb) return DU_ERR_BAD_ARG;
   const int vi = dtype == DU_BF16 ? 8 : 4;
   if (D % vi) return DU_ERR_BAD_ARG;
-  if (dtype == DU_F32) return ln_bwd_dispatch<float>(x, dy, w, mean, rstd, dx, dwdb, rows, D, ws, ws_elems, st);
-  if (dtype == DU_BF16) return ln_bwd_dispatch<bf16_t>(x, dy, w, mean, rstd, dx, dwdb, rows, D, ws, ws_elems, st);
+  if (dtype == DU_F32) return ln_bwd_dispatch<float>(x, dy, w, mean, rstd, dx, dwdb, rows, D, ws, ws_elems, dres, st);
+  if (dtype == DU_BF16) return ln_bwd_dispatch<bf16_t>(x, dy, w, mean, rstd, dx, dwdb, rows, D, ws, ws_elems, dres, st);
   return DU_ERR_BAD_ARG;
 }
 

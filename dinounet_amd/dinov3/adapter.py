@@ -145,13 +145,13 @@ class Extractor(nn.Module):
             self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
     def forward(self, query, reference_points, feat, spatial_shapes, level_start_index, H, W):
-        qn = ops.layer_norm(query, self.query_norm.weight, self.query_norm.bias, self.query_norm.eps)
+        qn, qres = ops.layer_norm_res(query, self.query_norm.weight, self.query_norm.bias, self.query_norm.eps)
         fn = ops.layer_norm(feat, self.feat_norm.weight, self.feat_norm.bias, self.feat_norm.eps)
-        query = self.attn(qn, reference_points, fn, spatial_shapes, level_start_index, None, residual=query)   # ADP:142-145
+        query = self.attn(qn, reference_points, fn, spatial_shapes, level_start_index, None, residual=qres)    # ADP:142-145
         if self.with_cffn:
-            f = ops.layer_norm(query, self.ffn_norm.weight, self.ffn_norm.bias, self.ffn_norm.eps)
+            f, fres = ops.layer_norm_res(query, self.ffn_norm.weight, self.ffn_norm.bias, self.ffn_norm.eps)
             mask = self.drop_path.mask(query.shape[0], query.device) if isinstance(self.drop_path, DropPath) else None
-            query = self.ffn(f, H, W, residual=query, row_scale=mask)                                            # ADP:148
+            query = self.ffn(f, H, W, residual=fres, row_scale=mask)                                             # ADP:148
         return query
 
 

@@ -601,6 +601,9 @@ def conv2d_stats(x, w, bias=None, stride=1, pad=1, x2=None):
     return y, (part if part.numel() else None)
 
 
+_DGRAD_NT = os.environ.get("DINOUNET_DGRAD_NT", "0") == "1"
+
+
 class _Linear(torch.autograd.Function):
     """y = x w^T + b [* row_scale per sample] [+ residual]   on (rows, K) matrices."""
 
@@ -614,8 +617,10 @@ class _Linear(torch.autograd.Function):
             elif wq.dim() != 2:
                 wq = wq.view(w.shape[0], -1)
         y = mm(x, wq, bias=_f32(bias), residual=residual, row_scale=row_scale, rs_rows=rs_rows, out_dtype=out_dtype)
-        # W^T (K, N) from the weight pack turns the data gradient into a contraction-contiguous product (direct-to-LDS kernel)
-        ctx.wT = PACK.get(w, PK_TRANSPOSE, x.dtype) if (w.dtype != x.dtype and w.shape[0] % 64 == 0) else None
+        # W^T (K, N) from the weight pack would turn the data gradient into a contraction-contiguous product for the direct-to-LDS
+        # kernel; measured on the dinounet_l step it is a wash against the transpose-read ROW x COL kernel (-1.4 ms / +1.7 ms), so it
+        # stays off by default (DINOUNET_DGRAD_NT=1 enables it)
+        ctx.wT = PACK.get(w, PK_TRANSPOSE, x.dtype) if (_DGRAD_NT and w.dtype != x.dtype and w.shape[0] % 64 == 0) else None
         ctx.save_for_backward(x, wq, row_scale)
         ctx.rs_rows = rs_rows
         ctx.has_bias = bias is not None
@@ -877,29 +882,49 @@ def layernorm_raw(x2d, w, b, eps, out_dtype, want_stats=False):
 
 
 class _LayerNorm(torch.autograd.Function):
+    """LayerNorm over the last dim.  With `with_res` the input is also handed through as a second output (identity) to be used as the
+    residual of the block (y = x + f(LN(x)), dinov3_adapter.py:142-148): the gradient that comes back on that branch is then added
+    inside the LayerNorm backward kernel instead of by a separate full-size add of the autograd engine."""
+
     @staticmethod
-    def forward(ctx, x, w, b, eps):
+    def forward(ctx, x, w, b, eps, with_res):
         xc = x.contiguous()
         wf, bf = _f32(w), _f32(b)
         y, mean, rstd = layernorm_raw(xc.view(-1, xc.shape[-1]), wf, bf, eps, xc.dtype, True)
         ctx.save_for_backward(xc, wf, mean, rstd)
+        ctx.with_res = with_res
+        ctx.set_materialize_grads(False)      # an unused residual output hands None (not a zero tensor) to backward
+        if with_res:
+            return y.view(x.shape), xc.view(x.shape).view_as(xc)
         return y.view(x.shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         xc, wf, mean, rstd = ctx.saved_tensors
         D = xc.shape[-1]
+        if dy is None:
+            return dres, None, None, None, None
         dyc = dy.contiguous()
         dx = torch.empty_like(xc)
         dwdb = torch.empty((D, 2), dtype=torch.float32, device=xc.device)
         ws, n = _reduce_ws(xc.dtype, 1, xc.numel() // D, D, xc.device)
+        dr = None
+        if dres is not None:
+            dr = dres.contiguous()
+            if dr.dtype != xc.dtype:
+                dr = cast(dr, xc.dtype)
         _lib.check(_lib.lib().du_layernorm_bwd(_code(xc.dtype), _p(xc), _p(dyc), _p(wf), _p(mean), _p(rstd), _p(dx), _p(dwdb),
-                                               xc.numel() // D, D, _p(ws), n, _st()), "du_layernorm_bwd")
-        return dx, dwdb[:, 0], dwdb[:, 1], None
+                                               xc.numel() // D, D, _p(ws), n, _p(dr), _st()), "du_layernorm_bwd")
+        return dx, dwdb[:, 0], dwdb[:, 1], None, None
 
 
 def layer_norm(x, w, b, eps):
-    return _LayerNorm.apply(x, w, b, eps)
+    return _LayerNorm.apply(x, w, b, eps, False)
+
+
+def layer_norm_res(x, w, b, eps):
+    """-> (LN(x), x): use the second output as the block's residual so its gradient is fused into the LayerNorm backward."""
+    return _LayerNorm.apply(x, w, b, eps, True)
 
 
 # ----------------------------------------------------------------------------------------------------

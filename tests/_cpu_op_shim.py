@@ -96,6 +96,10 @@ def layer_norm(x, w, b, eps):
     return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps).to(x.dtype)
 
 
+def layer_norm_res(x, w, b, eps):
+    return layer_norm(x, w, b, eps), x
+
+
 def layernorm_raw(x2d, w, b, eps, out_dtype, want_stats=False):
     return F.layer_norm(x2d.float(), (x2d.shape[-1],), w, b, eps).to(out_dtype), None, None
 
@@ -177,7 +181,7 @@ def attention(qkv, sin, cos, B, N, H, Dh, prefix, workspace):
     return o.transpose(1, 2).reshape(B * N, H * Dh).to(qkv.dtype)
 
 
-_NAMES = ["mm", "linear", "linear_cat", "conv1x1_cat", "conv1x1", "conv2d", "conv2d_stats", "conv_transpose2x2", "norm_act", "layer_norm", "layernorm_raw", "msda_prep", "msda",
+_NAMES = ["mm", "linear", "linear_cat", "conv1x1_cat", "conv1x1", "conv2d", "conv2d_stats", "conv_transpose2x2", "norm_act", "layer_norm", "layer_norm_res", "layernorm_raw", "msda_prep", "msda",
           "dwconv3x3", "dwconv_tokens", "maxpool3x3s2", "bilinear_add", "squeeze_excite", "nchw_to_nhwc", "nhwc_to_nchw_f32", "patchify16", "cast",
           "attention"]
 
