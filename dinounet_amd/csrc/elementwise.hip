@@ -806,3 +806,72 @@ extern "C" int du_pack_weights(const int64_t* table, const int64_t* bprefix, int
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, table, bprefix, n);
   return du_check_launch();
 }
+
+// ---------------- FiLM modulation of FAPM (dinounet_training.py:427-429): z = gamma * z_specific + beta ----------------
+// gb (rows, 2R) = [gamma | beta] (film generator output), z2 (rows, 2R) = [z_shared | z_specific] (the fused shared+specific GEMM);
+// z (rows, R).  Backward writes the full dgb and the z_specific half of dz2 (the z_shared half is filled by the film-generator
+// data gradient), so no slice / zero-fill / add launches of the autograd engine are needed.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void film_fwd_kernel(const T* __restrict__ gb, const T* __restrict__ z2, T* __restrict__ z, long rows, int R) {
+  constexpr int V = Elem<T>::VEC;
+  const int rv = R / V;
+  const long total = rows * rv;
+  GRID_STRIDE(i, total) {
+    const long row = i / rv;
+    const int c0 = (int)(i % rv) * V;
+    Vec16<T> g = as_vec<T>(*(const uint4*)(gb + row * 2 * R + c0));
+    Vec16<T> b = as_vec<T>(*(const uint4*)(gb + row * 2 * R + R + c0));
+    Vec16<T> s = as_vec<T>(*(const uint4*)(z2 + row * 2 * R + R + c0));
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(to_f32(g.v[j]) * to_f32(s.v[j]) + to_f32(b.v[j]));
+    *(uint4*)(z + row * R + c0) = as_u4(o);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void film_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ gb, const T* __restrict__ z2,
+                                                       T* __restrict__ dgb, T* __restrict__ dz2, long rows, int R) {
+  constexpr int V = Elem<T>::VEC;
+  const int rv = R / V;
+  const long total = rows * rv;
+  GRID_STRIDE(i, total) {
+    const long row = i / rv;
+    const int c0 = (int)(i % rv) * V;
+    Vec16<T> d = as_vec<T>(*(const uint4*)(dz + row * R + c0));
+    Vec16<T> g = as_vec<T>(*(const uint4*)(gb + row * 2 * R + c0));
+    Vec16<T> s = as_vec<T>(*(const uint4*)(z2 + row * 2 * R + R + c0));
+    Vec16<T> og, os;
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      og.v[j] = from_f32<T>(to_f32(d.v[j]) * to_f32(s.v[j]));     // d gamma
+      os.v[j] = from_f32<T>(to_f32(d.v[j]) * to_f32(g.v[j]));     // d z_specific
+    }
+    *(uint4*)(dgb + row * 2 * R + c0) = as_u4(og);
+    *(uint4*)(dgb + row * 2 * R + R + c0) = as_u4(d);             // d beta = dz
+    *(uint4*)(dz2 + row * 2 * R + R + c0) = as_u4(os);
+  }
+}
+}  // namespace
+
+extern "C" int du_film_fwd(int dtype, const void* gb, const void* z2, void* z, int64_t rows, int R, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (!gb || !z2 || !z || rows <= 0 || R <= 0 || R % v) return DU_ERR_BAD_ARG;
+  const long total = rows * (R / v);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(film_fwd_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, (const bf16_t*)gb, (const bf16_t*)z2, (bf16_t*)z, (long)rows, R),
+             hipLaunchKernelGGL(film_fwd_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, (const float*)gb, (const float*)z2, (float*)z, (long)rows, R));
+  return du_check_launch();
+}
+
+extern "C" int du_film_bwd(int dtype, const void* dz, const void* gb, const void* z2, void* dgb, void* dz2, int64_t rows, int R, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (!dz || !gb || !z2 || !dgb || !dz2 || rows <= 0 || R <= 0 || R % v) return DU_ERR_BAD_ARG;
+  const long total = rows * (R / v);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(film_bwd_kernel<bf16_t>, dim3(grid_1d(total)), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)gb, (const bf16_t*)z2, (bf16_t*)dgb, (bf16_t*)dz2, (long)rows, R),
+             hipLaunchKernelGGL(film_bwd_kernel<float>, dim3(grid_1d(total)), dim3(256), 0, st, (const float*)dz, (const float*)gb, (const float*)z2, (float*)dgb, (float*)dz2, (long)rows, R));
+  return du_check_launch();
+}

@@ -13,8 +13,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
-constexpr int STG_LD = BN + 4;
+constexpr int BM = 128;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -41,18 +40,21 @@ template <> struct Out4g<bf16_t> {
 // BK = 64, NST = 2: two buffers, vmcnt(0) + barrier per K step (64 KB LDS, 2 workgroups / CU).
 // BK = 32, NST = 3: three buffers, tile t+2 is issued while tile t is multiplied and only tile t+1 is waited for (counted
 //                   vmcnt, raw s_barrier: a plain __syncthreads() would drain the DMA queue); 48 KB LDS, 3 workgroups / CU.
-template <typename TC, int BK, int NST>
-__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
-  constexpr int TILE_EL = BM * BK;        // elements per operand tile
+// WNW = 2: 128 x 128 tile, 4 waves (2 x 2).  WNW = 4: 128 x 256 tile, 8 waves (2 x 4), 27 % less operand traffic per flop (the
+// 128 x 128 kernel moves 32 KB L2->LDS per 2.1 MFLOP, as many cycles as its MFMAs), one 96 KB workgroup per CU.
+template <typename TC, int BK, int NST, int WNW>
+__global__ __launch_bounds__(WNW * 128) void gemm_nt_glds_kernel(GemmParams P) {
+  constexpr int BN = WNW * 64, NW = 2 * WNW, NT = NW * 64, STG_LD = BN + 4;
+  constexpr int A_EL = BM * BK, B_EL = BN * BK, BUF_EL = A_EL + B_EL;   // elements per operand tile / per buffer
   constexpr int CH = BK / 8;              // 16-byte chunks per tile row
   constexpr int RPW = 64 / CH;            // tile rows covered by one wave-level global_load_lds (64 lanes x 16 B)
-  constexpr int ROUNDS = BM / (4 * RPW);  // staging rounds per operand
+  constexpr int RA = BM / (NW * RPW), RB = BN / (NW * RPW);   // staging rounds per operand
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* smem = (bf16_t*)smem_raw;       // buffer b: A tile at b*2*TILE_EL, B tile at b*2*TILE_EL + TILE_EL
+  bf16_t* smem = (bf16_t*)smem_raw;       // buffer b: A tile at b*BUF_EL, B tile right behind it
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
   int tile;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -67,24 +69,26 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
   // per-lane source rows of the staging rounds: round r covers tile rows (r*4 + wave)*RPW + lane/CH, physical chunk lane%CH.
   // Swizzle: physical chunk pc of row r holds logical chunk pc ^ swz(r); swz spreads the 16 rows of a ds_read_b128 lane group over
   // the 16 16-byte slots of a 256-byte bank row (BK = 64: 2 rows per bank row, BK = 32: 4 rows per bank row).
-  const bf16_t* asrc[ROUNDS];
-  const bf16_t* bsrc[ROUNDS];
+  const bf16_t* asrc[RA];
+  const bf16_t* bsrc[RB];
 #pragma unroll
-  for (int r = 0; r < ROUNDS; r++) {
-    const int row = (r * 4 + wave) * RPW + lane / CH;
+  for (int r = 0; r < RB; r++) {
+    const int row = (r * NW + wave) * RPW + lane / CH;
     const int lc = (lane % CH) ^ (BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3));
-    int ma = m0 + row; if (ma > P.M - 1) ma = P.M - 1;
+    if (r < RA) {
+      int ma = m0 + row; if (ma > P.M - 1) ma = P.M - 1;
+      asrc[r] = Ag + (long)ma * P.a.ld + lc * 8;
+    }
     int nb = n0 + row; if (nb > P.N - 1) nb = P.N - 1;
-    asrc[r] = Ag + (long)ma * P.a.ld + lc * 8;
     bsrc[r] = Bg + (long)nb * P.b.ld + lc * 8;
   }
   auto stage = [&](int buf, int kt) {
-    bf16_t* At = smem + buf * 2 * TILE_EL;
-    bf16_t* Bt = At + TILE_EL;
+    bf16_t* At = smem + buf * BUF_EL;
+    bf16_t* Bt = At + A_EL;
 #pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-      const int rowbase = (r * 4 + wave) * RPW;        // wave-uniform LDS destination (lane l lands at + l * 16 B)
-      __builtin_amdgcn_global_load_lds((gbl_void*)(asrc[r] + kt * BK), (lds_void*)(At + rowbase * BK), 16, 0, 0);
+    for (int r = 0; r < RB; r++) {
+      const int rowbase = (r * NW + wave) * RPW;       // wave-uniform LDS destination (lane l lands at + l * 16 B)
+      if (r < RA) __builtin_amdgcn_global_load_lds((gbl_void*)(asrc[r] + kt * BK), (lds_void*)(At + rowbase * BK), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_void*)(bsrc[r] + kt * BK), (lds_void*)(Bt + rowbase * BK), 16, 0, 0);
     }
   };
@@ -105,8 +109,8 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
 
   const int nk = P.K / BK;
   auto compute = [&](int buf) {
-    const bf16_t* Ac = smem + buf * 2 * TILE_EL;
-    const bf16_t* Bc = Ac + TILE_EL;
+    const bf16_t* Ac = smem + buf * BUF_EL;
+    const bf16_t* Bc = Ac + A_EL;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; kk++) {
       bf16x8 fa[2], fb[2];
@@ -132,10 +136,10 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
       __syncthreads();
     }
   } else {
-    // 3-stage ring: ROUNDS*2 DMA instructions per tile per thread; "vmcnt(ROUNDS*2)" = everything but the newest tile has landed
+    // 3-stage ring: RA + RB DMA instructions per tile per thread; "vmcnt(RA + RB)" = everything but the newest tile has landed
     stage(0, 0);
     if (nk > 1) stage(1, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ROUNDS * 2) : "memory");
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RA + RB) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int cur = 0;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
       int nxt2 = cur + 2; if (nxt2 >= 3) nxt2 -= 3;
       if (kt + 2 < nk) stage(nxt2, kt + 2);      // buffer last read in step kt-1 (everyone passed that step's barrier)
       compute(cur);
-      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ROUNDS * 2) : "memory");   // tile kt+1 landed, kt+2 may be in flight
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RA + RB) : "memory");       // tile kt+1 landed, kt+2 may be in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
       for (int r = 0; r < 16; r++)
         stg[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * STG_LD + (wn * 2 + j) * 32 + (lane & 31)] = acc[i][j][r];
     __syncthreads();
-    for (int v = tid; v < NVEC; v += 256) {
+    for (int v = tid; v < NVEC; v += NT) {
       const int row = v / C4, c4 = v % C4;
       const int m = m0 + ((row >> 5) * 2 + i) * 32 + (row & 31);
       const int n = n0 + c4 * 4;
@@ -214,20 +218,21 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmParams P) {
   }
 }
 
-template <typename TC, int BK, int NST>
+template <typename TC, int BK, int NST, int WNW>
 int launch(const du_gemm_args& a, hipStream_t st) {
-  constexpr int MAIN_BYTES = NST * 2 * BM * BK * 2;    // 64 KB (BK 64, 2 stages) / 48 KB (BK 32, 3 stages)
-  constexpr int STG_BYTES = 64 * STG_LD * 4;
+  constexpr int BN = WNW * 64;
+  constexpr int MAIN_BYTES = NST * (BM + BN) * BK * 2;  // 64 KB (128x128, BK 64, 2 stages) / 48 KB (BK 32, 3 stages) / 96 KB (128x256)
+  constexpr int STG_BYTES = 64 * (BN + 4) * 4;
   constexpr int LDS_BYTES = MAIN_BYTES > STG_BYTES ? MAIN_BYTES : STG_BYTES;
   GemmParams P = make_params(a, DU_PLAIN_ROW, DU_PLAIN_ROW, BM, BN, BK);
   dim3 grid(((a.M + BM - 1) / BM) * P.tiles_n, a.batch < 1 ? 1 : a.batch);
-  auto kfn = gemm_nt_glds_kernel<TC, BK, NST>;
+  auto kfn = gemm_nt_glds_kernel<TC, BK, NST, WNW>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return DU_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kfn, grid, dim3(256), LDS_BYTES, st, P);
+  hipLaunchKernelGGL(kfn, grid, dim3(WNW * 128), LDS_BYTES, st, P);
   return du_check_launch();
 }
 
@@ -244,9 +249,15 @@ int du_gemm_nt_glds(const du_gemm_args& a, hipStream_t st) {
   // CU and a deeper DMA queue), the 2-stage BK=64 kernel for K >= 1024 (fewer barriers per flop)
   const bool ring = var ? var[0] == '3' : a.K <= 512;
   if (ring) {
-    if (a.out_dtype == DU_BF16) return launch<bf16_t, 32, 3>(a, st);
-    return launch<float, 32, 3>(a, st);
+    if (a.out_dtype == DU_BF16) return launch<bf16_t, 32, 3, 2>(a, st);
+    return launch<float, 32, 3, 2>(a, st);
   }
-  if (a.out_dtype == DU_BF16) return launch<bf16_t, 64, 2>(a, st);
-  return launch<float, 64, 2>(a, st);
+  static const char* wide_env = getenv("DU_GLDS_WIDE");            // "1": 128 x 256 tiles (8 waves) for N >= 256, "0": never
+  const bool wide = wide_env ? (wide_env[0] == '1' && a.N >= 256) : false;
+  if (wide) {
+    if (a.out_dtype == DU_BF16) return launch<bf16_t, 64, 2, 4>(a, st);
+    return launch<float, 64, 2, 4>(a, st);
+  }
+  if (a.out_dtype == DU_BF16) return launch<bf16_t, 64, 2, 2>(a, st);
+  return launch<float, 64, 2, 2>(a, st);
 }

@@ -149,12 +149,8 @@ class FAPM(nn.Module):
         for i, x in enumerate(x_list):
             # shared + specific bases read the same D-channel input: one GEMM with 2*rank output columns (DT:423-424)
             sb, sp = self.shared_basis, self.specific_bases[i]
-            z2 = ops.conv1x1_cat(x, sb.weight, sp.weight, sb.bias, sp.bias)
-            z_shared, z_specific = z2[..., :rank], z2[..., rank:]
             fg = self.film_generators[i]
-            gb = ops.conv1x1(z_shared, fg.weight, fg.bias)                                     # DT:427
-            z = gb[..., :rank] * z_specific + gb[..., rank:]                                  # DT:428-429 FiLM
-            z = z.contiguous()
+            z = ops.fapm_project(x, sb.weight, sp.weight, sb.bias, sp.bias, fg.weight, fg.bias)      # DT:423-429, one autograd node
             r = self.refinement_blocks[i]
             t = ops.conv1x1(z, r[0].weight, r[0].bias)
             t = _norm_act(t, r[1], self._act, self.training)

@@ -705,6 +705,67 @@ def conv1x1_cat(x, w1, w2, b1=None, b2=None, out_dtype=None):
     return y.view(B, H, W, y.shape[-1])
 
 
+class _FAPMProject(torch.autograd.Function):
+    """FAPM projection of one scale (dinounet_training.py:423-429) as ONE autograd node:
+        z2 = x [W_shared; W_specific]^T + b        (one product, 2R columns)
+        gb = z2[:, :R] W_film^T + b_film           ([gamma | beta])
+        z  = gamma * z2[:, R:] + beta
+    The backward fills the two halves of dz2 in place (FiLM backward kernel + the film generator's data gradient written through a
+    strided output), so the channel slices cost no zero-fill / copy / add launches of the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x, ws, wp, bs, bp, wf, bf):
+        B, H, W, Cc, ld = _nhwc(x)
+        rows = B * H * W
+        R = ws.shape[0]
+        xm = x.as_strided((rows, Cc), (ld, 1), x.storage_offset())
+        dt = x.dtype
+        wq = PACK.get((ws.reshape(R, -1), wp.reshape(R, -1)), PK_CAST, dt)
+        if wq is None:
+            wq = torch.cat([ws.reshape(R, -1), wp.reshape(R, -1)], 0).to(dt)
+        bq = None
+        if bs is not None:
+            bq = PACK.get((bs, bp), PK_CAST, torch.float32)
+            if bq is None:
+                bq = torch.cat([bs, bp], 0).float()
+        wfq = PACK.get(wf.reshape(2 * R, -1), PK_CAST, dt)
+        if wfq is None:
+            wfq = wf.reshape(2 * R, -1).to(dt)
+        z2 = mm(xm, wq, bias=bq)
+        gb = mm(z2[:, :R], wfq, bias=_f32(bf))
+        z = torch.empty((rows, R), dtype=dt, device=x.device)
+        _lib.check(_lib.lib().du_film_fwd(_code(dt), _p(gb), _p(z2), _p(z), rows, R, _st()), "du_film_fwd")
+        ctx.save_for_backward(xm, wq, wfq, z2, gb)
+        ctx.conf = (R, tuple(ws.shape), tuple(wp.shape), tuple(wf.shape), bs is not None, bf is not None, (B, H, W, Cc))
+        return z.view(B, H, W, R)
+
+    @staticmethod
+    def backward(ctx, dz):
+        xm, wq, wfq, z2, gb = ctx.saved_tensors
+        R, s_ws, s_wp, s_wf, has_b, has_bf, (B, H, W, Cc) = ctx.conf
+        rows = xm.shape[0]
+        dt = xm.dtype
+        dz = dz.contiguous().view(rows, R)
+        dgb = torch.empty((rows, 2 * R), dtype=dt, device=dz.device)
+        dz2 = torch.empty((rows, 2 * R), dtype=dt, device=dz.device)
+        _lib.check(_lib.lib().du_film_bwd(_code(dt), _p(dz), _p(gb), _p(z2), _p(dgb), _p(dz2), rows, R, _st()), "du_film_bwd")
+        mm_dgrad(dgb, wfq, out=dz2[:, :R])                       # d z_shared, written into the left half of dz2
+        dwf = mm_wgrad(dgb, z2[:, :R])
+        dbf = colsum(dgb) if has_bf else None
+        dx = mm_dgrad(dz2, wq).view(B, H, W, Cc) if ctx.needs_input_grad[0] else None
+        dw = mm_wgrad(dz2, xm)
+        dbs = dbp = None
+        if has_b:
+            db = colsum(dz2)
+            dbs, dbp = db[:R], db[R:]
+        return dx, dw[:R].view(s_ws), dw[R:].view(s_wp), dbs, dbp, dwf.view(s_wf), dbf
+
+
+def fapm_project(x, ws, wp, bs, bp, wf, bf):
+    """x NHWC (B,H,W,D) -> FiLM-modulated z (B,H,W,R); ws / wp: shared / scale-specific basis (R,D,1,1), wf: film generator (2R,R,1,1)."""
+    return _FAPMProject.apply(x, ws, wp, bs, bp, wf, bf)
+
+
 def conv1x1(x, w, bias=None, out_dtype=None):
     """1x1 conv on NHWC = linear over pixels.  w (Cout, Cin, 1, 1)."""
     B, H, W, Cc, ld = _nhwc(x)

@@ -249,6 +249,11 @@ int du_dice_ce_finish(const float* sums, float* loss, float* coef, int K, int64_
 int du_dice_ce_bwd(const float* logits, const int64_t* target, const float* coef, const float* grad_out, float* dlogits, int B, int K,
                    int64_t HW, void* stream);
 
+/* ---- FAPM FiLM modulation (dinounet_training.py:427-429): z = gamma * z_specific + beta; gb (rows,2R) = [gamma|beta], z2 (rows,2R) =
+        [z_shared|z_specific], z (rows,R).  Backward writes all of dgb and the z_specific half of dz2. ---- */
+int du_film_fwd(int dtype, const void* gb, const void* z2, void* z, int64_t rows, int R, void* stream);
+int du_film_bwd(int dtype, const void* dz, const void* gb, const void* z2, void* dgb, void* dz2, int64_t rows, int R, void* stream);
+
 /* ---- elementwise helpers --------------------------------------------------------------------------- */
 int du_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
 /* NCHW fp32 image -> NHWC `dtype` with channels zero-padded to Cpad */

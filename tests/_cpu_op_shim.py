@@ -54,6 +54,13 @@ def conv1x1_cat(x, w1, w2, b1=None, b2=None, out_dtype=None):
     return linear_cat(x, w1, w2, b1, b2, out_dtype)
 
 
+def fapm_project(x, ws, wp, bs, bp, wf, bf):
+    R = ws.shape[0]
+    z2 = conv1x1_cat(x, ws, wp, bs, bp)
+    gb = conv1x1(z2[..., :R], wf, bf)
+    return gb[..., :R] * z2[..., R:] + gb[..., R:]
+
+
 def conv1x1(x, w, bias=None, out_dtype=None):
     return linear(x, w.view(w.shape[0], -1), bias, out_dtype=out_dtype)
 
@@ -181,7 +188,7 @@ def attention(qkv, sin, cos, B, N, H, Dh, prefix, workspace):
     return o.transpose(1, 2).reshape(B * N, H * Dh).to(qkv.dtype)
 
 
-_NAMES = ["mm", "linear", "linear_cat", "conv1x1_cat", "conv1x1", "conv2d", "conv2d_stats", "conv_transpose2x2", "norm_act", "layer_norm", "layer_norm_res", "layernorm_raw", "msda_prep", "msda",
+_NAMES = ["mm", "linear", "linear_cat", "conv1x1_cat", "fapm_project", "conv1x1", "conv2d", "conv2d_stats", "conv_transpose2x2", "norm_act", "layer_norm", "layer_norm_res", "layernorm_raw", "msda_prep", "msda",
           "dwconv3x3", "dwconv_tokens", "maxpool3x3s2", "bilinear_add", "squeeze_excite", "nchw_to_nhwc", "nhwc_to_nchw_f32", "patchify16", "cast",
           "attention"]
 
