@@ -393,7 +393,8 @@ static inline int norm_slots(int G, long P, int C, int vec) {
 // out[g][c][j] = sum over the strips of group g of part[g*strips + s][c][j].  Workgroup = COLS columns x (256 / COLS) strip
 // lanes; 4 independent partial sums per lane keep 4 loads in flight.
 template <int COLS>
-__global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int strips, int C2) {
+__global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int strips, int C2,
+                                                       int first_only) {
   constexpr int LANES = 256 / COLS;
   __shared__ float red[LANES][COLS + 1];
   const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
@@ -413,24 +414,28 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
   if (sl == 0 && c < C2) {
     float t = 0.f;
     for (int q = 0; q < LANES; q++) t += red[q][col];
-    out[(long)g * C2 + c] = t;
+    if (!first_only) out[(long)g * C2 + c] = t;
+    else if (first_only == 2) out[(long)g * C2 + (c & 1) * (C2 >> 1) + (c >> 1)] = t;   // planar: all first components, then all second
+    else if ((c & 1) == 0) out[((long)g * C2 + c) >> 1] = t;      // only the first component of every (sum, sum2) pair, compacted
   }
 }
 
 // launches the strip kernel through `launch(part)` and, in two-stage mode, the finalize kernel
 template <typename L>
-int strip_launch(float* out, float* ws, long ws_elems, int G, long strips, int C, hipStream_t st, L launch) {
+int strip_launch(float* out, float* ws, long ws_elems, int G, long strips, int C, hipStream_t st, L launch, int first_only = 0) {
   const long need = (long)G * strips * C * 2;
   float* part = (ws && ws_elems >= need) ? ws : nullptr;   // with scratch the result is always OVERWRITTEN (no zero-fill needed)
   launch(part);
   if (part) {
     if ((long)G * C * 2 >= 4096) {
       const int chunks = (C * 2 + 31) / 32;
-      hipLaunchKernelGGL(finalize_kernel<32>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, (const float*)part, out, G, (int)strips, C * 2);
+      hipLaunchKernelGGL(finalize_kernel<32>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, (const float*)part, out, G, (int)strips, C * 2, first_only);
     } else {
       const int chunks = (C * 2 + 3) / 4;
-      hipLaunchKernelGGL(finalize_kernel<4>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, (const float*)part, out, G, (int)strips, C * 2);
+      hipLaunchKernelGGL(finalize_kernel<4>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, (const float*)part, out, G, (int)strips, C * 2, first_only);
     }
+  } else if (first_only) {
+    return DU_ERR_BAD_ARG;      // the compacted form needs the two-stage path (scratch)
   }
   return du_check_launch();
 }
@@ -491,9 +496,11 @@ int ln_bwd_dispatch(const void* x, const void* dy, const float* w, const float* 
 #undef LNB_LAUNCH
   const int STRIP = pick_strip(1, rows, D, Elem<T>::VEC);
   long strips = (rows + STRIP - 1) / STRIP;
+  // with scratch the result is PLANAR (dw[D] then db[D]) so both gradients are contiguous tensors; the atomics fallback keeps the
+  // interleaved (D, 2) layout
   return strip_launch(dwdb, ws, ws_elems, 1, strips, D, st, [&](float* part) {
     hipLaunchKernelGGL(layernorm_bwd_wb_kernel<T>, dim3((unsigned)strips), block, 0, st, (const T*)x, (const T*)dy, mean, rstd, dwdb, rows, D, STRIP, part);
-  });
+  }, (ws && ws_elems >= (long)strips * D * 2) ? 2 : 0);
 }
 
 }  // namespace
@@ -516,10 +523,10 @@ extern "C" int du_strip_finalize(const float* part, float* out, int G, int strip
   if (!part || !out || G <= 0 || strips <= 0 || C <= 0) return DU_ERR_BAD_ARG;
   if ((long)G * C * 2 >= 4096) {
     const int chunks = (C * 2 + 31) / 32;
-    hipLaunchKernelGGL(finalize_kernel<32>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, part, out, G, strips, C * 2);
+    hipLaunchKernelGGL(finalize_kernel<32>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, part, out, G, strips, C * 2, 0);
   } else {
     const int chunks = (C * 2 + 3) / 4;
-    hipLaunchKernelGGL(finalize_kernel<4>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, part, out, G, strips, C * 2);
+    hipLaunchKernelGGL(finalize_kernel<4>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, part, out, G, strips, C * 2, 0);
   }
   return du_check_launch();
 }
@@ -555,6 +562,21 @@ extern "C" int du_chan_stats(int dtype, const void* x, int64_t ldx, float* sums,
     if (dtype == DU_BF16) hipLaunchKernelGGL(chan_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, sums, G, P, C, STRIP, part);
     else hipLaunchKernelGGL(chan_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, sums, G, P, C, STRIP, part);
   });
+}
+
+// column sums only: out[c] = sum_rows x[row][c]  (bias gradients); scratch du_reduce_ws_elems(dtype, 1, rows, C) is required
+extern "C" int du_colsum(int dtype, const void* x, int64_t ldx, float* out, int64_t rows, int C, float* ws, int64_t ws_elems, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (rows <= 0 || C <= 0 || C % v || ldx % v || !x || !out || !ws) return DU_ERR_BAD_ARG;
+  if (dtype != DU_BF16 && dtype != DU_F32) return DU_ERR_BAD_ARG;
+  const int STRIP = pick_strip(1, rows, C, v);
+  long strips = (rows + STRIP - 1) / STRIP;
+  dim3 grid((unsigned)strips), block(256);
+  return strip_launch(out, ws, ws_elems, 1, strips, C, st, [&](float* part) {
+    if (dtype == DU_BF16) hipLaunchKernelGGL(chan_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, out, 1, (long)rows, C, STRIP, part);
+    else hipLaunchKernelGGL(chan_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, out, 1, (long)rows, C, STRIP, part);
+  }, 1);
 }
 
 extern "C" int du_chan_dot(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, float* sums, int G, int64_t P, int C,

@@ -370,15 +370,12 @@ def _reduce_ws(dt, G, P, Cc, device):
 def colsum(x2d):
     """sum over rows of a (rows, C) matrix -> fp32 (C,)   (bias gradients)."""
     rows, Cc, ld = _rows2d(x2d)
-    sums = torch.empty((1, Cc, 2), dtype=torch.float32, device=x2d.device)    # overwritten by the two-stage reduction
+    out = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
     ws, n = _reduce_ws(x2d.dtype, 1, rows, Cc, x2d.device)
-    _lib.check(_lib.lib().du_chan_stats(_code(x2d.dtype), _p(x2d), ld, _p(sums), 1, rows, Cc, _p(ws), n, _st()), "du_chan_stats")
-    return sums[0, :, 0].contiguous()
+    _lib.check(_lib.lib().du_colsum(_code(x2d.dtype), _p(x2d), ld, _p(out), rows, Cc, _p(ws), n, _st()), "du_colsum")
+    return out
 
 
-# ----------------------------------------------------------------------------------------------------
-# convolution as implicit GEMM
-# ----------------------------------------------------------------------------------------------------
 def _geom(src, KH, KW, stride, pad, Ho, Wo, transposed, src2=None):
     B, Hi, Wi, C1, ld = _nhwc(src)
     g = ConvGeom()
@@ -967,7 +964,7 @@ class _LayerNorm(torch.autograd.Function):
             return dres, None, None, None, None
         dyc = dy.contiguous()
         dx = torch.empty_like(xc)
-        dwdb = torch.empty((D, 2), dtype=torch.float32, device=xc.device)
+        dwdb = torch.empty((2, D), dtype=torch.float32, device=xc.device)      # planar: dw, db (two-stage path)
         ws, n = _reduce_ws(xc.dtype, 1, xc.numel() // D, D, xc.device)
         dr = None
         if dres is not None:
@@ -976,7 +973,7 @@ class _LayerNorm(torch.autograd.Function):
                 dr = cast(dr, xc.dtype)
         _lib.check(_lib.lib().du_layernorm_bwd(_code(xc.dtype), _p(xc), _p(dyc), _p(wf), _p(mean), _p(rstd), _p(dx), _p(dwdb),
                                                xc.numel() // D, D, _p(ws), n, _p(dr), _st()), "du_layernorm_bwd")
-        return dx, dwdb[:, 0], dwdb[:, 1], None, None
+        return dx, dwdb[0], dwdb[1], None, None
 
 
 def layer_norm(x, w, b, eps):

@@ -142,7 +142,8 @@ int du_layernorm_fwd(int in_dtype, int out_dtype, const void* x, int64_t ldx, co
    up and OVERWRITES the result buffer.  With ws == NULL the partials are accumulated with fp32 atomics into a result buffer the
    caller must have zero-filled (same-cache-line atomics serialise: ~0.1 us each, measured, so this is the slow fallback). */
 int64_t du_reduce_ws_elems(int dtype, int G, int64_t pix_per_group, int C);
-/* dx (same dtype as x); dwdb fp32 (D, 2) receives (dw[c], db[c]) interleaved; scratch: du_reduce_ws_elems(dtype, 1, rows, D).
+/* dx (same dtype as x); dwdb fp32: with scratch (du_reduce_ws_elems(dtype, 1, rows, D) floats) PLANAR dw[D] then db[D]; with ws == NULL the
+   atomics fallback accumulates (dw[c], db[c]) interleaved into a zero-filled (D, 2) buffer.
    dres (nullable, same dtype/shape as x): gradient of a residual branch that by-passes the norm, added into dx. */
 int du_layernorm_bwd(int dtype, const void* x, const void* dy, const float* w, const float* mean, const float* rstd,
                      void* dx, float* dwdb, int64_t rows, int D, float* ws, int64_t ws_elems, const void* dres, void* stream);
@@ -151,6 +152,8 @@ int du_layernorm_bwd(int dtype, const void* x, const void* dy, const float* w, c
 /* sums[g][c][0..1] += (sum x, sum x^2) over the pixels of group g (G groups of `pix_per_group` pixels). */
 int du_chan_stats(int dtype, const void* x, int64_t ldx, float* sums, int G, int64_t pix_per_group, int C, float* ws,
                   int64_t ws_elems, void* stream);
+/* out[c] = sum over rows of x[row][c] (bias gradients); scratch of du_reduce_ws_elems(dtype, 1, rows, C) floats is required */
+int du_colsum(int dtype, const void* x, int64_t ldx, float* out, int64_t rows, int C, float* ws, int64_t ws_elems, void* stream);
 /* sums[g][c][0..1] += (sum a*b, sum a) over the pixels of group g (squeeze-excitation gate gradient, a = dy, b = x). */
 int du_chan_dot(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, float* sums, int G, int64_t pix_per_group, int C,
                 float* ws, int64_t ws_elems, void* stream);
