@@ -71,21 +71,21 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, lo
 }
 
 // dw[c][tap] += sum_pix x[pix+tap][c] * dy[pix][c]; db[c] += sum dy.  Block = strip of pixels, thread = (pixel lane, cvec);
-// per-thread register partials are reduced across the block's pixel lanes through LDS, so each block issues one atomic
-// per (channel, tap) instead of one per thread.
+// per-thread register partials are reduced across the block's pixel lanes through LDS in two passes of five taps (every thread
+// takes part in the column sums), so each block issues one store / atomic per (channel, tap).
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, long ldx, long xbs,
                                                                 const T* __restrict__ dy, long lddy, long dybs,
                                                                 float* __restrict__ dw, float* __restrict__ db, int B, int H,
                                                                 int W, int C, int strip, float* __restrict__ part) {
   constexpr int V = Elem<T>::VEC;
-  __shared__ float red[256 * V];
+  __shared__ float red[5][256 * V];
   const int cvn = C / V;
   const int cvb = min(cvn, 256);
   const int np = 256 / cvb;
   const int tp = threadIdx.x / cvb, tcv = threadIdx.x % cvb;
-  const long npix = (long)B * H * W;
-  const long p0 = (long)blockIdx.x * strip, p1 = min(npix, p0 + strip);
+  const int npix = B * H * W;
+  const int p0 = blockIdx.x * strip, p1 = min(npix, p0 + strip);
   for (int cv0 = 0; cv0 < cvn; cv0 += cvb) {
     const int cv = cv0 + tcv;
     const bool active = (cv < cvn) && (tp < np);
@@ -96,13 +96,15 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
 #pragma unroll
       for (int j = 0; j < V; j++) aw[k][j] = 0.f;
     if (active) {
-      for (long p = p0 + tp; p < p1; p += np) {
-        const int xo = (int)(p % W); long t = p / W;
-        const int yo = (int)(t % H); const int b = (int)(t / H);
+      int p = p0 + tp;
+      int xo = p % W, t = p / W;
+      int yo = t % H, b = t / H;
+      for (; p < p1; p += np) {
         Vec16<T> g = as_vec<T>(*(const uint4*)(dy + (long)b * dybs + ((long)yo * W + xo) * lddy + c0));
         float gf[V];
 #pragma unroll
         for (int j = 0; j < V; j++) { gf[j] = to_f32(g.v[j]); aw[9][j] += gf[j]; }
+        const T* xb = x + (long)b * xbs + c0;
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
           const int yi = yo + ky - 1;
@@ -111,34 +113,40 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
           for (int kx = 0; kx < 3; kx++) {
             const int xi = xo + kx - 1;
             if (xi < 0 || xi >= W) continue;
-            Vec16<T> v = as_vec<T>(*(const uint4*)(x + (long)b * xbs + ((long)yi * W + xi) * ldx + c0));
+            Vec16<T> v = as_vec<T>(*(const uint4*)(xb + ((long)yi * W + xi) * ldx));
 #pragma unroll
             for (int j = 0; j < V; j++) aw[ky * 3 + kx][j] += to_f32(v.v[j]) * gf[j];
           }
         }
+        xo += np;                                   // advance the pixel coordinate without divisions
+        while (xo >= W) { xo -= W; if (++yo == H) { yo = 0; b++; } }
       }
     }
+    const int ncol = cvb * V;                        // channel columns this pass covers
 #pragma unroll
-    for (int k = 0; k < 10; k++) {
+    for (int half = 0; half < 2; half++) {
 #pragma unroll
-      for (int j = 0; j < V; j++) red[threadIdx.x * V + j] = aw[k][j];
+      for (int k = 0; k < 5; k++)
+#pragma unroll
+        for (int j = 0; j < V; j++) red[k][(tp * cvb + tcv) * V + j] = aw[half * 5 + k][j];
       __syncthreads();
-      if (tp == 0 && cv < cvn) {
-#pragma unroll
-        for (int j = 0; j < V; j++) {
-          float sacc = 0.f;
-          for (int q = 0; q < np; q++) sacc += red[(q * cvb + tcv) * V + j];
-          if (part) part[((long)blockIdx.x * C + c0 + j) * 10 + k] = sacc;    // two-stage: dwconv_wgrad_finalize_kernel sums the strips
-          else if (k < 9) atomic_add_f32(dw + (c0 + j) * 9 + k, sacc);
-          else if (db) atomic_add_f32(db + c0 + j, sacc);
-        }
+      for (int o = threadIdx.x; o < 5 * ncol; o += 256) {
+        const int k5 = o / ncol, ci = o - k5 * ncol;
+        const int c = cv0 * V + ci;
+        if (c >= C) continue;
+        float sacc = 0.f;
+        for (int q = 0; q < np; q++) sacc += red[k5][q * ncol + ci];
+        const int k = half * 5 + k5;
+        if (part) part[((long)blockIdx.x * 10 + k) * C + c] = sacc;      // [strip][tap][C]; dwconv_wgrad_finalize_kernel sums the strips
+        else if (k < 9) atomic_add_f32(dw + c * 9 + k, sacc);
+        else if (db) atomic_add_f32(db + c, sacc);
       }
       __syncthreads();
     }
   }
 }
 
-// dw[c][k] (+)= sum_blocks part[blk][c][k] (k < 9), db[c] (+)= part[blk][c][9]; `accum` adds to the existing values (later image
+// dw[c][k] (+)= sum_blocks part[blk][k][c] (k < 9), db[c] (+)= part[blk][9][c]; `accum` adds to the existing values (later image
 // segments of the same depthwise kernel, dinov3_adapter.py:99-109)
 __global__ __launch_bounds__(256) void dwconv_wgrad_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                     float* __restrict__ db, int blocks, int C, int accum) {
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_finalize_kernel(const float*
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; q++) t += red[q][col];
-    const int c = i / 10, k = i - c * 10;
+    const int k = i / C, c = i - k * C;
     if (k < 9) dw[c * 9 + k] = accum ? dw[c * 9 + k] + t : t;
     else if (db) db[c] = accum ? db[c] + t : t;
   }
@@ -440,49 +448,61 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const T* __restrict__ x, 
   }
 }
 
-// gate MLP backward; a single workgroup walks the samples so the parameter gradients accumulate deterministically.
+// gate MLP backward.  One 1024-thread workgroup holds a chunk of samples in LDS and every phase is parallel over (sample, unit);
+// the parameter gradients are summed over the samples in a fixed order (deterministic, no atomics).
 // dsum (B,C,2): [..,0] = sum_pix dy * x.   Outputs: dpool (B,C) = d loss / d x[b,p,c] through the pooling path (already / P);
 // dW1 (R,C), db1 (R), dW2 (C,R), db2 (C) -- written (not accumulated).
-__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restrict__ dsum, const float* __restrict__ sums, float invP,
-                                                          const float* __restrict__ gate, const float* __restrict__ hidden,
-                                                          const float* __restrict__ W1, const float* __restrict__ W2,
-                                                          float* __restrict__ dpool, float* __restrict__ dW1, float* __restrict__ db1,
-                                                          float* __restrict__ dW2, float* __restrict__ db2, int B, int C, int R) {
-  extern __shared__ float sm[];   // dgp[C] | pooled[C] | h[R] | dhp[R]
+__global__ __launch_bounds__(1024) void se_gate_bwd_kernel(const float* __restrict__ dsum, const float* __restrict__ sums, float invP,
+                                                           const float* __restrict__ gate, const float* __restrict__ hidden,
+                                                           const float* __restrict__ W1, const float* __restrict__ W2,
+                                                           float* __restrict__ dpool, float* __restrict__ dW1, float* __restrict__ db1,
+                                                           float* __restrict__ dW2, float* __restrict__ db2, int B, int C, int R, int Bc) {
+  extern __shared__ float sm[];   // dgp[Bc][C] | pooled[Bc][C] | h[Bc][R] | dhp[Bc][R]
   float* dgp = sm;
-  float* pooled = sm + C;
-  float* h = sm + 2 * C;
-  float* dhp = sm + 2 * C + R;
+  float* pooled = dgp + Bc * C;
+  float* h = pooled + Bc * C;
+  float* dhp = h + Bc * R;
   const int tid = threadIdx.x;
-  for (int i = tid; i < C * R; i += 256) { dW1[i] = 0.f; dW2[i] = 0.f; }
-  for (int i = tid; i < C; i += 256) db2[i] = 0.f;
-  for (int i = tid; i < R; i += 256) db1[i] = 0.f;
-  __syncthreads();
-  for (int b = 0; b < B; b++) {
-    for (int c = tid; c < C; c += 256) {
-      const float g = gate[(long)b * C + c];
-      dgp[c] = dsum[((long)b * C + c) * 2] * g * (1.f - g);
-      pooled[c] = sums[((long)b * C + c) * 2] * invP;
+  for (int b0 = 0; b0 < B; b0 += Bc) {
+    const int nb = min(Bc, B - b0);
+    for (int i = tid; i < nb * C; i += 1024) {
+      const long gi = (long)b0 * C + i;
+      const float g = gate[gi];
+      dgp[i] = dsum[gi * 2] * g * (1.f - g);
+      pooled[i] = sums[gi * 2] * invP;
     }
-    for (int r = tid; r < R; r += 256) h[r] = hidden[(long)b * R + r];
+    for (int i = tid; i < nb * R; i += 1024) h[i] = hidden[(long)b0 * R + i];
     __syncthreads();
-    for (int r = tid; r < R; r += 256) {
+    for (int i = tid; i < nb * R; i += 1024) {            // dhp[b][r] = relu'(h) * sum_c W2[c][r] dgp[b][c]
+      const int bl = i / R, r = i - bl * R;
       float acc = 0.f;
-      for (int c = 0; c < C; c++) acc += W2[c * R + r] * dgp[c];
-      dhp[r] = h[r] > 0.f ? acc : 0.f;
+      for (int c = 0; c < C; c++) acc += W2[c * R + r] * dgp[bl * C + c];
+      dhp[i] = h[i] > 0.f ? acc : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < C * R; i += 256) {
-      { const int c = i / R, r = i - c * R; dW2[i] += dgp[c] * h[r]; }        // W2 is (C,R)
-      { const int r = i / C, c = i - r * C; dW1[i] += dhp[r] * pooled[c]; }   // W1 is (R,C)
+    for (int i = tid; i < C * R; i += 1024) {
+      float a2 = 0.f, a1 = 0.f;
+      { const int c = i / R, r = i - c * R; for (int bl = 0; bl < nb; bl++) a2 += dgp[bl * C + c] * h[bl * R + r]; }        // W2 is (C,R)
+      { const int r = i / C, c = i - r * C; for (int bl = 0; bl < nb; bl++) a1 += dhp[bl * R + r] * pooled[bl * C + c]; }   // W1 is (R,C)
+      dW2[i] = b0 ? dW2[i] + a2 : a2;
+      dW1[i] = b0 ? dW1[i] + a1 : a1;
     }
-    for (int c = tid; c < C; c += 256) {
-      db2[c] += dgp[c];
+    for (int c = tid; c < C; c += 1024) {
+      float a = 0.f;
+      for (int bl = 0; bl < nb; bl++) a += dgp[bl * C + c];
+      db2[c] = b0 ? db2[c] + a : a;
+    }
+    for (int r = tid; r < R; r += 1024) {
+      float a = 0.f;
+      for (int bl = 0; bl < nb; bl++) a += dhp[bl * R + r];
+      db1[r] = b0 ? db1[r] + a : a;
+    }
+    for (int i = tid; i < nb * C; i += 1024) {            // dpool[b][c] = invP * sum_r W1[r][c] dhp[b][r]
+      const int bl = i / C, c = i - bl * C;
       float acc = 0.f;
-      for (int r = 0; r < R; r++) acc += W1[r * C + c] * dhp[r];
-      dpool[(long)b * C + c] = acc * invP;
+      for (int r = 0; r < R; r++) acc += W1[r * C + c] * dhp[bl * R + r];
+      dpool[(long)b0 * C + i] = acc * invP;
     }
-    for (int r = tid; r < R; r += 256) db1[r] += dhp[r];
     __syncthreads();
   }
 }
@@ -717,8 +737,11 @@ extern "C" int du_se_gate_bwd(const float* dsum, const float* sums, float inv_co
   hipStream_t st = (hipStream_t)stream;
   if (!dsum || !sums || !gate || !hidden || !W1 || !W2 || !dpool || !dW1 || !db1 || !dW2 || !db2 || B <= 0 || C <= 0 || R <= 0)
     return DU_ERR_BAD_ARG;
-  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(1), dim3(256), (2 * C + 2 * R) * sizeof(float), st, dsum, sums, inv_count, gate, hidden, W1, W2,
-                     dpool, dW1, db1, dW2, db2, B, C, R);
+  int Bc = (int)(8000 / (long)(C + R));               // samples resident in LDS at once (<= 64 KB)
+  if (Bc < 1) return DU_ERR_UNSUPPORTED;
+  if (Bc > B) Bc = B;
+  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(1), dim3(1024), (size_t)2 * Bc * (C + R) * sizeof(float), st, dsum, sums, inv_count, gate, hidden,
+                     W1, W2, dpool, dW1, db1, dW2, db2, B, C, R, Bc);
   return du_check_launch();
 }
 

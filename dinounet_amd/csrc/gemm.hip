@@ -294,6 +294,15 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 }  // namespace
 
 int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st);   // gemm_bf16.hip
+int du_gemm_ragged_rows(const du_gemm_args& a);                      // gemm_bf16.hip
+int64_t du_gemm_skinny_ws_elems(int N, int K);                      // gemm_skinny.hip
+
+extern "C" int64_t du_gemm_ws_elems(const du_gemm_args* pa) {
+  if (!pa) return 0;
+  static const bool generic = getenv("DU_GEMM_GENERIC") != nullptr;
+  if (generic) return 0;
+  return du_gemm_ragged_rows(*pa) > 0 ? du_gemm_skinny_ws_elems(pa->N, pa->K) : 0;
+}
 
 extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
   if (!pa) return DU_ERR_BAD_ARG;

@@ -351,6 +351,28 @@ int launch_modes(const du_gemm_args& a, hipStream_t st) {
 }  // namespace
 
 int du_gemm_nt_glds(const du_gemm_args& a, hipStream_t st);   // gemm_glds.hip
+int du_gemm_skinny(const du_gemm_args& a, hipStream_t st);    // gemm_skinny.hip
+int64_t du_gemm_skinny_ws_elems(int N, int K);
+
+// Rows of a tall bf16 NT product that should leave the 128 x 128 tile grid: r = M % 128 when 0 < r <= 64 and the full tile rows
+// fill the resident workgroup slots (2 per CU) a whole number of times, at most 3 times (measured: with 4+ rounds the ragged tiles
+// hide behind the spread of tile finish times; tools/gemm_ragged.py).  0 = leave the product alone.
+int du_gemm_ragged_rows(const du_gemm_args& a) {
+  static const bool off = getenv("DU_GEMM_NO_RAGGED_SPLIT") != nullptr;      // debugging / A-B aid
+  if (off || a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.store_mode != DU_STORE_PLAIN) return 0;
+  if (a.batch > 1 || a.split_k > 1 || a.K % 64 || a.N < 96 || a.N % 4 || a.M < 1024 || a.lda % 8 || a.ldb % 8) return 0;
+  const int r = a.M % 128;
+  if (r == 0 || r > 64) return 0;
+  if (a.row_scale && (a.rs_rows < 1 || (a.M - r) % a.rs_rows)) return 0;
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0; hipDeviceProp_t prop;
+    slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? 2 * prop.multiProcessorCount : 512;
+  }
+  const long full = (long)(a.M / 128) * ((a.N + 127) / 128);
+  if (full % slots || full / slots > 3) return 0;
+  return r;
+}
 
 // returns DU_ERR_UNSUPPORTED when the generic kernel must be used instead
 int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
@@ -362,6 +384,31 @@ int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && a.ps_C % 4) return DU_ERR_UNSUPPORTED;
   if (a.c_batch_stride % 4) return DU_ERR_UNSUPPORTED;
   {
+    const int r = du_gemm_ragged_rows(a);
+    if (r > 0 && a.ws && a.ws_elems >= du_gemm_skinny_ws_elems(a.N, a.K)) {
+      // exact part on the tile kernel, the short ragged tail on the K-parallel skinny kernels (gemm_skinny.hip)
+      const long m0 = a.M - r;
+      const long osz = a.out_dtype == DU_BF16 ? 2 : 4;
+      du_gemm_args tail = a;
+      tail.M = r;
+      tail.A = (const char*)a.A + m0 * a.lda * 2;
+      tail.C = (char*)a.C + m0 * a.ldc * osz;
+      if (a.residual) tail.residual = (const char*)a.residual + m0 * a.ldr * osz;
+      if (a.row_scale) tail.row_scale = a.row_scale + m0 / a.rs_rows;
+      du_gemm_args head = a;
+      head.M = (int)m0;
+      // (forking the tail onto a side stream with event edges measured slower, eager and inside a hipGraph: 191.6 vs 194.0 slices/s)
+      int rc = du_gemm_nt_glds(head, st);
+      if (rc == DU_OK) {
+        rc = du_gemm_skinny(tail, st);
+        if (rc == DU_ERR_UNSUPPORTED) {
+          tail.ws = nullptr; tail.ws_elems = 0;
+          return a.out_dtype == DU_BF16 ? launch_modes<bf16_t>(tail, st) : launch_modes<float>(tail, st);
+        }
+        return rc;
+      }
+      if (rc != DU_ERR_UNSUPPORTED) return rc;
+    }
     int rc = du_gemm_nt_glds(a, st);      // direct-to-LDS kernel for the large contraction-contiguous products
     if (rc != DU_ERR_UNSUPPORTED) return rc;
   }

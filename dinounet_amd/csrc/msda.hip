@@ -89,23 +89,30 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ val
     for (int l = 0; l < L; l++) {
       const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
       const T* vbase = value + ((long)b * S + lsi[l]) * qstride + (long)m * D + c0;
-      for (int p = 0; p < P; p++) {
+      // every corner is gathered unconditionally from a clamped address with a zeroed weight when it is outside the level: no
+      // branch separates the loads, so all corners of all points are in flight together (the kernel is gather-latency bound)
+      auto point = [&](int p) {
         const float lw_ = lp[(l * P + p) * 2], lh_ = lp[(l * P + p) * 2 + 1];
         const float a = ap[l * P + p];
-        const float h = lh_ * H - 0.5f, w = lw_ * W - 0.5f;
-        if (h > -1.f && w > -1.f && h < (float)H && w < (float)W) {
-          Corner c = corners(h, w, H, W);
+        float h = lh_ * H - 0.5f, w = lw_ * W - 0.5f;
+        const bool in = h > -1.f && w > -1.f && h < (float)H && w < (float)W;
+        h = in ? h : 0.f; w = in ? w : 0.f;
+        Corner c = corners(h, w, H, W);
+        float v[4][CPT];
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            if (c.ok[k]) {
-              float v[CPT];
-              load_chan<T, CPT>(vbase + (long)c.off[k] * qstride, v);
-              const float f = c.wt[k] * a;
+        for (int k = 0; k < 4; k++) load_chan<T, CPT>(vbase + (long)((in && c.ok[k]) ? c.off[k] : 0) * qstride, v[k]);
 #pragma unroll
-              for (int j = 0; j < CPT; j++) acc[j] += f * v[j];
-            }
-          }
+        for (int k = 0; k < 4; k++) {
+          const float f = (in && c.ok[k]) ? c.wt[k] * a : 0.f;
+#pragma unroll
+          for (int j = 0; j < CPT; j++) acc[j] += f * v[k][j];
         }
+      };
+      if (P == 4) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) point(p);
+      } else {
+        for (int p = 0; p < P; p++) point(p);
       }
     }
     store_chan<T, CPT>(out + pair * (long)D + c0, acc);
@@ -155,8 +162,11 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ val
           const float lw_ = lp[s * 2], lh_ = lp[s * 2 + 1];
           const float a = ap[s];
           const float h = lh_ * H - 0.5f, w = lw_ * W - 0.5f;
-          if (h > -1.f && w > -1.f && h < (float)H && w < (float)W) {
-            Corner c = corners(h, w, H, W);
+          const bool in = h > -1.f && w > -1.f && h < (float)H && w < (float)W;
+          if (GV ? in : true) {
+            // without the grad_value atomics (GV = false) nothing below needs a branch: corners outside the level are gathered from a
+            // clamped address with zero coefficients, so the loads of all corners and samples overlap
+            Corner c = corners(in ? h : 0.f, in ? w : 0.f, H, W);
             const float hh = 1.f - c.lh, hw = 1.f - c.lw;
             // d(val)/dh and d(val)/dw corner coefficients (cuh:122-158)
             const float dh[4] = {-hw, -c.lw, hw, c.lw};
@@ -164,17 +174,34 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const T* __restrict__ val
             float val[CPT], ghw[CPT], gww[CPT];
 #pragma unroll
             for (int j = 0; j < CPT; j++) { val[j] = 0.f; ghw[j] = 0.f; gww[j] = 0.f; }
+            if constexpr (GV) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-              if (c.ok[k]) {
-                float v[CPT];
-                load_chan<T, CPT>(value + base + (long)c.off[k] * qstride, v);
+              for (int k = 0; k < 4; k++) {
+                if (c.ok[k]) {
+                  float v[CPT];
+                  load_chan<T, CPT>(value + base + (long)c.off[k] * qstride, v);
+#pragma unroll
+                  for (int j = 0; j < CPT; j++) {
+                    val[j] += c.wt[k] * v[j];
+                    ghw[j] += dh[k] * v[j];
+                    gww[j] += dw[k] * v[j];
+                    atomic_add_f32(gvalue + base + (long)c.off[k] * qstride + j, c.wt[k] * tg[j] * a);
+                  }
+                }
+              }
+            } else {
+              float v[4][CPT];
+#pragma unroll
+              for (int k = 0; k < 4; k++) load_chan<T, CPT>(value + base + (long)((in && c.ok[k]) ? c.off[k] : 0) * qstride, v[k]);
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const bool okk = in && c.ok[k];
+                const float wk = okk ? c.wt[k] : 0.f, dhk = okk ? dh[k] : 0.f, dwk = okk ? dw[k] : 0.f;
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {
-                  val[j] += c.wt[k] * v[j];
-                  ghw[j] += dh[k] * v[j];
-                  gww[j] += dw[k] * v[j];
-                  if constexpr (GV) atomic_add_f32(gvalue + base + (long)c.off[k] * qstride + j, c.wt[k] * tg[j] * a);
+                  val[j] += wk * v[k][j];
+                  ghw[j] += dhk * v[k][j];
+                  gww[j] += dwk * v[k][j];
                 }
               }
             }
@@ -347,7 +374,13 @@ __global__ __launch_bounds__(256) void msda_gv_finalize_kernel(const float* __re
 //
 // Workgroup = 1024 threads = 16 waves; it owns PT = 512 consecutive value pixels of one (batch, head) plane: wave w accumulates
 // pixels [32w, 32w+32) x 32 channels (one f32x16).  K step = 128 columns = 32 queries x 4 points:
-//   zero own previous non-zero -> barrier -> write new non-zeros + G^T tile -> barrier -> 8 MFMAs -> barrier.
+//   clear own previous non-zero, install the new column entries + G^T tile, OR the touched 32-pixel blocks into a step mask
+//   -> barrier -> waves whose pixel block was touched: 8 MFMAs (the others skip) -> barrier (skipped when nothing was touched).
+// The clear and the install of one column are done by the 4 corner lanes of that column -- adjacent lanes of ONE wave -- so program
+// order keeps them apart without a barrier.  Consecutive queries sample neighbouring pixels (reference point + learned offset), so
+// a step usually touches 2-3 of the 16 pixel blocks: the skip removes most of the dense-MFMA redundancy, and is only a speed-up
+// (any offset pattern stays correct).  A 64-column double-buffered variant (one barrier per step) measured slower: the per-step
+// scatter + barrier cost, not the barrier count, paces the loop.
 // ------------------------------------------------------------------------------------------------------
 constexpr int GV_PT = 512;        // plane pixels per workgroup
 constexpr int GV_KQ = 32;         // queries per K step
@@ -359,6 +392,7 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
                                                             float* __restrict__ gvalue, int N, int S, int M, int D, int Lq,
                                                             int q_per_chunk, int tiles, long chunk_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ unsigned step_mask[3];
   bf16_t* Wl = (bf16_t*)smem_raw;                       // [GV_PT][GV_WLD]
   bf16_t* Gt = Wl + GV_PT * GV_WLD;                     // [32 channels][GV_GLD]   (G^T: k contiguous)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -368,8 +402,8 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
   const int pix0 = ptile * GV_PT;
   const int q0 = blockIdx.x * q_per_chunk;
   const int q1 = min(Lq, q0 + q_per_chunk);
-  for (int i = tid; i < GV_PT * GV_WLD / 8; i += 1024) ((uint4*)Wl)[i] = make_uint4(0, 0, 0, 0);
-  for (int i = tid; i < 32 * GV_GLD / 8; i += 1024) ((uint4*)Gt)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < (GV_PT * GV_WLD + 32 * GV_GLD) / 8; i += 1024) ((uint4*)Wl)[i] = make_uint4(0, 0, 0, 0);
+  if (tid < 3) step_mask[tid] = 0u;
   __syncthreads();
 
   f32x16 acc;
@@ -381,52 +415,71 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
   // G role (all threads): query ql_g, channel c_g
   const int ql_g = tid >> 5, c_g = tid & 31;
   int my_off = -1;
-  for (int qs = q0; qs < q1; qs += GV_KQ) {
-    // ---- loads for this step (issued before the barrier so they overlap the previous step's MFMAs of other waves) ----
-    float wv = 0.f; int woff = -1;
+  // the per-step operands (sampling location, attention weight, grad_out element) are fetched one step ahead: the loads of step s+1 are in
+  // flight while step s is scattered and multiplied, so their HBM/L2 latency is off the critical path of the barrier-paced loop
+  float lx_n = 0.f, ly_n = 0.f, a_n = 0.f; bf16_t g_n = (bf16_t)0.f;
+  auto fetch = [&](int qs) {
+    lx_n = -4.f; ly_n = -4.f; a_n = 0.f; g_n = (bf16_t)0.f;
     if (tid < 512) {
       const int q = qs + ql_s;
       if (q < q1) {
         const long pr = ((long)b * Lq + q) * M + m;
-        const float lx = loc[(pr * 4 + p_s) * 2], ly = loc[(pr * 4 + p_s) * 2 + 1];
-        const float a = attn[pr * 4 + p_s];
-        const float h = ly * Hs - 0.5f, w = lx * Ws - 0.5f;
-        if (h > -1.f && w > -1.f && h < (float)Hs && w < (float)Ws) {
-          const int h0 = (int)floorf(h), w0 = (int)floorf(w);
-          const float lh = h - h0, lw = w - w0;
-          const int hy = h0 + (corner >> 1), wx = w0 + (corner & 1);
-          if (hy >= 0 && hy < Hs && wx >= 0 && wx < Ws) {
-            const int pl = hy * Ws + wx - pix0;
-            if (pl >= 0 && pl < GV_PT) {
-              wv = ((corner >> 1) ? lh : 1.f - lh) * ((corner & 1) ? lw : 1.f - lw) * a;
-              woff = pl * GV_WLD + col;
-            }
+        const float2 l2 = *(const float2*)(loc + (pr * 4 + p_s) * 2);
+        lx_n = l2.x; ly_n = l2.y;
+        a_n = attn[pr * 4 + p_s];
+      }
+    }
+    const int qg = qs + ql_g;
+    if (qg < q1 && c_g < D) g_n = gout[(((long)b * Lq + qg) * M + m) * D + c_g];
+  };
+  fetch(q0);
+  int par = 0;     // step index mod 3: three masks rotate so that a mask is cleared a full step before its next writers
+  for (int qs = q0; qs < q1; qs += GV_KQ, par = (par == 2 ? 0 : par + 1)) {
+    const float lx = lx_n, ly = ly_n, a = a_n;
+    const bf16_t gval = g_n;
+    if (qs + GV_KQ < q1) fetch(qs + GV_KQ);
+    if (tid < 512) {                                   // waves 0..7 (wave-uniform)
+      float wv = 0.f; int woff = -1; unsigned blk = 0u;
+      const float h = ly * Hs - 0.5f, w = lx * Ws - 0.5f;
+      if (h > -1.f && w > -1.f && h < (float)Hs && w < (float)Ws) {
+        const int h0 = (int)floorf(h), w0 = (int)floorf(w);
+        const float lh = h - h0, lw = w - w0;
+        const int hy = h0 + (corner >> 1), wx = w0 + (corner & 1);
+        if (hy >= 0 && hy < Hs && wx >= 0 && wx < Ws) {
+          const int pl = hy * Ws + wx - pix0;
+          if (pl >= 0 && pl < GV_PT) {
+            wv = ((corner >> 1) ? lh : 1.f - lh) * ((corner & 1) ? lw : 1.f - lw) * a;
+            woff = pl * GV_WLD + col;
+            blk = 1u << (pl >> 5);
           }
         }
       }
+      if (my_off >= 0) Wl[my_off] = (bf16_t)0.f;
+      if (woff >= 0) Wl[woff] = (bf16_t)wv;
+      my_off = woff;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) blk |= (unsigned)__shfl_xor((int)blk, o, 64);
+      if (lane == 0 && blk) atomicOr(&step_mask[par], blk);
     }
-    bf16_t gval = (bf16_t)0.f;
-    {
-      const int q = qs + ql_g;
-      if (q < q1 && c_g < D) gval = gout[(((long)b * Lq + q) * M + m) * D + c_g];
-    }
-    // ---- clear this thread's non-zero of the previous step, then install the new column entries ----
-    if (my_off >= 0) Wl[my_off] = (bf16_t)0.f;
-    __syncthreads();
-    if (woff >= 0) Wl[woff] = (bf16_t)wv;
-    my_off = woff;
     {
       bf16x4 g4; g4[0] = gval; g4[1] = gval; g4[2] = gval; g4[3] = gval;
       *(bf16x4*)(Gt + c_g * GV_GLD + ql_g * 4) = g4;
     }
     __syncthreads();
+    const unsigned touched = step_mask[par];           // block-uniform
+    // the mask of step s+2: its last readers (step s-1) are behind the barrier above, its next writers behind the next step's
+    if (tid == 0) step_mask[par == 0 ? 2 : par - 1] = 0u;
+    if (touched) {
+      if ((touched >> wave) & 1u) {
 #pragma unroll
-    for (int kk = 0; kk < 8; kk++) {
-      bf16x8 fa = *(const bf16x8*)(Wl + (wave * 32 + (lane & 31)) * GV_WLD + kk * 16 + (lane >> 5) * 8);
-      bf16x8 fb = *(const bf16x8*)(Gt + (lane & 31) * GV_GLD + kk * 16 + (lane >> 5) * 8);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+        for (int kk = 0; kk < 8; kk++) {
+          bf16x8 fa = *(const bf16x8*)(Wl + (wave * 32 + (lane & 31)) * GV_WLD + kk * 16 + (lane >> 5) * 8);
+          bf16x8 fb = *(const bf16x8*)(Gt + (lane & 31) * GV_GLD + kk * 16 + (lane >> 5) * 8);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+        }
+      }
+      __syncthreads();                                 // W / G^T are rewritten by the next step (nobody read them if nothing was touched)
     }
-    __syncthreads();
   }
   // lane: channel (lane & 31), pixels (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32-pixel block
   const int c = lane & 31;
@@ -530,6 +583,7 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
     const int PLD = ((size_t)S * (D + 4) * sizeof(float) <= 156 * 1024 && D % CPT == 0) ? D + 4 : D;
     const size_t lds_bytes = (size_t)S * PLD * sizeof(float);
     float* part = (ws && ws_elems >= (long)nchunk * plane_all && plane_all % 4 == 0 && nchunk > 1) ? ws : nullptr;
+    if (!part && hipMemsetAsync(gv, 0, (size_t)plane_all * sizeof(float), st) != hipSuccess) return DU_ERR_LAUNCH;   // atomic flush target
     dim3 grid(nchunk, N * M);
 #define MSDA_BWD_LDS(MAXLP) do { \
       auto kfn = msda_bwd_lds_kernel<T, CPT, MAXLP>; \
@@ -545,6 +599,7 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
     }
     return du_check_launch();
   }
+  if (hipMemsetAsync(gv, 0, (size_t)N * S * M * D * sizeof(float), st) != hipSuccess) return DU_ERR_LAUNCH;             // atomic scatter target
 #define MSDA_BWD(MAXLP) hipLaunchKernelGGL((msda_bwd_kernel<T, CPT, MAXLP, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value, shapes, lsi, loc, attn, (const T*)gout, gv, gl, ga, N, S, M, D, L, Lq, P, LPP, npairs)
   if (LP <= 4) MSDA_BWD(4); else if (LP <= 8) MSDA_BWD(8); else if (LP <= 16) MSDA_BWD(16); else return DU_ERR_UNSUPPORTED;
 #undef MSDA_BWD

@@ -392,6 +392,7 @@ class DinoUNet(nn.Module):
             raise RuntimeError("DinoUNet (dinounet_amd) runs on the MI355X through libdinounet_hip.so; move the module and "
                                "its input to the GPU (there is no CPU fallback)")
         ops.PACK.refresh()          # one launch: kernel-ready bf16 forms of every trainable weight for this step
+        ops.ZEROS.new_step()        # one fill: the fp32 accumulators of this step's split-K weight gradients
         return self.decoder(self.encoder(x.float()))
 
     def compute_conv_feature_map_size(self, input_size):

@@ -134,6 +134,13 @@ def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat,
     a.ps_H, a.ps_W, a.ps_C = ps
     if geom is not None:
         a.geom = geom
+    ws = None
+    if dtype == DU_BF16 and a_mode == PLAIN_ROW and b_mode == PLAIN_ROW and M >= 1024 and 0 < M % 128 <= 64:
+        # tall product with a short ragged last tile row: lend the library the scratch of its K-parallel tail kernels (gemm_skinny.hip)
+        n_ws = int(_lib.lib().du_gemm_ws_elems(C.byref(a)))
+        if n_ws > 0:
+            ws = torch.empty(n_ws, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+            a.ws, a.ws_elems = ws.data_ptr(), n_ws
     if PROFILE is not None:
         e0 = PROFILE.start()
         _lib.check(_lib.lib().du_gemm(C.byref(a), _st()), "du_gemm")
@@ -337,6 +344,58 @@ def mm_dgrad(dy, w, out=None):
 # split-K of the weight gradients: workgroups aimed for / minimum contraction rows per split.  Swept on the dinounet_l shapes
 # (tools/gemm_bench.py, profiles/r01_splitk_sweep.txt): 512 x 1024 for the linear layers (2 workgroups per CU, fewer fp32 atomics),
 # 1024 x 1024 for the convolutions (their M = Cout <= 128 tiles are small).
+class ZeroPool:
+    """fp32 accumulators of the split-K weight-gradient GEMMs (the kernel adds into them atomically, so they start at zero).
+    A train step asks for ~100 of them; each torch.zeros is its own >= 5 us fill launch even inside a hipGraph.  The pool records
+    the request sizes of one step and, from the next step on, serves the same sequence as views of ONE freshly allocated, once
+    filled buffer per step (a new buffer every step: gradients handed to autograd never alias a later step's).  Any deviation
+    from the recorded sequence falls back to plain torch.zeros for the rest of that step.  `new_step()` is called at the top of
+    DinoUNet.forward; DINOUNET_ZERO_POOL=0 disables."""
+    ALIGN = 64     # floats (256 B)
+
+    def __init__(self):
+        self.enabled = os.environ.get("DINOUNET_ZERO_POOL", "1") != "0"
+        self.plan = None
+        self.rec = []
+        self._reset()
+
+    def _reset(self):
+        self.buf = None
+        self.idx = 0
+        self.off = 0
+        self.ok = True
+
+    def new_step(self):
+        if self.rec:
+            self.plan = self.rec
+        self.rec = []
+        self._reset()
+
+    def zeros(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if not self.enabled:
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        self.rec.append(n)
+        if self.ok and self.plan is not None and self.idx < len(self.plan) and self.plan[self.idx] == n and \
+                (self.buf is None or self.buf.device == device):
+            if self.buf is None:
+                if self.idx != 0:
+                    self.ok = False
+                    return torch.zeros(shape, dtype=torch.float32, device=device)
+                total = sum((m + self.ALIGN - 1) // self.ALIGN * self.ALIGN for m in self.plan)
+                self.buf = torch.zeros(total, dtype=torch.float32, device=device)
+            v = self.buf[self.off:self.off + n].view(shape)
+            self.off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            self.idx += 1
+            return v
+        self.ok = False
+        return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
+ZEROS = ZeroPool()
+
 _SPLIT_TARGET = int(os.environ.get("DU_SPLIT_TARGET", "0"))
 _SPLIT_MINK = int(os.environ.get("DU_SPLIT_MINK", "1024"))
 
@@ -352,7 +411,7 @@ def mm_wgrad(dy, x):
     Mr, N, lda = _rows2d(dy)
     Mr2, K, ldb = _rows2d(x)
     assert Mr == Mr2 and dy.dtype == x.dtype
-    out = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+    out = ZEROS.zeros((N, K), dy.device)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     gemm_raw(dtype=_code(dy.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=PLAIN_COL, M=N, N=K, K=Mr,
              A=dy.data_ptr(), lda=lda, B=x.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=K,
@@ -511,7 +570,7 @@ def conv_wgrad(x, dy, KH, KW, stride, pad, x2=None):
     Bo, Ho, Wo, Cout, lddy = _nhwc(dy)
     g, B, ld, Ct = _geom(x, KH, KW, stride, pad, Ho, Wo, 0, x2)
     Ncol = KH * KW * Ct
-    out = torch.zeros((Cout, Ncol), dtype=torch.float32, device=x.device)
+    out = ZEROS.zeros((Cout, Ncol), x.device)
     npix = B * Ho * Wo
     tiles = ((Cout + 127) // 128) * ((Ncol + 127) // 128)
     gemm_raw(dtype=_code(x.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=IM2COL_COL, M=Cout, N=Ncol, K=npix,
@@ -546,6 +605,7 @@ class _Conv2d(torch.autograd.Function):
         if part is None:
             part = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)      # no zero tensor is built for the (never differentiated) statistics output
         return y, part
 
     @staticmethod
@@ -814,7 +874,7 @@ class _ConvT2x2(torch.autograd.Function):
                      N=Cin, K=4 * Cout, A=dy.data_ptr(), lda=lddy, B=wd.data_ptr(), ldb=4 * Cout, Cmat=dx.data_ptr(),
                      ldc=Cin, geom=g)
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros((Cin, 4 * Cout), dtype=torch.float32, device=dy.device)
+            gw = ZEROS.zeros((Cin, 4 * Cout), dy.device)
             npix = B * H * W
             tiles = ((Cin + 127) // 128) * ((4 * Cout + 127) // 128)
             gemm_raw(dtype=_code(dy.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=IM2COL_COL, M=Cin, N=4 * Cout,
@@ -1002,9 +1062,9 @@ def msda_backward_raw(value, shapes, lsi, loc, attn, grad_out):
     _req(value, shapes, lsi, loc, attn, grad_out)
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = loc.shape
-    gv = torch.zeros((N, S, M, D), dtype=torch.float32, device=value.device)
-    gl = torch.zeros(loc.shape, dtype=torch.float32, device=value.device)
-    ga = torch.zeros(attn.shape, dtype=torch.float32, device=value.device)
+    gv = torch.empty((N, S, M, D), dtype=torch.float32, device=value.device)      # all three are fully written by the library
+    gl = torch.empty(loc.shape, dtype=torch.float32, device=value.device)
+    ga = torch.empty(attn.shape, dtype=torch.float32, device=value.device)
     n = int(_lib.lib().du_msda_bwd_ws_elems(N, S, M, D, L, Lq, P))
     ws = torch.empty(max(n, 1), dtype=torch.float32, device=value.device)
     _lib.check(_lib.lib().du_msda_backward(_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(attn), _p(grad_out), _p(gv),

@@ -100,9 +100,15 @@ typedef struct {
   int32_t store_mode;
   int32_t ps_H, ps_W, ps_C; /* pixel-shuffle geometry: input grid H x W, Cout */
   du_conv_geom geom;  /* used by the IM2COL operand (at most one operand is IM2COL) */
+  float* ws; int64_t ws_elems; /* optional scratch, du_gemm_ws_elems(args) floats (0 = none wanted for this product); without it the
+                                  product still runs, on the plain tile kernels */
 } du_gemm_args;
 
 int du_gemm(const du_gemm_args* args, void* stream);
+/* Scratch du_gemm can use for `args` (ws / ws_elems are ignored here).  Non-zero for tall bf16 "NT" products whose row count
+   leaves a short ragged last tile row on an otherwise exactly filled GPU (the ViT's M = 8 * 1029): those rows then go through a
+   K-parallel skinny kernel pair instead of opening a nearly empty extra round of 128 x 128 tiles. */
+int64_t du_gemm_ws_elems(const du_gemm_args* args);
 
 /* ---- LDS-tiled direct 3x3 convolution (stride 1, pad 1), bf16 NHWC: decoder / FAPM / SPM-stem convs (dinounet_training.py:581-592,
         dinov3_adapter.py:243-249) and, with flipped + transposed weights, their data gradients --------------------------------------- */
@@ -183,8 +189,9 @@ int du_norm_act_bwd_dx(int dtype, const void* x, int64_t ldx, const void* dy, in
 int du_msda_forward(int dtype, const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                     const float* sampling_loc, const float* attn_weight, void* out, int N, int S, int M, int D, int L,
                     int Lq, int P, void* stream);
-/* grad_value (fp32, N,S,M,D), grad_sampling_loc, grad_attn_weight (fp32): zero-filled by the caller
-   (the reference allocates them with at::zeros, ms_deform_attn_cuda.cu:126-128). */
+/* grad_value (fp32, N,S,M,D), grad_sampling_loc, grad_attn_weight (fp32): OVERWRITTEN -- the caller need not zero them (the
+   reference allocates them with at::zeros, ms_deform_attn_cuda.cu:126-128; here the library clears grad_value itself on the
+   paths that scatter into it atomically and writes every element of the other two). */
 /* Optional scratch `ws` (du_msda_bwd_ws_elems floats, 0 = not needed for this shape): the LDS-resident kernel then writes one
    partial grad_value plane per query chunk with plain stores and a second kernel sums them into grad_value (OVERWRITING it)
    instead of flushing every chunk with global fp32 atomics. */

@@ -176,3 +176,32 @@ def test_host_glue_train_mode_and_grads():
         got = float(named[k].grad.norm())
         assert abs(got - n) <= 5e-3 * max(n, 1e-3 * gmax), (k, got, n)
     assert sorted(k for k, p in named.items() if p.requires_grad and p.grad is None) == meta["unused"]
+
+
+def test_zero_pool_one_buffer_per_step_without_aliasing():
+    """ops.ZeroPool: the second step with the same request sequence is served from ONE zero-filled buffer; a later step never hands
+    out memory that an earlier step's gradients still own; a deviating request falls back to plain zeros."""
+    from dinounet_amd import ops
+    pool = ops.ZeroPool()
+    pool.enabled = True
+    dev = torch.device("cpu")
+    pool.new_step()
+    a1, b1 = pool.zeros((4, 8), dev), pool.zeros((3,), dev)                      # recording step: plain tensors
+    assert a1.untyped_storage().data_ptr() != b1.untyped_storage().data_ptr()
+    pool.new_step()
+    a2, b2 = pool.zeros((4, 8), dev), pool.zeros((3,), dev)
+    assert a2.untyped_storage().data_ptr() == b2.untyped_storage().data_ptr() and a2.shape == (4, 8) and b2.shape == (3,)
+    assert float(a2.abs().sum()) == 0 and float(b2.abs().sum()) == 0
+    a2.add_(1.0)
+    b2.add_(2.0)
+    pool.new_step()
+    a3 = pool.zeros((4, 8), dev)
+    assert a3.untyped_storage().data_ptr() != a2.untyped_storage().data_ptr()
+    assert float(a3.abs().sum()) == 0 and float(a2.sum()) == 32 and float(b2.sum()) == 6
+    c3 = pool.zeros((5,), dev)                                                   # not the recorded size: fallback
+    assert c3.untyped_storage().data_ptr() != a3.untyped_storage().data_ptr() and float(c3.abs().sum()) == 0
+    d3 = pool.zeros((3,), dev)                                                   # rest of the step stays on the fallback
+    assert d3.untyped_storage().data_ptr() != a3.untyped_storage().data_ptr()
+    pool.new_step()                                                              # the deviating step became the new plan
+    a4, c4, d4 = pool.zeros((4, 8), dev), pool.zeros((5,), dev), pool.zeros((3,), dev)
+    assert a4.untyped_storage().data_ptr() == c4.untyped_storage().data_ptr() == d4.untyped_storage().data_ptr()

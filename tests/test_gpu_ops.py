@@ -60,6 +60,36 @@ def test_gemm_plain_epilogues(dt, M, N, K):
     assert rel(y, (x @ w.t() + b) * gam + res) < TOL[dt]
 
 
+@pytest.mark.parametrize("N,K", [(1024, 1024), (3072, 1024), (1024, 4096)])
+def test_gemm_ragged_tail_split(N, K):
+    """The ViT-L products (M = 8 * 1029 = 64 * 128 + 40): the last 40 rows leave the tile grid and run on the K-parallel skinny
+    kernels (gemm_skinny.hip).  Same result as the unsplit product (DU_GEMM_NO_RAGGED_SPLIT path = no scratch lent), every epilogue."""
+    import ctypes
+    from dinounet_amd import ops, _lib
+    from dinounet_amd._lib import ACT_GELU
+    d = dev()
+    M, bf = 8232, torch.bfloat16
+    x, w = q(gen(M, K, seed=1), bf).to(d, bf), q(gen(N, K, seed=2, scale=K ** -0.5), bf).to(d, bf)
+    b, gam, res = gen(N, seed=3).to(d), gen(N, seed=4).to(d), gen(M, N, seed=5).to(d)
+    rs = (torch.arange(1029, device=d) % 3 != 0).float() * 1.5          # one scale per 8 rows: the split keeps the row blocks aligned
+    # the library asks for scratch on this shape
+    a = _lib.GemmArgs()
+    a.dtype, a.out_dtype, a.a_mode, a.b_mode, a.M, a.N, a.K = _lib.DU_BF16, _lib.DU_BF16, 0, 0, M, N, K
+    a.lda, a.ldb, a.ldc, a.batch, a.split_k = K, K, N, 1, 1
+    assert int(_lib.lib().du_gemm_ws_elems(ctypes.byref(a))) > 0
+    ref = x.float() @ w.float().t()
+    y = ops.mm(x, w, bias=b, act=ACT_GELU)
+    assert y.dtype == bf and rel(y, F.gelu(ref + b)) < TOL[bf]
+    assert rel(y[-40:], F.gelu(ref + b)[-40:]) < TOL[bf]
+    r = res.clone()
+    y = ops.mm(x, w, bias=b, gamma=gam, residual=r, out=r, row_scale=rs, rs_rows=8)            # in-place fp32 residual stream
+    want = (ref + b) * gam * rs.repeat_interleave(8)[:, None] + res
+    assert y.dtype == torch.float32 and rel(y, want) < TOL[bf] and rel(y[-40:], want[-40:]) < TOL[bf]
+    # the tail rows are produced from fp32 partial sums: at least as close to the fp32 product as the tile kernel's rows
+    y32 = ops.mm(x, w, out_dtype=torch.float32)
+    assert rel(y32[-40:], ref[-40:]) < 2e-3 and rel(y32[:-40], ref[:-40]) < 2e-3
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_gemm_dgrad_wgrad(dt):
     from dinounet_amd import ops

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""GPU tuning aid: which Python call sites launch the small torch kernels (copies, fills, adds, casts) that remain around the
+HIP ops in one eager train step of the bench workload.  A TorchDispatchMode records every watched aten call with the innermost
+frames inside this repo (backward Functions included) and prints the call sites ordered by launch count.
+usage: python tools/glue_trace.py [--model dinounet_l] [--batch 8] [--top 60]"""
+import argparse
+import collections
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+WATCH = ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::mul", "aten::mul_", "aten::cat", "aten::_to_copy",
+         "aten::clone", "aten::contiguous", "aten::sum", "aten::div", "aten::sub", "aten::neg", "aten::zeros", "aten::zeros_like",
+         "aten::index", "aten::slice_backward", "aten::select_backward", "aten::masked_fill_", "aten::where", "aten::stack")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="dinounet_l")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--top", type=int, default=60)
+    a = ap.parse_args()
+    from oracle.refshim import PLANS_2D
+    from dinounet_amd.network_architecture import DinoUNet
+    from dinounet_amd.training import dc_and_ce_loss
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1234)
+    net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name=a.model, precision="bf16").to(dev).train()
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5)
+    g = torch.Generator(device="cpu").manual_seed(100)
+    x = torch.randn(a.batch, 3, a.size, a.size, generator=g).to(dev)
+    tgt = torch.randint(0, 2, (a.batch, 1, a.size, a.size), generator=g).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = dc_and_ce_loss(net(x), tgt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 12.0)
+        opt.step()
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+    sites = collections.Counter()
+
+    class Tracer(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = "aten::" + func.__name__.split(".")[0]
+            if name in WATCH or name in ("aten::empty_strided", "aten::bernoulli_", "aten::_foreach_add_", "aten::_foreach_mul_"):
+                frames = [f for f in traceback.extract_stack() if ("dinounet_amd" in f.filename or "tools/" in f.filename) and "glue_trace" not in f.filename]
+                where = " < ".join(f"{os.path.relpath(f.filename, ROOT)}:{f.lineno}" for f in frames[-3:][::-1]) or "(autograd engine / optimizer)"
+                shp = ""
+                for x_ in args:
+                    if torch.is_tensor(x_):
+                        shp = str(tuple(x_.shape)); break
+                    if isinstance(x_, (list, tuple)) and x_ and isinstance(x_[0], int):
+                        shp = str(tuple(x_)); break
+                sites[(name, where, shp)] += 1
+            return func(*args, **(kwargs or {}))
+
+    with Tracer():
+        step()
+    torch.cuda.synchronize()
+    print(f"# {sum(sites.values())} watched aten calls in one eager step")
+    for (name, where, shp), n in sites.most_common(a.top):
+        print(f"{n:5d}  {name:18s} {shp:28s} {where}")
+
+
+if __name__ == "__main__":
+    main()
