@@ -315,9 +315,12 @@ class DINOv3_Adapter(nn.Module):
             xi, _cls = layers[i]
             c = layer(xi, c, ref, shapes, H_c, W_c)
 
-        c2 = c[:, :n2].contiguous().view(B, H_c * 2, W_c * 2, D)                            # ADP:460-466
-        c3 = c[:, n2:n2 + n3].contiguous().view(B, H_c, W_c, D)
-        c4 = c[:, n2 + n3:].contiguous().view(B, H_c // 2, W_c // 2, D)
+        # ADP:460-466.  split (not three slices): its backward is ONE concatenation of the three gradients instead of three
+        # zero-filled full-size tensors, three slice copies and two adds
+        c2, c3, c4 = c.split([n2, n3, c.shape[1] - n2 - n3], dim=1)
+        c2 = c2.contiguous().view(B, H_c * 2, W_c * 2, D)
+        c3 = c3.contiguous().view(B, H_c, W_c, D)
+        c4 = c4.contiguous().view(B, H_c // 2, W_c // 2, D)
         c1 = ops.conv_transpose2x2(c2, self.up.weight, self.up.bias, residual=c1)          # ADP:467 (add fused in the epilogue)
         cs = [c1, c2, c3, c4]
         if self.add_vit_feature:                                                            # ADP:469-476

@@ -754,10 +754,19 @@ def linear_cat(x, w1, w2, b1=None, b2=None, out_dtype=None):
     return y.view(*shp[:-1], y.shape[-1])
 
 
+def _pixel_rows(x, rows, Cc, ld):
+    """NHWC tensor (pixel stride ld) as a (rows, C) matrix for the linear ops.  A plain view when x is dense: as_strided on a tensor
+    that requires grad records AsStridedBackward, whose backward zero-fills a flat buffer of the whole storage and copies the
+    gradient into it (two extra passes per 1x1 convolution, seen in the glue trace); only channel slices of wider tensors need it."""
+    if ld == Cc and x.is_contiguous():
+        return x.view(rows, Cc)
+    return x.as_strided((rows, Cc), (ld, 1), x.storage_offset())
+
+
 def conv1x1_cat(x, w1, w2, b1=None, b2=None, out_dtype=None):
     """two 1x1 convolutions of the same NHWC input as one product; w (Cout_i, Cin, 1, 1)."""
     B, H, W, Cc, ld = _nhwc(x)
-    xm = x.as_strided((B * H * W, Cc), (ld, 1), x.storage_offset())
+    xm = _pixel_rows(x, B * H * W, Cc, ld)
     y = _LinearCat.apply(xm, w1, w2, b1, b2, out_dtype)
     return y.view(B, H, W, y.shape[-1])
 
@@ -826,7 +835,7 @@ def fapm_project(x, ws, wp, bs, bp, wf, bf):
 def conv1x1(x, w, bias=None, out_dtype=None):
     """1x1 conv on NHWC = linear over pixels.  w (Cout, Cin, 1, 1)."""
     B, H, W, Cc, ld = _nhwc(x)
-    xm = x.as_strided((B * H * W, Cc), (ld, 1), x.storage_offset())
+    xm = _pixel_rows(x, B * H * W, Cc, ld)
     y = _Linear.apply(xm, w.view(w.shape[0], -1), bias, None, None, 0, out_dtype)
     return y.view(B, H, W, w.shape[0])
 

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--top", type=int, default=60)
+    ap.add_argument("--profiler", action="store_true", help="torch.profiler view instead: every watched op with input shapes, split by thread (the autograd engine's own copies / zero fills are invisible to the dispatch-mode tracer)")
     a = ap.parse_args()
     from oracle.refshim import PLANS_2D
     from dinounet_amd.network_architecture import DinoUNet
@@ -46,6 +47,23 @@ def main():
     for _ in range(2):
         step()
     torch.cuda.synchronize()
+    if a.profiler:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        main_thread = None
+        rows = collections.Counter()
+        for ev in prof.events():
+            if main_thread is None and ev.name.startswith("aten::"):
+                main_thread = ev.thread
+            if ev.name in ("aten::copy_", "aten::fill_", "aten::add", "aten::add_", "aten::mul", "aten::cat", "aten::index", "aten::div", "aten::neg", "aten::sum"):
+                shp = str([tuple(x) for x in (ev.input_shapes or []) if x])[:70]
+                rows[(ev.name, "fwd" if ev.thread == main_thread else "bwd", shp)] += 1
+        print(f"# {sum(rows.values())} launches-ish in one eager step (leaf aten ops only)")
+        for (name, th, shp), n in rows.most_common(a.top):
+            print(f"{n:5d}  {th}  {name:14s} {shp}")
+        return
     import traceback
     from torch.utils._python_dispatch import TorchDispatchMode
     sites = collections.Counter()
