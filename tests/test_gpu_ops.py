@@ -359,6 +359,7 @@ def test_msda_bf16_mfma_grad_value_odd_planes(N, Hs, Ws, Lq, Dh):
     shapes, lsi = torch.tensor([[Hs, Ws]], device=d), torch.zeros(1, dtype=torch.long, device=d)
     vg, lg, ag = v.to(d, dt).requires_grad_(True), loc.to(d).requires_grad_(True), a.to(d).requires_grad_(True)
     out = ops.msda(vg, shapes, lsi, lg, ag)
+    assert rel(out, O.msda_core(v, [(Hs, Ws)], loc, a)) < 2e-2        # forward from the LDS-resident plane when D/4 is a power of two
     gv, gl, ga = torch.autograd.grad(out, (vg, lg, ag), go.to(d, dt))
     assert rel(gv, gvr) < 2e-2 and rel(ga, gar) < 2e-2 and rel(gl, glr) < 1e-1
 
