@@ -39,6 +39,7 @@ def parse():
                     help="capture the train step into a hipGraph (auto = on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--torch-sgd", action="store_true", help="torch clip_grad_norm_ + torch.optim.SGD instead of the fused HIP clip+SGD (same arithmetic)")
     return ap.parse_args()
 
 
@@ -65,7 +66,11 @@ def main():
     net = net.to(dev).train()
     params = [p for p in net.parameters() if p.requires_grad]
     reducer = GradAllReducer(net, world) if (world > 1 or force_pg) else None
-    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5)   # nnUNetTrainer.py:486, DT:1024
+    if a.torch_sgd:
+        opt = torch.optim.SGD(params, lr=1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5)   # nnUNetTrainer.py:486, DT:1024
+    else:
+        from dinounet_amd.optim import FusedClipSGD                                                # same update + clip 12 (TRN:922), csrc/optim.hip
+        opt = FusedClipSGD(params, lr=1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5, max_norm=12.0)
 
     g = torch.Generator(device="cpu").manual_seed(100 + rank)
     x = torch.randn(a.batch, 3, a.size, a.size, generator=g).to(dev)

@@ -6,6 +6,8 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from .optim import FusedClipSGD
+
 
 class _AllReduceSumGrad(torch.autograd.Function):
     """dinounet/utilities/ddp_allgather.py:25-48 followed by .sum(0): all-gather forward / all-reduce backward."""
@@ -81,8 +83,12 @@ class TrainStep:
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
-        torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
-        self.opt.step()
+        if isinstance(self.opt, FusedClipSGD):              # clip + SGD in three launches (csrc/optim.hip)
+            self.opt.max_norm = self.max_norm
+            self.opt.step()
+        else:
+            torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
+            self.opt.step()
         return loss.detach()
 
     def __call__(self, x=None, tgt=None):
@@ -106,5 +112,7 @@ class TrainStep:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.loss = self._step()
+        if isinstance(self.opt, FusedClipSGD):
+            self.opt.refresh_hyper()                        # the captured step re-reads lr & co. from the pinned host buffer
         self.graph.replay()
         return self.loss

@@ -282,6 +282,18 @@ int du_pack_weights(const int64_t* table, const int64_t* bprefix, int n, int64_t
 const char* du_version(void);
 int du_device_ok(void); /* 1 if the current device is gfx950 */
 
+/* ---- fused clip_grad_norm_ + Nesterov SGD over all trainable tensors (replaces
+   torch.nn.utils.clip_grad_norm_(params, 12) + torch.optim.SGD.step(), dinounet/training/nnUNetTrainer/nnUNetTrainer.py:486,922-924).
+   table: n_tensors rows of 4 x int64 [param ptr, grad ptr, momentum-buffer ptr, numel] (fp32 tensors, contiguous);
+   bprefix[i] = first workgroup of row i, bprefix[n_tensors] = nblocks, 4096 elements per workgroup;
+   hyper (DEVICE, fp32): [lr, momentum, weight_decay, max_norm, nesterov (0/1)] -- read at run time, so a captured graph follows a
+   learning-rate schedule; ws: du_clip_sgd_ws_elems(nblocks) floats, ws[nblocks] = total gradient norm, ws[nblocks+1] = clip coefficient
+   on return.  Gradients are scaled in place by the coefficient (as clip_grad_norm_ does); zero-filled momentum buffers on the first
+   step reproduce torch's "buf = d_p". */
+int64_t du_clip_sgd_ws_elems(int nblocks);
+int du_clip_sgd(const int64_t* table, const int64_t* bprefix, int n_tensors, int nblocks, const float* hyper, float* ws,
+                int64_t ws_elems, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -589,7 +589,11 @@ def test_train_step_hipgraph_matches_eager():
     for mode in (False, True):
         net = build()
         params = [p for p in net.parameters() if p.requires_grad]
-        opt = torch.optim.SGD(params, 1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5)
+        if mode:      # the captured step also runs the fused clip + SGD (csrc/optim.hip); the eager one torch's clip_grad_norm_ + SGD
+            from dinounet_amd.optim import FusedClipSGD
+            opt = FusedClipSGD(params, 1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5)
+        else:
+            opt = torch.optim.SGD(params, 1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5)
         ts = TrainStep(net, opt, params, x.shape, tgt.shape, d, graph=mode, warmup=2)
         ts(x, tgt)
         ls = [float(ts()) for _ in range(7)]
@@ -599,3 +603,36 @@ def test_train_step_hipgraph_matches_eager():
         losses[mode] = ls
     print("eager", losses[False], "graph", losses[True])
     assert max(abs(a - b) for a, b in zip(losses[False], losses[True])) < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------ fused clip + SGD
+@pytest.mark.parametrize("scale,max_norm", [(1.0, 12.0), (50.0, 12.0), (1.0, None)])
+def test_fused_clip_sgd_matches_torch(scale, max_norm):
+    """FusedClipSGD == clip_grad_norm_(max_norm) + torch.optim.SGD(momentum 0.99, nesterov, weight decay) over several steps
+    (clip active / inactive / disabled), odd tensor sizes, a parameter without gradient, a learning-rate change between steps."""
+    from dinounet_amd.optim import FusedClipSGD
+    d = dev()
+    shapes = [(1024, 256), (37,), (3, 5, 7), (4097,), (256, 64, 3, 3), (1,), (8192,)]
+    pa = [torch.nn.Parameter(gen(*s_, seed=10 + i).to(d)) for i, s_ in enumerate(shapes)]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    pa.append(torch.nn.Parameter(torch.ones(5, device=d)))       # never receives a gradient
+    pb.append(torch.nn.Parameter(torch.ones(5, device=d)))
+    oa = FusedClipSGD(pa, lr=1e-2, momentum=0.99, weight_decay=3e-5, nesterov=True, max_norm=max_norm)
+    ob = torch.optim.SGD(pb, lr=1e-2, momentum=0.99, weight_decay=3e-5, nesterov=True)
+    for it in range(4):
+        for i in range(len(shapes)):
+            g = gen(*shapes[i], seed=100 * it + i).to(d) * scale
+            pa[i].grad, pb[i].grad = g.clone(), g.clone()
+        if it == 2:
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 3e-3
+        oa.step()
+        tn = torch.nn.utils.clip_grad_norm_(pb, max_norm) if max_norm is not None else torch.linalg.vector_norm(torch.stack([p.grad.norm() for p in pb[:-1]]))
+        ob.step()
+        assert abs(float(oa.total_norm) - float(tn)) < 1e-5 * float(tn)
+        for x, y in zip(pa, pb):
+            assert rel(x, y) < 1e-6
+            if x.grad is not None:
+                assert rel(x.grad, y.grad) < 1e-6                     # gradients are left clipped, like clip_grad_norm_
+    for x, y in zip(pa[:-1], pb[:-1]):
+        assert rel(oa.state[x]["momentum_buffer"], ob.state[y]["momentum_buffer"]) < 1e-6
+    assert torch.equal(pa[-1].detach().cpu(), torch.ones(5))
