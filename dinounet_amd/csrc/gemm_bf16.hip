@@ -169,7 +169,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int m0 = (tile / P.tiles_n) * BM, n0 = (tile % P.tiles_n) * BN;
+  int tm, tn;                                   // grouped tile order, see gemm_glds.hip
+  if (P.group_m > 1) {
+    const int band = P.group_m * P.tiles_n;
+    const int g = tile / band, l = tile - g * band;
+    const int first = g * P.group_m;
+    const int gsz = min(P.tiles_m - first, P.group_m);
+    tn = l / gsz; tm = first + (l - tn * gsz);
+  } else {
+    tm = tile / P.tiles_n; tn = tile - tm * P.tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.y;
   const int batch = z / P.split_k, split = z % P.split_k;
   const int kbeg = split * P.k_per_split;
@@ -315,7 +325,10 @@ int launch_cfg(const du_gemm_args& a, hipStream_t st) {
   constexpr int STG_BYTES = WM * 32 * (BN + 4) * 4;
   constexpr int LDS_BYTES = MAIN_BYTES > STG_BYTES ? MAIN_BYTES : STG_BYTES;
   GemmParams P = make_params(a, AMODE, BMODE, BM, BN, BK);
-  dim3 grid(((a.M + BM - 1) / BM) * P.tiles_n, (a.batch < 1 ? 1 : a.batch) * P.split_k);
+  P.tiles_m = (a.M + BM - 1) / BM;
+  static const int group_env = getenv("DU_GEMM_GROUP_M") ? atoi(getenv("DU_GEMM_GROUP_M")) : 8;    // 0 / 1: row-major tile order
+  P.group_m = group_env;
+  dim3 grid(P.tiles_m * P.tiles_n, (a.batch < 1 ? 1 : a.batch) * P.split_k);
   auto kfn = gemm_bf16_kernel<AMODE, BMODE, TC, WM, WN, TM, TN>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
@@ -355,8 +368,9 @@ int du_gemm_skinny(const du_gemm_args& a, hipStream_t st);    // gemm_skinny.hip
 int64_t du_gemm_skinny_ws_elems(int N, int K);
 
 // Rows of a tall bf16 NT product that should leave the 128 x 128 tile grid: r = M % 128 when 0 < r <= 64 and the full tile rows
-// fill the resident workgroup slots (2 per CU) a whole number of times, at most 3 times (measured: with 4+ rounds the ragged tiles
-// hide behind the spread of tile finish times; tools/gemm_ragged.py).  0 = leave the product alone.
+// fill the resident workgroup slots (2 per CU) a whole number of times, at most twice (measured, tools/gemm_ragged.py: one round --
+// proj 39 -> 36 us, fc2 122 -> 95 us; three rounds (qkv) 82 -> 85 us and four (fc1) no penalty to remove: the ragged tiles hide
+// behind the spread of tile finish times).  0 = leave the product alone.
 int du_gemm_ragged_rows(const du_gemm_args& a) {
   static const bool off = getenv("DU_GEMM_NO_RAGGED_SPLIT") != nullptr;      // debugging / A-B aid
   if (off || a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.store_mode != DU_STORE_PLAIN) return 0;
@@ -370,7 +384,7 @@ int du_gemm_ragged_rows(const du_gemm_args& a) {
     slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? 2 * prop.multiProcessorCount : 512;
   }
   const long full = (long)(a.M / 128) * ((a.N + 127) / 128);
-  if (full % slots || full / slots > 3) return 0;
+  if (full % slots || full / slots > 2) return 0;
   return r;
 }
 

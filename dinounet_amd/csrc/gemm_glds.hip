@@ -61,7 +61,20 @@ __global__ __launch_bounds__(WNW * 128) void gemm_nt_glds_kernel(GemmParams P) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int m0 = (tile / P.tiles_n) * BM, n0 = (tile % P.tiles_n) * BN;
+  // Tile order inside an XCD's run: bands of group_m tile rows walked column by column, so the ~64 workgroups resident on an XCD
+  // cover a square-ish (8 x 8) patch of C and share 8 A row panels + 8 B column panels through its L2.  Row-major order made them
+  // 2-3 rows x all columns: every round re-fetched the whole B matrix from the fabric (FETCH_SIZE 3.2x the algorithmic bytes).
+  int tm, tn;
+  if (P.group_m > 1) {
+    const int band = P.group_m * P.tiles_n;
+    const int g = tile / band, l = tile - g * band;
+    const int first = g * P.group_m;
+    const int gsz = min(P.tiles_m - first, P.group_m);
+    tn = l / gsz; tm = first + (l - tn * gsz);
+  } else {
+    tm = tile / P.tiles_n; tn = tile - tm * P.tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
   const int batch = blockIdx.y;
   const bf16_t* Ag = (const bf16_t*)P.a.p + (long)batch * P.a.bstride;
   const bf16_t* Bg = (const bf16_t*)P.b.p + (long)batch * P.b.bstride;
@@ -225,7 +238,10 @@ int launch(const du_gemm_args& a, hipStream_t st) {
   constexpr int STG_BYTES = 64 * (BN + 4) * 4;
   constexpr int LDS_BYTES = MAIN_BYTES > STG_BYTES ? MAIN_BYTES : STG_BYTES;
   GemmParams P = make_params(a, DU_PLAIN_ROW, DU_PLAIN_ROW, BM, BN, BK);
-  dim3 grid(((a.M + BM - 1) / BM) * P.tiles_n, a.batch < 1 ? 1 : a.batch);
+  P.tiles_m = (a.M + BM - 1) / BM;
+  static const int group_env = getenv("DU_GLDS_GROUP_M") ? atoi(getenv("DU_GLDS_GROUP_M")) : 8;   // 0 / 1: row-major tile order
+  P.group_m = group_env;
+  dim3 grid(P.tiles_m * P.tiles_n, a.batch < 1 ? 1 : a.batch);
   auto kfn = gemm_nt_glds_kernel<TC, BK, NST, WNW>;
   static bool attr_set = false;
   if (!attr_set) {

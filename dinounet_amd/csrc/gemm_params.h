@@ -22,6 +22,7 @@ struct GemmParams {
   const void* residual; long ldr;
   int store_mode, ps_H, ps_W, ps_C;
   int tiles_n;
+  int tiles_m, group_m;   // grouped tile order (gemm_glds.hip): bands of group_m tile rows are walked column by column; 0 = row-major
 };
 
 __device__ __forceinline__ int div_small(int x, int d) {

@@ -62,8 +62,8 @@ def test_gemm_plain_epilogues(dt, M, N, K):
 
 @pytest.mark.parametrize("N,K", [(1024, 1024), (3072, 1024), (1024, 4096)])
 def test_gemm_ragged_tail_split(N, K):
-    """The ViT-L products (M = 8 * 1029 = 64 * 128 + 40): the last 40 rows leave the tile grid and run on the K-parallel skinny
-    kernels (gemm_skinny.hip).  Same result as the unsplit product (DU_GEMM_NO_RAGGED_SPLIT path = no scratch lent), every epilogue."""
+    """The ViT-L products (M = 8 * 1029 = 64 * 128 + 40): for proj / fc2 the last 40 rows leave the tile grid and run on the K-parallel
+    skinny kernels (gemm_skinny.hip); every epilogue, against the fp32 product."""
     import ctypes
     from dinounet_amd import ops, _lib
     from dinounet_amd._lib import ACT_GELU
@@ -76,7 +76,8 @@ def test_gemm_ragged_tail_split(N, K):
     a = _lib.GemmArgs()
     a.dtype, a.out_dtype, a.a_mode, a.b_mode, a.M, a.N, a.K = _lib.DU_BF16, _lib.DU_BF16, 0, 0, M, N, K
     a.lda, a.ldb, a.ldc, a.batch, a.split_k = K, K, N, 1, 1
-    assert int(_lib.lib().du_gemm_ws_elems(ctypes.byref(a))) > 0
+    # one or two exact rounds of full tiles (N = 1024: 512 tiles on 512 slots) are split; three (N = 3072) measured no gain and are not
+    assert (int(_lib.lib().du_gemm_ws_elems(ctypes.byref(a))) > 0) == (N == 1024)
     ref = x.float() @ w.float().t()
     y = ops.mm(x, w, bias=b, act=ACT_GELU)
     assert y.dtype == bf and rel(y, F.gelu(ref + b)) < TOL[bf]
