@@ -78,8 +78,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, ql = lane & 31;
-  const int bh = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // XCD-aware order: workgroup b lands on XCD b % 8, so with the plain (q tile, head) grid the 9 query tiles of one head sat on 8
+  // different XCDs and every XCD pulled every head's K / V through its own L2 (FETCH_SIZE 5.5x the algorithmic bytes).  All query
+  // tiles of a head now share an XCD: heads are dealt round-robin to the XCDs, the tiles of a head are consecutive local indices.
+  int bh = blockIdx.y, qt = blockIdx.x;
+  if ((gridDim.y & 7) == 0) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, idx = lin >> 3;
+    bh = (idx / (int)gridDim.x) * 8 + xcd;
+    qt = idx % (int)gridDim.x;
+  }
+  const int q0 = qt * 128 + wave * 32;
   const bool active = q0 < N;        // wave-uniform: the last query tile of N = 1029 keeps only one wave busy
   const bf16_t* Qb = Q + (long)bh * Npad * DH;
   const bf16_t* Kb = K + (long)bh * Npad * DH;

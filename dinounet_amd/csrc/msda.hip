@@ -397,7 +397,16 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
   bf16_t* Gt = Wl + GV_PT * GV_WLD;                     // [32 channels][GV_GLD]   (G^T: k contiguous)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Hs = (int)shapes[0], Ws = (int)shapes[1];   // single level
-  const int bm = blockIdx.y / tiles, ptile = blockIdx.y % tiles;
+  // XCD-aware order (workgroup y lands on XCD y % 8 for the usual one-chunk grid): the loc / attn / grad_out rows of a query hold
+  // all M heads back to back, so neighbouring heads must share an XCD for the 128-byte lines to be reused in its L2.  XCD x serves
+  // the (head, pixel tile) pairs x*(M*tiles/8) .. of every batch sample instead of heads x, x+4, x+8, ... (4 different lines).
+  int bm = blockIdx.y / tiles, ptile = blockIdx.y % tiles;
+  const int mt = M * tiles;
+  if ((mt & 7) == 0 && gridDim.x == 1) {
+    const int per = mt >> 3, xcd = blockIdx.y & 7, idx = blockIdx.y >> 3;      // idx in [0, N * per)
+    const int bb = idx / per, r = idx - bb * per, hp = xcd * per + r;          // hp: (head, tile) pair of this sample
+    bm = bb * M + hp / tiles; ptile = hp % tiles;
+  }
   const int b = bm / M, m = bm % M;
   const int pix0 = ptile * GV_PT;
   const int q0 = blockIdx.x * q_per_chunk;
