@@ -637,3 +637,37 @@ def test_fused_clip_sgd_matches_torch(scale, max_norm):
     for x, y in zip(pa[:-1], pb[:-1]):
         assert rel(oa.state[x]["momentum_buffer"], ob.state[y]["momentum_buffer"]) < 1e-6
     assert torch.equal(pa[-1].detach().cpu(), torch.ones(5))
+
+
+# ------------------------------------------------------------------------------------------------ gradient reducer on the GPU
+def test_grad_reducer_single_rank_gather_matches_plain_grads():
+    """GradAllReducer on one rank (RCCL world of 1): the per-bucket gather kernel + all-reduce + 1/world must hand back exactly the
+    gradients autograd produced, as views of the flat buckets, over two steps (addresses of the incoming gradients change)."""
+    import os
+    import torch.distributed as dist
+    from dinounet_amd.parallel import GradAllReducer
+    d = dev()
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=d)
+        created = True
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(300, 257), torch.nn.GELU(), torch.nn.Linear(257, 64), torch.nn.Linear(64, 5)).to(d)
+        red = GradAllReducer(net, 1, bucket_elems=10000)
+        assert len(red.buckets) >= 2
+        for step in range(2):
+            x = gen(32, 300, seed=step).to(d)
+            net.zero_grad(set_to_none=True)
+            net(x).square().mean().backward()
+            want = [p.grad.clone() for p in net.parameters()]
+            # the hooks already gathered + reduced; finish() installs the flat views
+            red.finish()
+            for p, w in zip(net.parameters(), want):
+                assert p.grad.data_ptr() != w.data_ptr() and torch.equal(p.grad, w)
+        red.remove()
+    finally:
+        if created:
+            dist.destroy_process_group()
