@@ -98,11 +98,13 @@ def main():
     dt = time.perf_counter() - t0
     # roofline leg: the same step run eagerly with a HIP-event pair around every launch of the GEMM / attention kernels
     prof = None
-    if not a.no_roofline and rank == 0:
+    if not a.no_roofline:
+        # every rank runs these eager steps (they contain the gradient / SyncBN / Dice collectives); only rank 0 times its launches
         ts.use_graph = False
         ts()
         torch.cuda.synchronize()
-        ops.PROFILE = ops.KernelProfile()
+        if rank == 0:
+            ops.PROFILE = ops.KernelProfile()
         for _ in range(2):
             ts()
         torch.cuda.synchronize()
