@@ -55,7 +55,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
-    from oracle.refshim import PLANS_2D
+    from dinounet_amd.plans import PLANS_2D
     from dinounet_amd import ops
     from dinounet_amd.network_architecture import DinoUNet
     from dinounet_amd.parallel import GradAllReducer

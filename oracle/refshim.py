@@ -162,19 +162,7 @@ def install():
     _installed = True
 
 
-PLANS_2D = {  # what default_experiment_planner.py:377-396 emits for 2d / 4 stages (API:91-108 key set)
-    "architecture": {
-        "network_class_name": "dynamic_network_architectures.architectures.unet.PlainConvUNet",
-        "n_stages": 4, "features_per_stage": [32, 64, 128, 256],
-        "kernel_sizes": [[3, 3]] * 4, "strides": [[1, 1], [2, 2], [2, 2], [2, 2]],
-        "n_conv_per_stage": [2, 2, 2, 2], "n_conv_per_stage_decoder": [2, 2, 2],
-        "conv_op": "torch.nn.modules.conv.Conv2d", "norm_op": "torch.nn.modules.instancenorm.InstanceNorm2d",
-        "nonlin": "torch.nn.LeakyReLU", "conv_bias": True, "dropout_op": None,
-        "norm_op_kwargs": {"eps": 1e-5, "affine": True}, "nonlin_kwargs": {"inplace": True},
-        "dropout_op_kwargs": None,
-    },
-    "data_config": {"batch_size": 16, "patch_size": [512, 512]},
-}
+from dinounet_amd.plans import PLANS_2D  # noqa: E402,F401  (the 2D plans dict lives with the product: bench.py / tools must not import oracle/)
 
 
 def build_reference_dinounet(model_name="dinounet_s", num_classes=2, seed=0, deep_supervision=False, vit_kwargs=None):

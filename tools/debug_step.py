@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="run the steps through training.TrainStep with hipGraph capture")
     ap.add_argument("--no-jitter", action="store_true", help="disable drop-path and RoPE rescale")
     a = ap.parse_args()
-    from oracle.refshim import PLANS_2D
+    from dinounet_amd.plans import PLANS_2D
     from dinounet_amd import ops
     from dinounet_amd.network_architecture import DinoUNet
     from dinounet_amd.training import dc_and_ce_loss

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--top", type=int, default=60)
     ap.add_argument("--profiler", action="store_true", help="torch.profiler view instead: every watched op with input shapes, split by thread (the autograd engine's own copies / zero fills are invisible to the dispatch-mode tracer)")
     a = ap.parse_args()
-    from oracle.refshim import PLANS_2D
+    from dinounet_amd.plans import PLANS_2D
     from dinounet_amd.network_architecture import DinoUNet
     from dinounet_amd.training import dc_and_ce_loss
     dev = torch.device("cuda", 0)
