@@ -128,6 +128,7 @@ def main():
         if prof is not None:
             try:
                 out["roofline"], out["kernel_breakdown"] = prof.roofline(MFMA_BF16_PEAK_TFLOPS, HBM_PEAK_GBS, 2)
+                pmc_traffic(out["roofline"])
             except Exception as e:  # noqa: BLE001
                 out["roofline"] = {"error": repr(e)}
         if not a.no_cpu_baseline and world == 1:
@@ -145,6 +146,31 @@ def main():
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)
+
+
+def pmc_traffic(roof, tag="v12"):
+    """roofline.traffic = memory-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate runs, profiles/r01_pmc_*_eager_<tag>.txt; counters cannot
+    be collected from inside the process being timed).  FETCH_SIZE / WRITE_SIZE are kilobytes; on gfx950 FETCH_SIZE counts 128-byte
+    requests at 64 B, hence the factor 2 (MI355X_MICROARCH.md, HBM section).  Left null when the summaries are not there."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    key = roof.get("kernel", "").split("<")[0]
+    tot = {}
+    for name, mult in (("fetch", 2.0), ("write", 1.0)):
+        path = os.path.join(here, "profiles", f"r01_pmc_{name}_size_eager_{tag}.txt")
+        if not key or not os.path.exists(path):
+            return
+        calls, kb = 0, 0.0
+        for line in open(path):
+            f = line.split(None, 2)
+            if len(f) == 3 and f[0].isdigit() and key in f[2]:
+                calls += int(f[0]); kb += int(f[0]) * float(f[1])
+        if not calls:
+            return
+        tot[name] = kb / calls * 1024.0 * mult
+    roof["traffic"] = round(tot["fetch"] + tot["write"])
+    roof["traffic_unit"] = "bytes/launch"
+    roof["traffic_source"] = f"profiles/r01_pmc_{{fetch,write}}_size_eager_{tag}.txt (separate rocprofv3 --pmc passes of bench.py --graph off; FETCH_SIZE x2)"
 
 
 def cpu_baseline(net, a):
