@@ -757,6 +757,51 @@ extern "C" int du_se_scale_bwd(int dtype, const void* dy, int64_t lddy, const fl
   return du_check_launch();
 }
 
+// ---------------- sliding-window inference: Gaussian-weighted accumulation of window logits (predict_from_raw_data.py:607-610) --------
+namespace {
+// logits (nb, K, ph, pw) fp32; window i sits at slice coords[3i], rows coords[3i+1].., columns coords[3i+2]..; windows of one launch may
+// overlap (50 % steps), hence fp32 atomics -- at most 4 windows meet in a pixel
+__global__ __launch_bounds__(256) void window_accumulate_kernel(const float* __restrict__ logits, const float* __restrict__ gauss,
+                                                                const int* __restrict__ coords, float* __restrict__ pred,
+                                                                float* __restrict__ npred, int nb, int K, int ph, int pw, int D, int H,
+                                                                int W) {
+  const long per = (long)ph * pw, total = (long)nb * per;
+  GRID_STRIDE(i, total) {
+    const int b = (int)(i / per);
+    const int r = (int)(i - (long)b * per);
+    const int y = r / pw, x = r - y * pw;
+    const int d = coords[b * 3], y0 = coords[b * 3 + 1], x0 = coords[b * 3 + 2];
+    const float g = gauss[r];
+    const long o = ((long)d * H + y0 + y) * W + x0 + x;
+    atomic_add_f32(npred + o, g);
+    for (int k = 0; k < K; k++) atomic_add_f32(pred + (long)k * D * H * W + o, logits[((long)b * K + k) * per + r] * g);
+  }
+}
+__global__ __launch_bounds__(256) void window_normalize_kernel(float* __restrict__ pred, const float* __restrict__ npred, int K, long n) {
+  GRID_STRIDE(i, n) {
+    const float inv = 1.f / npred[i];
+    for (int k = 0; k < K; k++) pred[(long)k * n + i] *= inv;
+  }
+}
+}  // namespace
+
+extern "C" int du_window_accumulate(const float* logits, const float* gauss, const int32_t* coords, float* pred, float* npred, int nb, int K,
+                                    int ph, int pw, int D, int H, int W, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!logits || !gauss || !coords || !pred || !npred || nb <= 0 || K <= 0 || ph <= 0 || pw <= 0 || D <= 0 || H < ph || W < pw) return DU_ERR_BAD_ARG;
+  const long total = (long)nb * ph * pw;
+  hipLaunchKernelGGL(window_accumulate_kernel, dim3(grid_1d(total)), dim3(256), 0, st, logits, gauss, (const int*)coords, pred, npred, nb, K, ph, pw,
+                     D, H, W);
+  return du_check_launch();
+}
+
+extern "C" int du_window_normalize(float* pred, const float* npred, int K, int64_t n, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!pred || !npred || K <= 0 || n <= 0) return DU_ERR_BAD_ARG;
+  hipLaunchKernelGGL(window_normalize_kernel, dim3(grid_1d(n)), dim3(256), 0, st, pred, npred, K, (long)n);
+  return du_check_launch();
+}
+
 extern "C" const char* du_version(void) { return "dinounet_hip 0.1 (gfx950)"; }
 
 extern "C" int du_device_ok(void) {

@@ -1,0 +1,158 @@
+"""Sliding-window inference with Gaussian blending on the MI355X -- SURVEY.md 8(f) rank 2: the consumer of the forward path that
+produces the segmentation the Dice metric is computed on.  Mirrors the reference predictor
+(dinounet/inference/predict_from_raw_data.py:503-535 slicers, :571-621 accumulation, :680-727 padding / un-padding;
+dinounet/inference/sliding_window_prediction.py:10-60 Gaussian map and step positions) for the 2D networks of this repo:
+
+    data (C, D, H, W): every slice d is tiled with `patch_size` windows at `tile_step_size`; each window's logits are weighted with
+    a Gaussian importance map (sigma = patch / 8, peak value 10, zeros replaced by the smallest non-zero value), accumulated, and the
+    sum is divided by the accumulated weights.
+
+Differences from the reference, all on purpose: windows are run through the network in batches (the reference predicts one window
+per forward); the accumulators are fp32 (the reference keeps fp16 buffers and aborts on overflow, :612-615); the weighted
+accumulate and the final division are two HIP kernels (csrc/elementwise.hip: du_window_accumulate, du_window_normalize) instead of
+two indexed read-modify-write torch ops per window.  Test-time mirroring is not implemented (the in-trainer validation the
+reference actually uses passes use_mirroring=False, nnUNetTrainer.py:1160).  There is no CPU path: the module needs the GPU.
+`acvl_utils.pad_nd_image` (not vendored in the reference tree) is restated from its published behaviour: centred constant padding
+up to the patch size, extra pixel on the high side."""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def compute_gaussian(tile_size, sigma_scale=1.0 / 8, value_scaling_factor=1.0, dtype=torch.float32, device="cpu"):
+    """sliding_window_prediction.py:10-31 (scipy's gaussian_filter of a centred delta, normalised to `value_scaling_factor`)."""
+    from scipy.ndimage import gaussian_filter
+    tmp = np.zeros(tile_size)
+    tmp[tuple(i // 2 for i in tile_size)] = 1
+    g = gaussian_filter(tmp, [i * sigma_scale for i in tile_size], 0, mode="constant", cval=0)
+    g = torch.from_numpy(g)
+    g = g / torch.max(g) * value_scaling_factor
+    g = g.type(dtype).to(device)
+    g[g == 0] = torch.min(g[g != 0])       # the importance map must not be 0 (division by the accumulated weights)
+    return g
+
+
+def compute_steps_for_sliding_window(image_size, tile_size, tile_step_size):
+    """sliding_window_prediction.py:34-60: window origins per axis, evenly spread, at most tile*step apart."""
+    assert all(i >= j for i, j in zip(image_size, tile_size)), "image size must be as large or larger than patch_size"
+    assert 0 < tile_step_size <= 1, "step_size must be larger than 0 and smaller or equal to 1"
+    target = [i * tile_step_size for i in tile_size]
+    num_steps = [int(np.ceil((i - k) / j)) + 1 for i, j, k in zip(image_size, target, tile_size)]
+    steps = []
+    for dim in range(len(tile_size)):
+        max_step = image_size[dim] - tile_size[dim]
+        actual = max_step / (num_steps[dim] - 1) if num_steps[dim] > 1 else 99999999999
+        steps.append([int(np.round(actual * i)) for i in range(num_steps[dim])])
+    return steps
+
+
+def sliding_window_origins(image_size, patch_size, tile_step_size):
+    """(d, y0, x0) of every window of a (D, H, W) volume predicted slice-wise with a 2D patch -- predict_from_raw_data.py:505-522
+    (same order: slices outermost, then x steps, then y steps)."""
+    assert len(image_size) == 3 and len(patch_size) == 2
+    steps = compute_steps_for_sliding_window(image_size[1:], patch_size, tile_step_size)
+    return [(d, sy, sx) for d in range(image_size[0]) for sy in steps[0] for sx in steps[1]]
+
+
+def pad_to_patch(data, patch_size):
+    """pad_nd_image(data, patch_size, 'constant', {'value': 0}, return_slicer=True) for the trailing 2 axes: centred, the odd pixel
+    goes to the high side.  Returns (padded, (y slice, x slice)) where the slices undo the padding."""
+    H, W = data.shape[-2:]
+    nh, nw = max(H, patch_size[0]), max(W, patch_size[1])
+    dy, dx = nh - H, nw - W
+    if dy == 0 and dx == 0:
+        return data, (slice(0, H), slice(0, W))
+    lo_y, lo_x = dy // 2, dx // 2
+    padded = torch.nn.functional.pad(data, (lo_x, dx - lo_x, lo_y, dy - lo_y), mode="constant", value=0)
+    return padded, (slice(lo_y, lo_y + H), slice(lo_x, lo_x + W))
+
+
+class _WindowForward:
+    """Eval-mode forward of a fixed (batch, C, ph, pw) window batch captured into a hipGraph (the forward is a few hundred small
+    launches; eager it is host-bound).  A ragged last batch is padded with zero windows whose logits are never accumulated."""
+
+    def __init__(self, net, shape, device):
+        self.x = torch.zeros(shape, dtype=torch.float32, device=device)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):                      # allocator / lazy caches settle before the capture
+                net(self.x)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            y = net(self.x)
+            self.y = (y[0] if isinstance(y, (list, tuple)) else y).float().contiguous()
+
+    def __call__(self, x):
+        n = x.shape[0]
+        self.x[:n].copy_(x)
+        if n < self.x.shape[0]:
+            self.x[n:].zero_()
+        self.graph.replay()
+        return self.y
+
+
+def clear_window_cache(net):
+    """Drop the captured window forwards of `net` (after load_state_dict with re-allocated tensors, .to(), dtype changes)."""
+    net.__dict__.pop("_sw_forward_cache", None)
+
+
+@torch.no_grad()
+def predict_sliding_window_logits(net, data, patch_size, tile_step_size=0.5, use_gaussian=True, batch_size=8, graph=False):
+    """data (C, D, H, W) on the GPU (or host: moved once) -> fp32 logits (K, D, H, W) on the GPU.
+    predict_from_raw_data.py:680-727 with _internal_predict_sliding_window_return_logits :571-621.  graph=True replays a captured
+    forward of a full window batch (worth it from a few batches per volume on)."""
+    assert data.ndim == 4, "input_image must be a 4D tensor (c, d, y, x)"
+    dev = next(net.parameters()).device
+    if dev.type != "cuda":
+        raise RuntimeError("sliding-window inference runs on the MI355X (no CPU fallback)")
+    was_training = net.training
+    net.eval()
+    try:
+        data = data.to(dev, torch.float32)
+        data, (ys, xs) = pad_to_patch(data, patch_size)
+        Cc, D, H, W = data.shape
+        ph, pw = int(patch_size[0]), int(patch_size[1])
+        origins = sliding_window_origins((D, H, W), (ph, pw), tile_step_size)
+        gauss = (compute_gaussian((ph, pw), sigma_scale=1.0 / 8, value_scaling_factor=10, dtype=torch.float32, device=dev)
+                 if use_gaussian else torch.ones((ph, pw), dtype=torch.float32, device=dev)).contiguous()
+        pred = npred = fwd = None
+        coords_all = torch.tensor(origins, dtype=torch.int32).to(dev)        # one host->device copy for the whole volume
+        L = _lib.lib()
+        st = torch.cuda.current_stream().cuda_stream
+        for i0 in range(0, len(origins), batch_size):
+            chunk = origins[i0:i0 + batch_size]
+            x = torch.stack([data[:, d, y0:y0 + ph, x0:x0 + pw] for d, y0, x0 in chunk])           # (b, C, ph, pw)
+            if graph:
+                if fwd is None:
+                    # cached on the module: replays read the parameters / running statistics in place, so the capture stays valid
+                    # while they are updated (not if they are re-allocated: clear_window_cache(net) then)
+                    cache = net.__dict__.setdefault("_sw_forward_cache", {})
+                    key = (batch_size, Cc, ph, pw, str(dev))
+                    if key not in cache:
+                        cache[key] = _WindowForward(net, (batch_size, Cc, ph, pw), dev)
+                    fwd = cache[key]
+                logits = fwd(x)
+            else:
+                logits = net(x)
+                if isinstance(logits, (list, tuple)):
+                    logits = logits[0]
+                logits = logits.float().contiguous()
+            K = logits.shape[1]
+            if pred is None:
+                pred = torch.zeros((K, D, H, W), dtype=torch.float32, device=dev)
+                npred = torch.zeros((D, H, W), dtype=torch.float32, device=dev)
+            coords = coords_all[i0:i0 + len(chunk)]
+            _lib.check(L.du_window_accumulate(logits.data_ptr(), gauss.data_ptr(), coords.data_ptr(), pred.data_ptr(), npred.data_ptr(),
+                                              len(chunk), K, ph, pw, D, H, W, st), "du_window_accumulate")
+        _lib.check(L.du_window_normalize(pred.data_ptr(), npred.data_ptr(), K, D * H * W, st), "du_window_normalize")
+        if not math.isfinite(float(pred.abs().max())):
+            raise RuntimeError("Encountered inf in predicted array")                                 # :612-615
+        return pred[:, :, ys, xs]
+    finally:
+        net.train(was_training)

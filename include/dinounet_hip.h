@@ -282,6 +282,14 @@ int du_pack_weights(const int64_t* table, const int64_t* bprefix, int n, int64_t
 const char* du_version(void);
 int du_device_ok(void); /* 1 if the current device is gfx950 */
 
+/* ---- sliding-window inference: predicted_logits[sl] += prediction * gaussian; n_predictions[sl] += gaussian
+   (dinounet/inference/predict_from_raw_data.py:607-608) for a batch of nb windows, then predicted_logits /= n_predictions (:610).
+   logits (nb, K, ph, pw) fp32; gauss (ph, pw) fp32; coords (nb, 3) int32 = (slice d, row y0, column x0) of each window;
+   pred (K, D, H, W) and npred (D, H, W) fp32 accumulators, zero-initialised by the caller before the first window. */
+int du_window_accumulate(const float* logits, const float* gauss, const int32_t* coords, float* pred, float* npred, int nb, int K,
+                         int ph, int pw, int D, int H, int W, void* stream);
+int du_window_normalize(float* pred, const float* npred, int K, int64_t n, void* stream);
+
 /* ---- fused clip_grad_norm_ + Nesterov SGD over all trainable tensors (replaces
    torch.nn.utils.clip_grad_norm_(params, 12) + torch.optim.SGD.step(), dinounet/training/nnUNetTrainer/nnUNetTrainer.py:486,922-924).
    table: n_tensors rows of 4 x int64 [param ptr, grad ptr, momentum-buffer ptr, numel] (fp32 tensors, contiguous);

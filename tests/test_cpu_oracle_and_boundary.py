@@ -205,3 +205,59 @@ def test_zero_pool_one_buffer_per_step_without_aliasing():
     pool.new_step()                                                              # the deviating step became the new plan
     a4, c4, d4 = pool.zeros((4, 8), dev), pool.zeros((5,), dev), pool.zeros((3,), dev)
     assert a4.untyped_storage().data_ptr() == c4.untyped_storage().data_ptr() == d4.untyped_storage().data_ptr()
+
+
+def test_sliding_window_helpers_match_reference_golden():
+    """compute_gaussian / compute_steps_for_sliding_window: the oracle restatement AND the product's host logic reproduce the outputs
+    of the reference's own functions (tests/golden/sliding_window.npz, written by oracle/make_golden_sw.py from
+    dinounet/inference/sliding_window_prediction.py); window order as predict_from_raw_data.py:517-522; padding round trip."""
+    from oracle import sliding_window_oracle as SW
+    from dinounet_amd import inference as INF
+    g = np.load(os.path.join(GOLD, "sliding_window.npz"))
+    i = 0
+    while f"steps{i}_args" in g:
+        a = g[f"steps{i}_args"]
+        img, tile, step = (int(a[0]), int(a[1])), (int(a[2]), int(a[3])), float(a[4])
+        want = [g[f"steps{i}_ax0"].tolist(), g[f"steps{i}_ax1"].tolist()]
+        assert SW.compute_steps(img, tile, step) == want
+        assert INF.compute_steps_for_sliding_window(img, tile, step) == want
+        i += 1
+    assert i >= 5
+    i = 0
+    while f"gauss{i}_args" in g:
+        a = g[f"gauss{i}_args"]
+        tile, sig, val = (int(a[0]), int(a[1])), float(a[2]), float(a[3])
+        want = torch.from_numpy(g[f"gauss{i}"])
+        assert torch.equal(SW.compute_gaussian(tile, sig, val), want)
+        assert torch.equal(INF.compute_gaussian(tile, sig, val), want)
+        assert float(want.min()) > 0
+        i += 1
+    assert i >= 2
+    # slices outermost, then the first-axis steps, then the second-axis steps
+    assert INF.sliding_window_origins((2, 160, 200), (128, 128), 0.5) == [(d, y, x) for d in range(2) for y in (0, 32) for x in (0, 36, 72)]
+    # images smaller than the patch: centred zero padding, odd pixel on the high side; the slices undo it
+    x = torch.arange(2 * 3 * 5 * 7, dtype=torch.float32).view(2, 3, 5, 7)
+    for pad_fn in (INF.pad_to_patch, SW.pad_nd_image_2d):
+        p, (ys, xs) = pad_fn(x, (8, 8))
+        assert p.shape == (2, 3, 8, 8) and (ys, xs) == (slice(1, 6), slice(0, 7)) and torch.equal(p[..., ys, xs], x)
+        assert float(p.sum()) == float(x.sum())
+        p2, (ys2, xs2) = pad_fn(x, (4, 4))
+        assert p2.shape == x.shape and torch.equal(p2[..., ys2, xs2], x)
+
+
+def test_sliding_window_oracle_blending_properties():
+    """The blending itself, through size-independent properties: a predictor that returns a constant gives that constant everywhere
+    (weights cancel); a linear predictor of the window's own pixels reproduces the image-wide linear map; fp16 accumulators (the
+    reference's dtype) stay within fp16 rounding of the fp32 ones."""
+    from oracle import sliding_window_oracle as SW
+    torch.manual_seed(0)
+    data = torch.randn(3, 2, 70, 90)
+    const = SW.predict_sliding_window_logits(lambda w: torch.full((1, 4, *w.shape[-2:]), 2.5), data, (32, 48), 0.5)
+    assert const.shape == (4, 2, 70, 90) and float((const - 2.5).abs().max()) < 1e-5
+    A = torch.randn(4, 3)
+    lin = SW.predict_sliding_window_logits(lambda w: torch.einsum("kc,bchw->bkhw", A, w), data, (32, 48), 0.5)
+    assert float((lin - torch.einsum("kc,cdhw->kdhw", A, data)).abs().max()) < 1e-4
+    half = SW.predict_sliding_window_logits(lambda w: torch.einsum("kc,bchw->bkhw", A, w), data, (32, 48), 0.5, accum_dtype=torch.float16)
+    assert float((half.float() - lin).abs().max()) < 3e-2
+    small = SW.predict_sliding_window_logits(lambda w: torch.einsum("kc,bchw->bkhw", A, w), data[..., :20, :30], (32, 48), 0.5)
+    assert small.shape == (4, 2, 20, 30) and float((small - torch.einsum("kc,cdhw->kdhw", A, data[..., :20, :30])).abs().max()) < 1e-4

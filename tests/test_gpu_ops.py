@@ -671,3 +671,35 @@ def test_grad_reducer_single_rank_gather_matches_plain_grads():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ sliding-window inference
+@pytest.mark.parametrize("shape,patch,bs", [((3, 2, 160, 200), (128, 128), 5), ((3, 1, 100, 128), (128, 128), 8), ((3, 3, 128, 128), (128, 128), 2)])
+def test_sliding_window_inference_matches_oracle(shape, patch, bs):
+    """inference.predict_sliding_window_logits (batched windows, HIP accumulate / normalise kernels) against the CPU restatement of the
+    reference predictor (oracle/sliding_window_oracle.py: one window per call, torch indexing) driving the SAME network: image larger
+    than / smaller than / equal to the patch, ragged last batch of windows."""
+    from oracle import sliding_window_oracle as SW
+    from oracle import weights
+    from dinounet_amd.plans import PLANS_2D
+    from dinounet_amd.network_architecture import DinoUNet
+    from dinounet_amd import inference as INF
+    d = dev()
+    net = DinoUNet.from_config(PLANS_2D, 3, 3, dinov3_pretrained_path=None, dinov3_model_name="dinounet_s", precision="fp32")
+    ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    net.load_state_dict(weights.make_state_dict(ks, seed=0), strict=True)
+    net = net.to(d).eval()
+    data = gen(*shape, seed=7)
+    got = INF.predict_sliding_window_logits(net, data, patch, tile_step_size=0.5, use_gaussian=True, batch_size=bs)
+    with torch.no_grad():
+        want = SW.predict_sliding_window_logits(lambda w: net(w.to(d)).float().cpu(), data, patch, 0.5, True)
+    assert got.shape == want.shape == (3, shape[1], shape[2], shape[3])
+    assert rel(got, want) < 2e-5
+    assert torch.equal(got.argmax(0).cpu(), want.argmax(0)) or float((got.argmax(0).cpu() != want.argmax(0)).float().mean()) < 1e-4
+    flat = INF.predict_sliding_window_logits(net, data, patch, tile_step_size=1.0, use_gaussian=False, batch_size=bs)
+    with torch.no_grad():
+        want2 = SW.predict_sliding_window_logits(lambda w: net(w.to(d)).float().cpu(), data, patch, 1.0, False)
+    assert rel(flat, want2) < 2e-5
+    captured = INF.predict_sliding_window_logits(net, data, patch, tile_step_size=0.5, use_gaussian=True, batch_size=bs, graph=True)
+    assert rel(captured, want) < 2e-5                    # hipGraph-replayed window forward, zero-padded ragged batch
+    assert net.training is False
