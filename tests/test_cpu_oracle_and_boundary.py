@@ -261,3 +261,54 @@ def test_sliding_window_oracle_blending_properties():
     assert float((half.float() - lin).abs().max()) < 3e-2
     small = SW.predict_sliding_window_logits(lambda w: torch.einsum("kc,bchw->bkhw", A, w), data[..., :20, :30], (32, 48), 0.5)
     assert small.shape == (4, 2, 20, 30) and float((small - torch.einsum("kc,cdhw->kdhw", A, data[..., :20, :30])).abs().max()) < 1e-4
+
+
+def test_compact_checkpoint_round_trip_and_reference_key_contract(tmp_path):
+    """checkpoint.py: the compact file drops the frozen backbone and the `decoder.encoder.*` duplicates, and its
+    expansion is exactly the dict the reference's load_checkpoint feeds to load_state_dict(strict): same keys in the same order as the
+    reference module's state_dict (tests/golden/state_dict_dinounet_s.json), identical tensors, aliases sharing storage."""
+    from dinounet_amd import checkpoint as CK
+    from dinounet_amd.plans import PLANS_2D
+    from dinounet_amd.network_architecture import DinoUNet
+    torch.manual_seed(0)
+    net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name="dinounet_s", precision="fp32")
+    ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    net.load_state_dict(weights.make_state_dict(ks, seed=3), strict=True)
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-2, momentum=0.99, nesterov=True)
+    for p in params[:5]:
+        opt.state[p]["momentum_buffer"] = torch.randn_like(p)
+    full = {k: v.clone() for k, v in net.state_dict().items()}
+    compact, meta = CK.compact_state_dict(net)
+    assert not any(k.startswith("decoder.encoder.") for k in compact)
+    assert not any(k.startswith("encoder.dinov3_adapter.backbone.") for k in compact)          # the whole ViT is frozen
+    assert all(k in compact for k in full if k.startswith("encoder.fapm.") or k.startswith("decoder.stages."))
+    assert any(k.endswith("running_mean") for k in compact) and any(k.endswith("num_batches_tracked") for k in compact)
+    ref_keys = [k for k, _, _ in json.load(open(os.path.join(GOLD, "state_dict_dinounet_s.json")))["keys"]]
+    path = str(tmp_path / "ckpt.pth")
+    CK.save_checkpoint(path, net, opt, current_epoch=7, _best_ema=0.5, trainer_name="DinoUNetTrainer_s", init_args={"fold": 0},
+                       logging={"train_losses": [1.0]}, inference_allowed_mirroring_axes=None)
+    torch.save({"network_weights": full}, str(tmp_path / "full.pth"))
+    ratio = os.path.getsize(path) / os.path.getsize(str(tmp_path / "full.pth"))
+    assert ratio < 0.2, ratio                                                                   # dinounet_s: 86 M frozen x 2 copies dropped
+    # scramble the trainable part of the live module, then load the compact file back
+    with torch.no_grad():
+        for p in params:
+            p.add_(1.0)
+    opt2 = torch.optim.SGD(params, lr=1e-2, momentum=0.99, nesterov=True)
+    ck = CK.load_checkpoint(path, net, opt2)
+    assert ck["current_epoch"] == 7 and ck["trainer_name"] == "DinoUNetTrainer_s" and "network_weights_meta" not in ck
+    assert list(ck["network_weights"].keys()) == ref_keys == list(full.keys())
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, full[k]), k
+    w = ck["network_weights"]
+    assert w["decoder.encoder.fapm.shared_basis.weight"].data_ptr() == w["encoder.fapm.shared_basis.weight"].data_ptr()
+    assert len(opt2.state_dict()["state"]) == 5
+    # a different backbone is refused; a matching external backbone state dict is accepted
+    bb = {k[len(CK.FROZEN_PREFIX):]: v.clone() for k, v in full.items() if k.startswith(CK.FROZEN_PREFIX)}
+    ok = CK.expand_state_dict(compact, meta, backbone_state=bb)
+    assert all(torch.equal(ok[k], full[k]) for k in full)
+    bb["cls_token"] = bb["cls_token"] + 1
+    with pytest.raises(ValueError):
+        CK.expand_state_dict(compact, meta, backbone_state=bb)
+    assert CK.expand_state_dict(compact, meta, backbone_state=bb, check=False)["encoder.dinov3_adapter.backbone.cls_token"] is bb["cls_token"]
