@@ -96,6 +96,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    graph_used = ts.graph is not None          # False when capture was off or fell back to eager steps
     # roofline leg: the same step run eagerly with a HIP-event pair around every launch of the GEMM / attention kernels
     prof = None
     if not a.no_roofline:
@@ -123,7 +124,7 @@ def main():
            "config": {"workload": f"{a.model} train step (fwd+loss+bwd+clip+SGD), {a.size}x{a.size}x3 slices, batch {a.batch}/GPU, "
                                   f"frozen ViT + adapter + FAPM + U-Net decoder, random-init weights",
                       "global_batch": a.batch * world, "parallelism": f"dp{world}"},
-           "final_loss": round(float(loss.item()), 5), "hipgraph": bool(use_graph)}
+           "final_loss": round(float(loss.item()), 5), "hipgraph": bool(graph_used)}
     if rank == 0:
         if prof is not None:
             try:

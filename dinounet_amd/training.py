@@ -109,9 +109,19 @@ class TrainStep:
                 self._n += 1
                 return self.loss
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self.loss = self._step()
+                self.graph = graph
+            except Exception as e:  # noqa: BLE001   capture is an optimisation: a step that cannot be captured still has to train
+                import warnings
+                warnings.warn(f"hipGraph capture of the train step failed ({e!r}); continuing with eager steps")
+                self.use_graph = False
+                self.graph = None
+                torch.cuda.synchronize()
                 self.loss = self._step()
+                return self.loss
         if isinstance(self.opt, FusedClipSGD):
             self.opt.refresh_hyper()                        # the captured step re-reads lr & co. from the pinned host buffer
         self.graph.replay()
