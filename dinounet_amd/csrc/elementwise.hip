@@ -564,10 +564,10 @@ extern "C" int du_dwconv3x3_bwd_data(int dtype, const void* dy, int64_t lddy, in
 }
 
 static inline int dwconv_wgrad_strip(long npix, int C, int v) {
-  // ~1024 workgroups per launch, but at least 4 pixels per pixel lane so the 10-round LDS reduction stays amortised
+  // ~512 workgroups per launch, but at least 4 pixels per pixel lane so the LDS reduction stays amortised
   const int cvb_ = (C / v) < 256 ? (C / v) : 256;
   const int np_ = 256 / cvb_;
-  long strip_l = (npix + 1023) / 1024;
+  long strip_l = (npix + 511) / 512;        // 512 strips: the partial buffer the finalize kernel re-reads halves (measured vs 1024)
   if (strip_l < (long)np_ * 4) strip_l = (long)np_ * 4;
   return (int)strip_l;
 }
