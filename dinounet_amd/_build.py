@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdinounet_hip.so")
-SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_glds.hip", "gemm_skinny.hip", "conv_halo.hip", "attention.hip", "norm.hip", "msda.hip", "elementwise.hip", "loss.hip", "optim.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_glds.hip", "gemm_p8.hip", "gemm_skinny.hip", "conv_halo.hip", "attention.hip", "norm.hip", "msda.hip", "elementwise.hip", "loss.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc"]
 
 

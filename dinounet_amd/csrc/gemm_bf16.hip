@@ -367,14 +367,29 @@ int du_gemm_nt_glds(const du_gemm_args& a, hipStream_t st);   // gemm_glds.hip
 int du_gemm_skinny(const du_gemm_args& a, hipStream_t st);    // gemm_skinny.hip
 int64_t du_gemm_skinny_ws_elems(int N, int K);
 
-// Rows of a tall bf16 NT product that should leave the 128 x 128 tile grid: r = M % 128 when 0 < r <= 64 and the full tile rows
-// fill the resident workgroup slots (2 per CU) a whole number of times, at most twice (measured, tools/gemm_ragged.py: one round --
-// proj 39 -> 36 us, fc2 122 -> 95 us; three rounds (qkv) 82 -> 85 us and four (fc1) no penalty to remove: the ragged tiles hide
-// behind the spread of tile finish times).  0 = leave the product alone.
+int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st);     // gemm_p8.hip
+bool du_gemm_p8_wants(const du_gemm_args& a);
+
+// Rows of a tall bf16 NT product that should leave the tile grid for the K-parallel skinny kernels (gemm_skinny.hip).
+//  * products served by the 256 x 256 multi-phase kernel (gemm_p8.hip): r = M % 256 when 0 < r <= 64 (the ViT: M = 8 * 1029 =
+//    32 * 256 + 40) -- a ragged 33rd tile row would run a full K loop for 40 live rows;
+//  * products on the 128 x 128 kernel: r = M % 128 when 0 < r <= 64 and the full tile rows fill the resident workgroup slots (2 per
+//    CU) a whole number of times, at most twice (measured, tools/gemm_ragged.py: one round -- proj 39 -> 36 us, fc2 122 -> 95 us;
+//    three rounds (qkv) 82 -> 85 us and four (fc1) no penalty to remove: the ragged tiles hide behind the spread of finish times).
+// 0 = leave the product alone.
 int du_gemm_ragged_rows(const du_gemm_args& a) {
   static const bool off = getenv("DU_GEMM_NO_RAGGED_SPLIT") != nullptr;      // debugging / A-B aid
   if (off || a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.store_mode != DU_STORE_PLAIN) return 0;
   if (a.batch > 1 || a.split_k > 1 || a.K % 64 || a.N < 96 || a.N % 4 || a.M < 1024 || a.lda % 8 || a.ldb % 8) return 0;
+  {
+    const int r = a.M % 256;
+    if (r > 0 && r <= 64 && !(a.row_scale && (a.rs_rows < 1 || (a.M - r) % a.rs_rows))) {
+      du_gemm_args head = a;
+      head.M = a.M - r;
+      if (du_gemm_p8_wants(head)) return r;
+    }
+    if (du_gemm_p8_wants(a)) return 0;
+  }
   const int r = a.M % 128;
   if (r == 0 || r > 64) return 0;
   if (a.row_scale && (a.rs_rows < 1 || (a.M - r) % a.rs_rows)) return 0;
@@ -386,6 +401,15 @@ int du_gemm_ragged_rows(const du_gemm_args& a) {
   const long full = (long)(a.M / 128) * ((a.N + 127) / 128);
   if (full % slots || full / slots > 2) return 0;
   return r;
+}
+
+// large contraction-contiguous products: the 256 x 256 multi-phase kernel where it pays, else the 128 x 128 direct-to-LDS kernel
+static int nt_tiles(const du_gemm_args& a, hipStream_t st) {
+  if (du_gemm_p8_wants(a)) {
+    int rc = du_gemm_nt_p8(a, st);
+    if (rc != DU_ERR_UNSUPPORTED) return rc;
+  }
+  return du_gemm_nt_glds(a, st);
 }
 
 // returns DU_ERR_UNSUPPORTED when the generic kernel must be used instead
@@ -412,7 +436,7 @@ int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
       du_gemm_args head = a;
       head.M = (int)m0;
       // (forking the tail onto a side stream with event edges measured slower, eager and inside a hipGraph: 191.6 vs 194.0 slices/s)
-      int rc = du_gemm_nt_glds(head, st);
+      int rc = nt_tiles(head, st);
       if (rc == DU_OK) {
         rc = du_gemm_skinny(tail, st);
         if (rc == DU_ERR_UNSUPPORTED) {
@@ -423,7 +447,7 @@ int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
       }
       if (rc != DU_ERR_UNSUPPORTED) return rc;
     }
-    int rc = du_gemm_nt_glds(a, st);      // direct-to-LDS kernel for the large contraction-contiguous products
+    int rc = nt_tiles(a, st);
     if (rc != DU_ERR_UNSUPPORTED) return rc;
   }
   if (a.out_dtype == DU_BF16) return launch_modes<bf16_t>(a, st);

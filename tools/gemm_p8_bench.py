@@ -1,0 +1,115 @@
+#!/usr/bin/env python
+"""256 x 256 multi-phase NT GEMM (csrc/gemm_p8.hip) against the 128 x 128 kernel (csrc/gemm_glds.hip): full-matrix correctness vs an
+fp32 product of the same bf16 operands, a repeat-run race screen (the kernel is deterministic: any run-to-run difference is a
+pipeline race), and within-process interleaved timing of the variants on the ViT shapes (random normal operands).
+usage: python tools/gemm_p8_bench.py [rounds]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from dinounet_amd import _lib, ops  # noqa: E402
+
+dev = torch.device("cuda", 0)
+bf = torch.bfloat16
+L = _lib.lib()
+
+
+def opt(mode=-1, sched=1, group=4):
+    L.du_set_option(0, mode)
+    L.du_set_option(1, sched)
+    L.du_set_option(2, group)
+
+
+def run(x, w, od, bias=None, gamma=None, res=None, act=0):
+    out = torch.empty((x.shape[0], w.shape[0]), dtype=od, device=dev)
+    return ops.mm(x, w, out=out, bias=bias, gamma=gamma, residual=res, act=act)
+
+
+def check():
+    g = torch.Generator(device="cpu").manual_seed(1)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    ok = True
+    cases = [(256, 256, 256, bf, 0), (512, 512, 256, torch.float32, 0), (768, 640, 384, bf, 0), (1000, 516, 512, torch.float32, 1),
+             (8232, 3072, 1024, bf, 0), (8232, 1024, 1024, torch.float32, 2), (8232, 4096, 1024, bf, 3), (8232, 1024, 4096, torch.float32, 2),
+             (2048, 384, 1536, bf, 0)]
+    for M, N, K, od, epi in cases:
+        x, w = rnd(M, K).to(bf), (rnd(N, K) * 0.05).to(bf)
+        bias = rnd(N) if epi else None
+        gamma = rnd(N) if epi == 2 else None
+        res = rnd(M, N).to(od) if epi == 2 else None
+        act = 1 if epi == 3 else 0
+        ref = x.float() @ w.float().t()
+        if bias is not None:
+            ref = ref + bias
+        if act:
+            ref = torch.nn.functional.gelu(ref)
+        if gamma is not None:
+            ref = ref * gamma
+        if res is not None:
+            ref = ref + res.float()
+        opt(mode=0)
+        y_old = run(x, w, od, bias, gamma, res, act).float()
+        opt(mode=1)
+        y_new = run(x, w, od, bias, gamma, res, act).float()
+        scale = ref.abs().max().item()
+        e_old = (y_old - ref).abs().max().item() / scale
+        e_new = (y_new - ref).abs().max().item() / scale
+        d = (y_new - y_old).abs().max().item() / scale
+        # race screen: 30 repeats must be bit-identical
+        same = True
+        for _ in range(30):
+            same &= bool(torch.equal(run(x, w, od, bias, gamma, res, act).float(), y_new))
+        tol = 1e-2 if od == bf else 2e-3
+        good = e_new < tol and same and e_new < 2.0 * e_old + 1e-6
+        ok &= good
+        print(f"check M{M} N{N} K{K} {'bf16' if od == bf else 'f32 '} epi{epi}: err_new {e_new:.2e} err_old {e_old:.2e} new-old {d:.2e} "
+              f"deterministic {same} -> {'OK' if good else 'FAIL'}", flush=True)
+    opt()
+    return ok
+
+
+def time_variants(rounds):
+    g = torch.Generator(device="cpu").manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev).to(bf)
+    variants = [("old128", dict(mode=0)), ("p8 g4", dict(mode=1, sched=1, group=4)), ("p8 nosched", dict(mode=1, sched=0, group=4)),
+                ("p8 g1", dict(mode=1, sched=1, group=1)), ("p8 g2", dict(mode=1, sched=1, group=2)), ("p8 g8", dict(mode=1, sched=1, group=8)),
+                ("auto", dict(mode=-1))]
+    shapes = [(8232, 3072, 1024, bf, "qkv"), (8232, 4096, 1024, bf, "fc1"), (8232, 1024, 4096, torch.float32, "fc2"),
+              (8232, 1024, 1024, torch.float32, "proj"), (8192, 3072, 1024, bf, "qkv8192"), (8192, 4096, 1024, bf, "fc1_8192"),
+              (4096, 4096, 4096, bf, "4096^3"), (8192, 8192, 8192, bf, "8192^3"), (8232, 2304, 768, bf, "qkv_b"), (8232, 3072, 768, bf, "fc1_b"),
+              (43008, 1024, 512, bf, "adapter"), (43008, 1024, 256, bf, "adapterK256"), (131072, 512, 1024, bf, "fapm"),
+              (16644, 12288, 4096, bf, "7b_qkv"), (16644, 4096, 4096, torch.float32, "7b_proj")]
+    print(f"{'shape':>34} " + " ".join(f"{n:>11}" for n, _ in variants) + "   (us median | best TF/s)")
+    for M, N, K, od, name in shapes:
+        x, w = rnd(M, K), rnd(N, K)
+        out = torch.empty((M, N), dtype=od, device=dev)
+        ts = {n: [] for n, _ in variants}
+        for n, kw in variants:                     # warm-up each variant
+            opt(**kw)
+            ops.mm(x, w, out=out)
+        torch.cuda.synchronize()
+        for _ in range(rounds):
+            for n, kw in variants:
+                opt(**kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    ops.mm(x, w, out=out)
+                e1.record()
+                torch.cuda.synchronize()
+                ts[n].append(e0.elapsed_time(e1) / 5 * 1e3)
+        med = {n: sorted(v)[len(v) // 2] for n, v in ts.items()}
+        best = min(med.values())
+        print(f"{name:>10} M{M:>6} N{N:>5} K{K:>5} " + " ".join(f"{med[n]:11.1f}" for n, _ in variants)
+              + f"   | {2.0 * M * N * K / best / 1e6:7.1f}", flush=True)
+    opt()
+
+
+if __name__ == "__main__":
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+    ok = check()
+    time_variants(rounds)
+    print("CHECK", "PASSED" if ok else "FAILED")
+    sys.exit(0 if ok else 1)
