@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
   // ---- prologue: K-tiles 0 and 1 entirely, then A0(2) once A-half0[0] has been read ----
   stage(IC<0>{}, IC<0>{}, 0); stage(IC<2>{}, IC<0>{}, 0); stage(IC<3>{}, IC<0>{}, 0); stage(IC<1>{}, IC<0>{}, 0);
   stage(IC<0>{}, IC<1>{}, 1); stage(IC<2>{}, IC<1>{}, 1); stage(IC<3>{}, IC<1>{}, 1); stage(IC<1>{}, IC<1>{}, 1);
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // A0(0), B0(0) landed
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // A0(0), B0(0) and B1(0) (read in q0 of tile 0: no earlier phase waits for it) landed
   __builtin_amdgcn_s_barrier();
   readA(IC<0>{}, IC<0>{});
   readB(IC<0>{}, IC<0>{}, IC<0>{});

@@ -126,7 +126,7 @@ def vit_block(x, p: SD, cfg, sin, cos):
     return x
 
 
-def vit_intermediate(x, p: SD, cfg, rope_rescale: Optional[float] = None):
+def vit_intermediate(x, p: SD, cfg, rope_rescale=None):
     """VIT:281-318 get_intermediate_layers(n=interaction_indexes, return_class_token=True, norm=True)
     via VIT:265-279 and prepare_tokens_with_masks VIT:186-216.  Returns [(patch (B,hw,D), cls (B,D))]."""
     B = x.shape[0]
@@ -136,9 +136,13 @@ def vit_intermediate(x, p: SD, cfg, rope_rescale: Optional[float] = None):
     t = t.flatten(2).transpose(1, 2)
     cls = p["cls_token"] + 0 * p["mask_token"]                                              # VIT:195
     t = torch.cat([cls.expand(B, -1, -1), p["storage_tokens"].expand(B, -1, -1), t], dim=1)
-    sin, cos = rope_sincos(H, W, p["rope_embed.periods"], rope_rescale)
+    per_block = isinstance(rope_rescale, (list, tuple)) or (torch.is_tensor(rope_rescale) and rope_rescale.dim() == 1)
+    if not per_block:
+        sin, cos = rope_sincos(H, W, p["rope_embed.periods"], rope_rescale)
     outs = []
     for i in range(cfg["depth"]):
+        if per_block:                                                                        # train mode: one draw per block, VIT:271-272
+            sin, cos = rope_sincos(H, W, p["rope_embed.periods"], float(rope_rescale[i]))
         t = vit_block(t, p.sub(f"blocks.{i}."), cfg, sin, cos)
         if i in cfg["interaction_indexes"]:
             o = F.layer_norm(t, (D,), p["norm.weight"], p["norm.bias"], VIT_LN_EPS)          # VIT:300

@@ -157,6 +157,79 @@ def train_case(name, model_name, B, H, W, num_classes=2):
                                                       grad_norms=norms, unused=unused))), **small)
 
 
+class pin_reference_randomness:
+    """Feed fixed draws to the reference's own train-mode random ops: `torch.empty(1).uniform_(lo, hi)` of the RoPE rescale
+    (LAY/rope_position_encoding.py:96) returns the next pinned log-scale, `x.new_empty((B,1,1)).bernoulli_(keep)` of drop_path
+    (ADP:23) the next pinned 0/1 mask.  Nothing else in the forward calls these two methods (asserted by shape)."""
+
+    def __init__(self, log_scales, masks, keep):
+        self.ls, self.masks, self.keep = [float(v) for v in log_scales], [m.clone() for m in masks], keep
+        self.i = self.j = 0
+
+    def __enter__(self):
+        self._u, self._b = torch.Tensor.uniform_, torch.Tensor.bernoulli_
+        outer = self
+
+        def uniform_(t, a=0.0, b=1.0, **kw):
+            assert t.numel() == 1, t.shape
+            v = outer.ls[outer.i]; outer.i += 1
+            assert a - 1e-6 <= v <= b + 1e-6
+            return t.fill_(v)
+
+        def bernoulli_(t, p=0.5, **kw):
+            m = outer.masks[outer.j]; outer.j += 1
+            assert t.numel() == m.numel(), (t.shape, m.shape)
+            return t.copy_((m > 0).to(t.dtype).view(t.shape))
+
+        torch.Tensor.uniform_, torch.Tensor.bernoulli_ = uniform_, bernoulli_
+        return self
+
+    def __exit__(self, *a):
+        torch.Tensor.uniform_, torch.Tensor.bernoulli_ = self._u, self._b
+
+
+def train_case_pinned(name, model_name, B, H, W, num_classes=2, sample=65536, check_oracle=True):
+    """train() forward + DC/CE + backward of the REFERENCE with its random ops pinned (per-block RoPE rescale, DropPath masks):
+    golden = logits, loss, per-parameter gradient norms, and every gradient in full (<= `sample` elements) or as a fixed
+    `sample`-element subset (weights.sample_indices)."""
+    t0 = time.time()
+    net, ks, sd = build(model_name, num_classes)
+    net.train()
+    depth = len(net.encoder.dinov3_adapter.backbone.blocks)
+    log_scales, masks = weights.pinned_randomness(depth, B, seed=2)
+    x = weights.make_input(B, 3, H, W, seed=2)
+    tgt = weights.make_target(B, H, W, num_classes, seed=2)
+    with pin_reference_randomness(log_scales, masks, 0.7) as pr:
+        y_ref = net(x)
+        assert pr.i == depth and pr.j == len(masks), (pr.i, pr.j)
+    loss_ref = O.dc_and_ce_loss(y_ref, tgt)
+    loss_ref.backward()
+    named = dict(net.named_parameters())
+    g_ref = {k: p.grad for k, p in named.items() if p.requires_grad and p.grad is not None}
+    print(f"[{name}] reference train step done ({time.time() - t0:.1f}s), loss {loss_ref.item():.6f}")
+    if check_oracle:
+        with torch.no_grad():
+            y_or = O.dinounet_forward(x, sd, model_name, training=True, rope_rescale=log_scales.exp(), drop_masks=masks)
+        e = rel(y_or, y_ref.detach())
+        print(f"[{name}] oracle (pinned randomness) vs reference logits rel err {e:.2e}")
+        assert e < TOL, e
+    norms = {k: float(g.norm()) for k, g in g_ref.items()}
+    unused = sorted(k for k, p in named.items() if p.requires_grad and p.grad is None)
+    out = {}
+    tot = 0
+    for k, g in g_ref.items():
+        flat = g.flatten()
+        if flat.numel() > sample:
+            flat = flat[weights.sample_indices(k, flat.numel(), sample)]
+        out["grad:" + k] = flat.numpy().astype(np.float32)
+        tot += flat.numel()
+    print(f"[{name}] {len(g_ref)} gradients, {tot / 1e6:.2f} M elements stored")
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), logits=y_ref.detach().numpy().astype(np.float32),
+                        loss=np.float64(loss_ref.item()),
+                        meta=np.array(json.dumps(dict(model=model_name, B=B, H=H, W=W, num_classes=num_classes, mode="train_pinned",
+                                                      sample=sample, grad_norms=norms, unused=unused))), **out)
+
+
 def msda_cases():
     """ops/test.py fixture (N,M,D=1,2,2; Lq,L,P=2,2,2; shapes (6,4),(3,2); manual_seed(3)) evaluated with the
     reference's own ms_deform_attn_core_pytorch in fp64 + its gradients, for the gradcheck channel list."""
@@ -204,7 +277,7 @@ def msda_cases():
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["msda", "s", "b", "l", "train", "s512", "misc"]
+    which = sys.argv[1:] or ["msda", "s", "b", "l", "train", "s512", "misc", "b512", "l512", "pinned"]
     if "msda" in which:
         msda_cases()
     if "s" in which:
@@ -224,6 +297,13 @@ def main():
         net, ks, _ = build("dinounet_l"); dump_keys("dinounet_l", ks, net.state_dict())
     if "s512" in which:
         eval_case("dinounet_s_512_eval", "dinounet_s", 1, 3, 512, 512)
+    if "b512" in which:     # BASELINE.json configs 2-3 at their own resolution (batch 1)
+        eval_case("dinounet_b_512_eval", "dinounet_b", 1, 3, 512, 512)
+    if "l512" in which:     # the headline config's shape: N = 1029 tokens, Lq = 5376 queries, 512^2 decoder
+        eval_case("dinounet_l_512_eval", "dinounet_l", 1, 3, 512, 512)
+    if "pinned" in which:   # train mode with the random ops pinned on both sides
+        train_case_pinned("dinounet_s_64_train_pinned", "dinounet_s", 2, 64, 64, sample=4096)
+        train_case_pinned("dinounet_l_256_train_pinned", "dinounet_l", 2, 256, 256, sample=16384)
 
 
 if __name__ == "__main__":

@@ -84,3 +84,23 @@ def make_input(batch, channels, H, W, seed=0):
 def make_target(batch, H, W, num_classes, seed=0):
     g = torch.Generator(device="cpu"); g.manual_seed(2000 + seed)
     return torch.randint(0, num_classes, (batch, 1, H, W), generator=g)
+
+
+def pinned_randomness(depth, batch, n_drop_paths=6, drop_prob=0.3, rescale=2.0, seed=0):
+    """Fixed draws for the train-mode random ops, fed to BOTH sides of a parity test: one log-uniform RoPE rescale factor per ViT
+    block (LAY/rope_position_encoding.py:93-97, redrawn in every block, VIT:271-272) and one per-sample DropPath mask per extractor
+    (ADP:18-26, already divided by keep_prob).  Returns (log_scales (depth,) fp32, [masks (batch,) fp32] * n_drop_paths)."""
+    g = torch.Generator(device="cpu"); g.manual_seed(3000 + seed)
+    mx = math.log(rescale)
+    log_scales = (torch.rand(depth, generator=g) * 2 - 1) * mx
+    keep = 1.0 - drop_prob
+    masks = [(torch.rand(batch, generator=g) < keep).float() / keep for _ in range(n_drop_paths)]
+    masks[1][0] = 0.0            # make sure at least one sample is dropped and one kept somewhere
+    masks[1][-1] = 1.0 / keep
+    return log_scales, masks
+
+
+def sample_indices(key: str, numel: int, n: int) -> torch.Tensor:
+    """Deterministic element sample of a flattened tensor (gradient fixtures of tensors too large to commit in full)."""
+    g = _gen("sample:" + canonical_key(key), 0)
+    return torch.randperm(numel, generator=g)[:n].sort().values

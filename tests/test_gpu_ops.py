@@ -76,8 +76,9 @@ def test_gemm_ragged_tail_split(N, K):
     a = _lib.GemmArgs()
     a.dtype, a.out_dtype, a.a_mode, a.b_mode, a.M, a.N, a.K = _lib.DU_BF16, _lib.DU_BF16, 0, 0, M, N, K
     a.lda, a.ldb, a.ldc, a.batch, a.split_k = K, K, N, 1, 1
-    # one or two exact rounds of full tiles (N = 1024: 512 tiles on 512 slots) are split; three (N = 3072) measured no gain and are not
-    assert (int(_lib.lib().du_gemm_ws_elems(ctypes.byref(a))) > 0) == (N == 1024)
+    # every ViT-L product sheds its last 40 rows: behind 256 x 256 tiles (gemm_p8.hip) a ragged 33rd tile row would run a full K loop
+    # for 40 live rows; behind 128 x 128 tiles one or two exact rounds of full tiles (N = 1024: 512 tiles on 512 slots) are split
+    assert int(_lib.lib().du_gemm_ws_elems(ctypes.byref(a))) > 0
     ref = x.float() @ w.float().t()
     y = ops.mm(x, w, bias=b, act=ACT_GELU)
     assert y.dtype == bf and rel(y, F.gelu(ref + b)) < TOL[bf]
