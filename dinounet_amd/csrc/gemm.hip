@@ -297,6 +297,14 @@ int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st);   // gemm_bf16.hip
 int du_gemm_ragged_rows(const du_gemm_args& a);                      // gemm_bf16.hip
 int64_t du_gemm_skinny_ws_elems(int N, int K);                      // gemm_skinny.hip
 
+int du_gemm_route_bf16(const du_gemm_args& a);                       // gemm_bf16.hip
+
+extern "C" int du_gemm_route(const du_gemm_args* pa) {
+  if (!pa) return DU_ERR_BAD_ARG;
+  static const bool generic = getenv("DU_GEMM_GENERIC") != nullptr;
+  return generic ? 0 : du_gemm_route_bf16(*pa);
+}
+
 extern "C" int64_t du_gemm_ws_elems(const du_gemm_args* pa) {
   if (!pa) return 0;
   static const bool generic = getenv("DU_GEMM_GENERIC") != nullptr;

@@ -369,6 +369,8 @@ int64_t du_gemm_skinny_ws_elems(int N, int K);
 
 int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st);     // gemm_p8.hip
 bool du_gemm_p8_wants(const du_gemm_args& a);
+int du_gemm_p8_choice(const du_gemm_args& a);
+bool du_gemm_glds_serves(const du_gemm_args& a);              // gemm_glds.hip
 
 // Rows of a tall bf16 NT product that should leave the tile grid for the K-parallel skinny kernels (gemm_skinny.hip).
 //  * products served by the 256 x 256 multi-phase kernel (gemm_p8.hip): r = M % 256 when 0 < r <= 64 (the ViT: M = 8 * 1029 =
@@ -452,4 +454,18 @@ int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
   }
   if (a.out_dtype == DU_BF16) return launch_modes<bf16_t>(a, st);
   return launch_modes<float>(a, st);
+}
+
+// which kernel family du_gemm runs for the bulk of this product (measurement tools name the kernel from this, not from a mirror of the
+// dispatch): 0 generic (gemm.hip), 1 bf16 tile engine (this file), 2 128 x 128 direct-to-LDS (gemm_glds.hip), 3 / 4 the 256 x 256 /
+// 256 x 128 multi-phase kernels (gemm_p8.hip)
+int du_gemm_route_bf16(const du_gemm_args& a) {
+  if (a.dtype != DU_BF16) return 0;
+  if (a.N % 4 || a.ldc % 4 || (((uintptr_t)a.C) & 15)) return 0;
+  du_gemm_args head = a;
+  const int r = du_gemm_ragged_rows(a);
+  if (r > 0) head.M = a.M - r;
+  const int c = du_gemm_p8_choice(head);
+  if (c) return 2 + c;
+  return du_gemm_glds_serves(head) ? 2 : 1;
 }

@@ -254,12 +254,16 @@ int launch(const du_gemm_args& a, hipStream_t st) {
 
 }  // namespace
 
+bool du_gemm_glds_serves(const du_gemm_args& a) {
+  if (a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.dtype != DU_BF16) return false;
+  if (a.K % 64 || a.split_k > 1 || a.N < 96 || a.M < 64) return false;
+  static const bool off = getenv("DU_GEMM_NO_GLDS") != nullptr;   // debugging / A-B aid
+  return !off;
+}
+
 // returns DU_ERR_UNSUPPORTED when the shape / mode is not served by this kernel (caller falls back to gemm_bf16.hip)
 int du_gemm_nt_glds(const du_gemm_args& a, hipStream_t st) {
-  if (a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.dtype != DU_BF16) return DU_ERR_UNSUPPORTED;
-  if (a.K % 64 || a.split_k > 1 || a.N < 96 || a.M < 64) return DU_ERR_UNSUPPORTED;
-  static const bool off = getenv("DU_GEMM_NO_GLDS") != nullptr;   // debugging / A-B aid
-  if (off) return DU_ERR_UNSUPPORTED;
+  if (!du_gemm_glds_serves(a)) return DU_ERR_UNSUPPORTED;
   static const char* var = getenv("DU_GLDS_VARIANT");             // "3": force the 3-stage BK=32 ring, "2": force the 2-stage BK=64 kernel
   // measured (tools/gemm_bench.py): the 3-stage BK=32 ring wins for short contractions (K <= 512: +8..20 %, more workgroups per
   // CU and a deeper DMA queue), the 2-stage BK=64 kernel for K >= 1024 (fewer barriers per flop)

@@ -28,6 +28,14 @@
 // use exact smaller counts (nothing is issued past the end of K).
 //
 // Rows past M / N read as zeros through the buffer descriptor's bounds check (their products are never stored).  K % 128 == 0, K >= 256.
+//
+// gemm_nt_p8n_kernel is the 256 x 128 sibling for products whose 256 x 256 tile count quantises badly on 256 CUs (ViT-L proj / fc2:
+// 128 tiles, qkv: 384 = 1.5 rounds): 8 waves as 4 x 2 (64 x 64 per wave), two phases per K step (A-half 0 / 1 against the whole
+// 128-row B tile), THREE 48 KB LDS buffers rotated at run time (a K-tile is issued five phases before its first read, counted
+// vmcnt(6)).  Both kernels feed the MFMA with (B fragment, A fragment): the accumulator then holds, per lane, one output row and
+// 4 consecutive columns per register quad, so the epilogue stages 8-byte (bf16, after bias / activation / LayerScale in registers)
+// or 16-byte (fp32) pieces into a row-major LDS tile and writes whole 512-byte output rows (a lane-per-row store would touch 32
+// cache lines per instruction).
 #include "common.h"
 #include "gemm_params.h"
 
@@ -61,33 +69,25 @@ template <> struct Out4p<bf16_t> {
 
 template <int N> struct IC { static constexpr int value = N; };
 
-__device__ __forceinline__ void wait_vm_halves(int h) {
-  // outstanding LDS-DMA instructions allowed = 2 per half-tile
-  switch (h) {
-    case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+__device__ __forceinline__ void wait_vm_count(int n) {      // n = LDS-DMA instructions that may stay in flight (even, <= 12)
+  switch (n) {
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
 
-template <typename TC, int SCHED>
-__global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  int tile;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;     // bijective XCD remap: an XCD owns a run of tiles
-  }
-  int tm, tn;
-  if (P.group_m > 1) {      // bands of group_m tile rows walked column by column: an XCD's ~32 resident tiles share few A / B panels
+// XCD-aware tile order shared by both kernels: an XCD owns a run of tiles; inside it bands of group_m tile rows are walked column
+// by column so the ~32 resident tiles of an XCD share few A / B panels through its L2.
+__device__ __forceinline__ void tile_coords(const GemmParams& P, int& tm, int& tn) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;     // bijective
+  if (P.group_m > 1) {
     const int band = P.group_m * P.tiles_n;
     const int g = tile / band, l = tile - g * band;
     const int first = g * P.group_m;
@@ -96,6 +96,152 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
   } else {
     tm = tile / P.tiles_n; tn = tile - tm * P.tiles_n;
   }
+}
+
+// ---- epilogue pieces.  Accumulator layout (MFMA fed with (B fragment, A fragment)): lane l holds output row (l & 31) of the 32 x 32
+// block and columns 8 g + 4 (l >> 5) + e of it in registers 4 g + e. ----
+
+// erf GELU without branches (the libm erff takes two exec-masked paths, ~40 VALU per element): Abramowitz-Stegun 7.1.26, |erf error|
+// < 1.5e-7, i.e. far inside the bf16 rounding of the stored value; used only on the bf16-output path (fc1 of the frozen ViT)
+__device__ __forceinline__ float gelu_fast(float v) {
+  const float x = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = p * t * __expf(-x * x);          // erfc(|x|)
+  return 0.5f * v * (v < 0.f ? e : 2.0f - e);
+}
+
+// bf16 staging of one 32 x 32 block: bias (+ GELU) in registers, 4 columns packed into one ds_write_b64
+template <int ACT>
+__device__ __forceinline__ void stage_block_bf16(const f32x16& a, const float4 (&bv)[4], bf16_t* stg, int ldb, int srow, int scol, int hi) {
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    float o[4] = {a[4 * g] + bv[g].x, a[4 * g + 1] + bv[g].y, a[4 * g + 2] + bv[g].z, a[4 * g + 3] + bv[g].w};
+    if constexpr (ACT == DU_ACT_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] = gelu_fast(o[e]);
+    }
+    bf16x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; e++) t[e] = (bf16_t)o[e];
+    *(uint2*)(stg + srow * ldb + scol + 8 * g + 4 * hi) = __builtin_bit_cast(uint2, t);
+  }
+}
+// this lane's bias values for the block whose first column is ncol0 (zeros without a bias); columns past N are clamped (never stored)
+__device__ __forceinline__ void load_bias4(const GemmParams& P, int ncol0, int hi, float4 (&bv)[4]) {
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const int n = ncol0 + 8 * g + 4 * hi;
+    bv[g] = P.bias ? *(const float4*)(P.bias + (n < P.N ? n : 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__device__ __forceinline__ void stage_block_f32(const f32x16& a, float* stg, int ldf, int srow, int scol, int lane) {
+  const int hi = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+    *(float4*)(stg + srow * ldf + scol + 8 * g + 4 * hi) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+}
+// rows [0, nrows) of the bf16 staging tile -> C rows mrow0 + ...: 16 bytes per lane, whole rows per wave
+template <int TBN>
+__device__ __forceinline__ void readout_bf16(const GemmParams& P, const bf16_t* stg, int ldb, int nrows, int mrow0, int n0, bf16_t* Cb, int tid) {
+  constexpr int C8 = TBN / 8;
+  const bool wide = (P.ldc % 8 == 0) && ((((uintptr_t)Cb) & 15) == 0);
+#pragma unroll 4
+  for (int v = tid; v < nrows * C8; v += 512) {
+    const int row = v / C8, c8 = v % C8;
+    const int m = mrow0 + row, n = n0 + c8 * 8;
+    if (m >= P.M || n >= P.N) continue;
+    const uint4 t = *(const uint4*)(stg + row * ldb + c8 * 8);
+    if ((P.ps_H & 1) && t.x != 0x12345678u) continue;      // measurement aid (du_set_option key 3): staging without the global stores
+    bf16_t* dst = Cb + (long)m * P.ldc + n;
+    if (wide && n + 8 <= P.N) *(uint4*)dst = t;
+    else {
+      *(uint2*)dst = make_uint2(t.x, t.y);
+      if (n + 8 <= P.N) *(uint2*)(dst + 4) = make_uint2(t.z, t.w);
+    }
+  }
+}
+// rows of the fp32 staging tile -> C with the full du_gemm epilogue (alpha, bias, act, gamma, row_scale, residual).  ACT: the
+// activation when it is known at compile time (NONE / GELU), -1 = read P.act per element.  Four 16-byte pieces per thread and trip:
+// the residual loads of a trip are all issued before the first is consumed.
+template <typename TC, int TBN, int ACT>
+__device__ __forceinline__ void readout_f32(const GemmParams& P, const float* stg, int ldf, int nrows, int mrow0, int n0, TC* Cb, const TC* Rb,
+                                            int tid) {
+  constexpr int C4 = TBN / 4, U = 4;
+  const int total = nrows * C4;
+  for (int v0 = tid; v0 < total; v0 += 512 * U) {
+    float rr[U][4];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int v = v0 + u * 512;
+      const int row = v / C4, c4 = v % C4;
+      const int m = mrow0 + row, n = n0 + c4 * 4;
+      live[u] = v < total && m < P.M && n < P.N;
+      rr[u][0] = rr[u][1] = rr[u][2] = rr[u][3] = 0.f;
+      if (Rb && live[u]) Out4p<TC>::load(Rb + (long)m * P.ldr + n, rr[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (!live[u]) continue;
+      const int v = v0 + u * 512;
+      const int row = v / C4, c4 = v % C4;
+      const int m = mrow0 + row, n = n0 + c4 * 4;
+      const float4 tt = *(const float4*)(stg + row * ldf + c4 * 4);
+      float o[4] = {tt.x * P.alpha, tt.y * P.alpha, tt.z * P.alpha, tt.w * P.alpha};
+      if (P.bias) {
+        const float4 bb = *(const float4*)(P.bias + n);
+        o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
+      }
+      if constexpr (ACT == DU_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = apply_act(o[e], DU_ACT_GELU);
+      } else if constexpr (ACT < 0) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = apply_act(o[e], P.act);
+      }
+      if (P.gamma) {
+        const float4 gg = *(const float4*)(P.gamma + n);
+        o[0] *= gg.x; o[1] *= gg.y; o[2] *= gg.z; o[3] *= gg.w;
+      }
+      if (P.row_scale) {
+        const float rs = P.row_scale[m / P.rs_rows];
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] *= rs;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] += rr[u][e];
+      Out4p<TC>::store(Cb + (long)m * P.ldc + n, o);
+    }
+  }
+}
+template <typename TC, int TBN>
+__device__ __forceinline__ void readout_f32_any(const GemmParams& P, const float* stg, int ldf, int nrows, int mrow0, int n0, TC* Cb,
+                                                const TC* Rb, int tid) {
+  if (P.act == DU_ACT_NONE) readout_f32<TC, TBN, DU_ACT_NONE>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
+  else if (P.act == DU_ACT_GELU) readout_f32<TC, TBN, DU_ACT_GELU>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
+  else readout_f32<TC, TBN, -1>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
+}
+// bf16 result whose epilogue is bias (+ GELU) only: staged as bf16 (the ViT's qkv and fc1)
+__device__ __forceinline__ bool bf16_simple(const GemmParams& P, const void* Rb) {
+  return !Rb && !P.gamma && !P.row_scale && P.alpha == 1.0f && (P.act == DU_ACT_NONE || P.act == DU_ACT_GELU);
+}
+
+constexpr int P8_STG_LDB = PBN + 8;            // bf16 staging row, elements (528 B: 16-byte aligned rows, 2-way ds_write_b64 conflicts)
+constexpr int P8_STG_LDF = PBN + 4;            // fp32 staging row, floats (1040 B: conflict-free ds_write_b128)
+constexpr int P8_LDS = 256 * P8_STG_LDB * 2;   // 135 168 B >= 2 * BUF_B and >= 128 * P8_STG_LDF * 4
+
+template <typename TC, int SCHED>
+__global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int tm, tn;
+  tile_coords(P, tm, tn);
   const int m0 = tm * PBM, n0 = tn * PBN;
   const int batch = blockIdx.y;
 
@@ -175,11 +321,11 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
     for (int kk = 0; kk < 4; kk++)
 #pragma unroll
       for (int b = 0; b < 2; b++)
-        acc[i][j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[i][b][kk], Bf[bset][kk], acc[i][j][b], 0, 0, 0);
+        acc[i][j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[bset][kk], Af[i][b][kk], acc[i][j][b], 0, 0, 0);
   };
   // pin the issue order of a phase.  The compiler orders every ds_read of the phase before its LDS-DMA issues (it must assume they
   // alias), so the reads ride behind the first four MFMAs and the two DMA issues behind the next two.
-  auto pin = [&](auto nrd_c, bool) {
+  auto pin = [&](auto nrd_c) {
     constexpr int nrd = decltype(nrd_c)::value;
     if constexpr (SCHED == 1) {
 #pragma unroll
@@ -203,7 +349,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
       if constexpr (TAIL) {
         int h = 4 * (nk - t - 1) - q;
         h = h < 0 ? 0 : (h > 6 ? 6 : h);
-        wait_vm_halves(h);
+        wait_vm_count(2 * h);
       } else {
         asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       }
@@ -215,25 +361,25 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
     readB(IC<b1set>{}, IC<1>{}, IC<p>{});
     if (!TAIL || t + 2 < nk) stage(IC<2>{}, IC<p>{}, t + 2);
     mma(IC<0>{}, IC<0>{}, IC<b0set>{});
-    pin(IC<4>{}, true);
+    pin(IC<4>{});
     finish(0);
     // q1
     readA(IC<1>{}, IC<p>{});
     if (!TAIL || t + 2 < nk) stage(IC<3>{}, IC<p>{}, t + 2);
     mma(IC<0>{}, IC<1>{}, IC<b1set>{});
-    pin(IC<8>{}, true);
+    pin(IC<8>{});
     finish(1);
     // q2
     if (!TAIL || t + 1 < nk) readA(IC<0>{}, IC<1 - p>{});
     if (!TAIL || t + 2 < nk) stage(IC<1>{}, IC<p>{}, t + 2);
     mma(IC<1>{}, IC<1>{}, IC<b1set>{});
-    pin(IC<8>{}, true);
+    pin(IC<8>{});
     finish(2);
     // q3  (the next tile's B-half0 goes to the set that held this tile's B-half1)
     if (!TAIL || t + 1 < nk) readB(IC<b1set>{}, IC<0>{}, IC<1 - p>{});
     if (!TAIL || t + 3 < nk) stage(IC<0>{}, IC<1 - p>{}, t + 3);
     mma(IC<1>{}, IC<0>{}, IC<b0set>{});
-    pin(IC<4>{}, true);
+    pin(IC<4>{});
     finish(3);
   };
 
@@ -259,71 +405,266 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
     ktile(IC<1>{}, IC<true>{}, t + 1);
   }
 
-  // ---- LDS-staged epilogue: 4 passes of 64 rows x 256 columns of fp32 (pass = quadrant row i, row block b) ----
+  // ---- epilogue (every LDS read of the main loop is behind the last phase's lgkmcnt(0) + barrier) ----
   TC* Cb = (TC*)P.C + (long)batch * P.cbs;
-  float* stg = (float*)smem;
   const TC* Rb = (const TC*)P.residual;
   if (Rb) Rb += (long)batch * P.cbs;
-  constexpr int C4 = PBN / 4;
+  if (P.ps_H & 2) return;            // measurement aid (du_set_option key 3): no epilogue at all
+  bool done = false;
+  if constexpr (sizeof(TC) == 2) {
+    if (bf16_simple(P, Rb)) {        // the whole 256 x 256 tile staged as bf16, one pass
+      bf16_t* stg = (bf16_t*)smem;
+      const int hi = lane >> 5;
+      float4 bv[2][4];
 #pragma unroll
-  for (int pass = 0; pass < 4; pass++) {
-    const int i = pass >> 1, b = pass & 1;
-    if (pass > 0) __syncthreads();
+      for (int j = 0; j < 2; j++) load_bias4(P, n0 + j * 128 + wn * 32, hi, bv[j]);
+      auto stage_all = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+        for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int r = 0; r < 16; r++)
-        stg[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * STG_LD + j * 128 + wn * 32 + (lane & 31)] = acc[i][j][b][r];
-    __syncthreads();
-#pragma unroll 2
-    for (int v = tid; v < 64 * C4; v += 512) {
-      const int row = v / C4, c4 = v % C4;
-      const int m = m0 + i * 128 + (row >> 5) * 64 + b * 32 + (row & 31);
-      const int n = n0 + c4 * 4;
-      if (m >= P.M || n >= P.N) continue;
-      float4 tt = *(const float4*)(stg + row * STG_LD + c4 * 4);
-      float o[4] = {tt.x * P.alpha, tt.y * P.alpha, tt.z * P.alpha, tt.w * P.alpha};
-      if (P.bias) {
-        float4 bb = *(const float4*)(P.bias + n);
-        o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
-      }
-      if (P.act != DU_ACT_NONE) {
+          for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) o[e] = apply_act(o[e], P.act);
-      }
-      if (P.gamma) {
-        float4 gg = *(const float4*)(P.gamma + n);
-        o[0] *= gg.x; o[1] *= gg.y; o[2] *= gg.z; o[3] *= gg.w;
-      }
-      if (P.row_scale) {
-        const float rs = P.row_scale[m / P.rs_rows];
+            for (int b = 0; b < 2; b++)
+              stage_block_bf16<ACT>(acc[i][j][b], bv[j], stg, P8_STG_LDB, i * 128 + wm * 64 + b * 32 + (lane & 31), j * 128 + wn * 32, hi);
+      };
+      if (P.act == DU_ACT_GELU) stage_all(IC<DU_ACT_GELU>{}); else stage_all(IC<DU_ACT_NONE>{});
+      __syncthreads();
+      readout_bf16<PBN>(P, stg, P8_STG_LDB, 256, m0, n0, (bf16_t*)Cb, tid);
+      done = true;
+    }
+  }
+  if (!done) {          // fp32 staging, two passes of 128 rows (quadrant row i)
+    float* stg = (float*)smem;
 #pragma unroll
-        for (int e = 0; e < 4; e++) o[e] *= rs;
-      }
-      const long off = (long)m * P.ldc + n;
-      if (Rb) {
-        float rr[4];
-        Out4p<TC>::load(Rb + (long)m * P.ldr + n, rr);
+    for (int i = 0; i < 2; i++) {
+      if (i > 0) __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; e++) o[e] += rr[e];
-      }
-      Out4p<TC>::store(Cb + off, o);
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+          stage_block_f32(acc[i][j][b], stg, P8_STG_LDF, wm * 64 + b * 32 + (lane & 31), j * 128 + wn * 32, lane);
+      __syncthreads();
+      readout_f32_any<TC, PBN>(P, stg, P8_STG_LDF, 128, m0 + i * 128, n0, Cb, Rb, tid);
     }
   }
 }
 
-int g_p8_mode = -1;      // -1: heuristic, 0: off, 1: force where legal
-int g_p8_sched = 1;
-int g_p8_group = 4;
+// ================================================================================================================================
+// 256 x 128 tiles: 8 waves as 4 (M) x 2 (N), 64 x 64 per wave; three 48 KB LDS buffers { A-half0, A-half1, B } rotated at run time.
+//   q0(t): MFMA (A0f, B) | ds_read A1(t) -> A1f                       | DMA A0(t+2), B(t+2) -> buffer (t+2) % 3
+//   q1(t): MFMA (A1f, B) | ds_read A0(t+1) -> A0f, B(t+1) -> other set | DMA A1(t+2)
+// Buffer (t+2) % 3 held tile t-1, last read in q1(t-2) (A0, B) and q0(t-1) (A1): free when q0(t) starts.  Issue order per tile:
+// A0 B | A1; at the end of either phase the data read next is followed by exactly 6 younger DMA instructions => vmcnt(6).
+// ================================================================================================================================
+constexpr int NBN = 128;
+constexpr int NBUF_B = 3 * HALF_B;             // 48 KB
+constexpr int N_STG_LDB = NBN + 8;             // 272 B rows
+constexpr int N_STG_LDF = NBN + 4;             // 528 B rows
+constexpr int P8N_LDS = 3 * NBUF_B;            // 147 456 B >= 256 * N_STG_LDF * 4 = 135 168
 
 template <typename TC, int SCHED>
+__global__ __launch_bounds__(512) void gemm_nt_p8n_kernel(GemmParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int tm, tn;
+  tile_coords(P, tm, tn);
+  const int m0 = tm * PBM, n0 = tn * NBN;
+  const int batch = blockIdx.y;
+
+  const bf16_t* Ab = (const bf16_t*)P.a.p + (long)batch * P.a.bstride + (long)m0 * P.a.ld;
+  const bf16_t* Bb = (const bf16_t*)P.b.p + (long)batch * P.b.bstride + (long)n0 * P.b.ld;
+  long abytes = ((long)(P.M - m0) * P.a.ld - (P.a.ld - P.K)) * 2, bbytes = ((long)(P.N - n0) * P.b.ld - (P.b.ld - P.K)) * 2;
+  if (abytes > 0x7fffffffL) abytes = 0x7fffffffL;
+  if (bbytes > 0x7fffffffL) bbytes = 0x7fffffffL;
+  const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)abytes, 0x00020000);
+  const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)bbytes, 0x00020000);
+
+  unsigned va[2][2], vb[2];
+  {
+    const int sw = ((wave & 1) << 2) | (lane >> 4);
+    const int lc = (lane & 7) ^ sw;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int row = (r * 8 + wave) * 8 + (lane >> 3);
+      va[0][r] = (unsigned)row * (unsigned)(P.a.ld * 2) + lc * 16;
+      va[1][r] = (unsigned)(128 + row) * (unsigned)(P.a.ld * 2) + lc * 16;
+      vb[r] = (unsigned)row * (unsigned)(P.b.ld * 2) + lc * 16;
+    }
+  }
+  // which: 0 = A-half0, 1 = A-half1, 2 = B of K-tile kt, into the buffer at byte offset bo
+  auto stage = [&](auto which_c, int bo, int kt) {
+    constexpr int which = decltype(which_c)::value;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      unsigned char* dst = smem + bo + which * HALF_B + (r * 8 + wave) * 1024;
+      if constexpr (which < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, va[which][r], kt * (PBK * 2), 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)dst, 16, vb[r], kt * (PBK * 2), 0, 0);
+    }
+  };
+  int L[4];
+  {
+    const int x = (lane >> 5) ^ ((lane >> 1) & 7);
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) L[kk] = (lane & 31) * 128 + ((x ^ (2 * kk)) << 4);
+  }
+  const int aoff = wm * 32 * 128, boff = 2 * HALF_B + wn * 64 * 128;
+
+  bf16x8 Af[2][4];        // [set = A half][kk]
+  bf16x8 Bf[2][2][4];     // [set][column block][kk]
+  f32x16 acc[2][2];       // [i][column block]
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][c][r] = 0.f;
+
+  auto readA = [&](auto set_c, int bo) {
+    constexpr int set = decltype(set_c)::value;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) Af[set][kk] = *(const bf16x8*)(smem + bo + set * HALF_B + aoff + L[kk]);
+  };
+  auto readB = [&](auto set_c, int bo) {
+    constexpr int set = decltype(set_c)::value;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) Bf[set][c][kk] = *(const bf16x8*)(smem + bo + boff + c * 4096 + L[kk]);
+  };
+  auto mma = [&](auto i_c, auto bset_c) {
+    constexpr int i = decltype(i_c)::value, bset = decltype(bset_c)::value;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+        acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[bset][c][kk], Af[i][kk], acc[i][c], 0, 0, 0);
+  };
+  auto pin = [&](auto nrd_c, auto ndma_c) {
+    constexpr int nrd = decltype(nrd_c)::value, ndma = decltype(ndma_c)::value;
+    if constexpr (SCHED == 1) {
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (m < 4) __builtin_amdgcn_sched_group_barrier(0x100, nrd / 4, 0);
+        else if (m - 4 < ndma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+    }
+  };
+
+  const int nk = P.K / PBK;
+  auto finish = [&](int vm) {
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vm_count(vm);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto finish6 = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // one K-tile; bc / bn / bnn = byte offsets of the buffers of tiles t, t+1, t+2
+  auto ktile = [&](auto par_c, auto tail_c, int t, int bc, int bn, int bnn) {
+    constexpr int p = decltype(par_c)::value;
+    constexpr bool TAIL = decltype(tail_c)::value;
+    // q0
+    readA(IC<1>{}, bc);
+    if (!TAIL || t + 2 < nk) { stage(IC<0>{}, bnn, t + 2); stage(IC<2>{}, bnn, t + 2); }
+    mma(IC<0>{}, IC<p>{});
+    pin(IC<4>{}, IC<4>{});
+    if constexpr (TAIL) finish((t + 1 < nk ? 2 : 0) + (t + 2 < nk ? 4 : 0)); else finish6();
+    // q1
+    if (!TAIL || t + 1 < nk) { readA(IC<0>{}, bn); readB(IC<1 - p>{}, bn); }
+    if (!TAIL || t + 2 < nk) stage(IC<1>{}, bnn, t + 2);
+    mma(IC<1>{}, IC<p>{});
+    pin(IC<12>{}, IC<2>{});
+    if constexpr (TAIL) finish(t + 2 < nk ? 6 : 0); else finish6();
+  };
+
+  // ---- prologue: K-tiles 0 and 1 ----
+  stage(IC<0>{}, 0, 0); stage(IC<2>{}, 0, 0); stage(IC<1>{}, 0, 0);
+  stage(IC<0>{}, NBUF_B, 1); stage(IC<2>{}, NBUF_B, 1); stage(IC<1>{}, NBUF_B, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // tile 0 landed (A-half1 is read in q0(0))
+  __builtin_amdgcn_s_barrier();
+  readA(IC<0>{}, 0);
+  readB(IC<0>{}, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  int bc = 0, bn = NBUF_B, bnn = 2 * NBUF_B;
+  int t = 0;
+  for (; t + 4 <= nk; t += 2) {
+    ktile(IC<0>{}, IC<false>{}, t, bc, bn, bnn);
+    ktile(IC<1>{}, IC<false>{}, t + 1, bn, bnn, bc);
+    const int o = bc; bc = bnn; bnn = bn; bn = o;        // advance two tiles: (bc, bn, bnn) <- (bnn, bc, bn)
+  }
+  for (; t < nk; t += 2) {
+    ktile(IC<0>{}, IC<true>{}, t, bc, bn, bnn);
+    ktile(IC<1>{}, IC<true>{}, t + 1, bn, bnn, bc);
+    const int o = bc; bc = bnn; bnn = bn; bn = o;
+  }
+
+  // ---- epilogue: one pass, 256 rows x 128 columns ----
+  TC* Cb = (TC*)P.C + (long)batch * P.cbs;
+  const TC* Rb = (const TC*)P.residual;
+  if (Rb) Rb += (long)batch * P.cbs;
+  if (P.ps_H & 2) return;
+  bool done = false;
+  if constexpr (sizeof(TC) == 2) {
+    if (bf16_simple(P, Rb)) {
+      bf16_t* stg = (bf16_t*)smem;
+      const int hi = lane >> 5;
+      float4 bv[2][4];
+#pragma unroll
+      for (int c = 0; c < 2; c++) load_bias4(P, n0 + wn * 64 + c * 32, hi, bv[c]);
+      auto stage_all = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int c = 0; c < 2; c++)
+            stage_block_bf16<ACT>(acc[i][c], bv[c], stg, N_STG_LDB, i * 128 + wm * 32 + (lane & 31), wn * 64 + c * 32, hi);
+      };
+      if (P.act == DU_ACT_GELU) stage_all(IC<DU_ACT_GELU>{}); else stage_all(IC<DU_ACT_NONE>{});
+      __syncthreads();
+      readout_bf16<NBN>(P, stg, N_STG_LDB, 256, m0, n0, (bf16_t*)Cb, tid);
+      done = true;
+    }
+  }
+  if (!done) {
+    float* stg = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+        stage_block_f32(acc[i][c], stg, N_STG_LDF, i * 128 + wm * 32 + (lane & 31), wn * 64 + c * 32, lane);
+    __syncthreads();
+    readout_f32_any<TC, NBN>(P, stg, N_STG_LDF, 256, m0, n0, Cb, Rb, tid);
+  }
+}
+
+int g_p8_mode = -1;      // -1: heuristic, 0: off, 1: 256 x 256 wherever legal, 2: 256 x 128 wherever legal
+int g_p8_sched = 1;
+int g_p8_group = 4;
+int g_p8_debug = 0;      // bit 0: skip the bf16 global stores, bit 1: skip the whole epilogue (timing ablations only)
+
+template <typename TC, int SCHED, bool NARROW>
 int launch_p8(const du_gemm_args& a, hipStream_t st) {
-  constexpr int LDS_BYTES = 2 * BUF_B;       // 128 KB (the epilogue staging needs 64 * 260 * 4 = 65 KB of it)
-  GemmParams P = make_params(a, DU_PLAIN_ROW, DU_PLAIN_ROW, PBM, PBN, PBK);
+  constexpr int LDS_BYTES = NARROW ? P8N_LDS : P8_LDS;
+  constexpr int TBN = NARROW ? NBN : PBN;
+  GemmParams P = make_params(a, DU_PLAIN_ROW, DU_PLAIN_ROW, PBM, TBN, PBK);
   P.tiles_m = (a.M + PBM - 1) / PBM;
   P.group_m = g_p8_group;
+  P.ps_H = g_p8_debug;           // pixel-shuffle geometry is unused by these kernels (plain stores only)
   dim3 grid(P.tiles_m * P.tiles_n, a.batch < 1 ? 1 : a.batch);
-  auto kfn = gemm_nt_p8_kernel<TC, SCHED>;
+  void (*kfn)(GemmParams);
+  if constexpr (NARROW) kfn = gemm_nt_p8n_kernel<TC, SCHED>; else kfn = gemm_nt_p8_kernel<TC, SCHED>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return DU_ERR_LAUNCH;
@@ -341,11 +682,12 @@ extern "C" int du_set_option(int key, int value) {
     case 0: g_p8_mode = value; return DU_OK;
     case 1: g_p8_sched = value; return DU_OK;
     case 2: g_p8_group = value; return DU_OK;
+    case 3: g_p8_debug = value; return DU_OK;
     default: return DU_ERR_BAD_ARG;
   }
 }
 
-// true when the 256 x 256 multi-phase kernel can run this product at all
+// true when the multi-phase kernels can run this product at all
 static bool p8_legal(const du_gemm_args& a) {
   if (a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.dtype != DU_BF16) return false;
   if (a.store_mode != DU_STORE_PLAIN || a.split_k > 1) return false;
@@ -356,18 +698,31 @@ static bool p8_legal(const du_gemm_args& a) {
   return true;
 }
 
-// true when du_gemm routes this product to the 256 x 256 multi-phase kernel (legal, and the heuristic or the debug knob says so)
-bool du_gemm_p8_wants(const du_gemm_args& a) {
-  if (g_p8_mode == 0 || !p8_legal(a)) return false;
-  if (g_p8_mode > 0) return true;
-  // enough 256 x 256 tiles to occupy the 256 CUs, long enough contraction to amortise the 9-half-tile prologue
-  const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) * (a.batch < 1 ? 1 : a.batch);
-  return tiles >= 192 && a.K >= 512;
+// 0: not served by gemm_p8.hip, 1: 256 x 256 tiles, 2: 256 x 128 tiles
+int du_gemm_p8_choice(const du_gemm_args& a) {
+  if (g_p8_mode == 0 || !p8_legal(a)) return 0;
+  if (g_p8_mode > 0) return g_p8_mode == 2 ? 2 : 1;
+  // rounds of workgroups on the 256 CUs (one 8-wave workgroup per CU) x cost per workgroup (a 256 x 128 tile costs ~0.56 of a
+  // 256 x 256 one: half the MFMAs at a lower operand reuse); measured crossovers: tools/gemm_p8_bench.py
+  const long batch = a.batch < 1 ? 1 : a.batch;
+  const long tm = (a.M + 255) / 256;
+  const long t256 = tm * ((a.N + 255) / 256) * batch, t128 = tm * ((a.N + 127) / 128) * batch;
+  if (t128 < 192) return 0;
+  const double c256 = (double)((t256 + 255) / 256) * 1.0, c128 = (double)((t128 + 255) / 256) * 0.56;
+  if (t256 >= 192 && c256 <= c128) return 1;
+  return 2;
 }
+bool du_gemm_p8_wants(const du_gemm_args& a) { return du_gemm_p8_choice(a) != 0; }
 
-// returns DU_ERR_UNSUPPORTED when this kernel cannot serve the product; the caller then uses gemm_glds.hip
+// returns DU_ERR_UNSUPPORTED when these kernels cannot serve the product; the caller then uses gemm_glds.hip
 int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st) {
-  if (!p8_legal(a)) return DU_ERR_UNSUPPORTED;
-  if (a.out_dtype == DU_BF16) return g_p8_sched ? launch_p8<bf16_t, 1>(a, st) : launch_p8<bf16_t, 0>(a, st);
-  return g_p8_sched ? launch_p8<float, 1>(a, st) : launch_p8<float, 0>(a, st);
+  const int c = du_gemm_p8_choice(a);
+  if (c == 0) return DU_ERR_UNSUPPORTED;
+  const bool bf = a.out_dtype == DU_BF16;
+  if (c == 1) {
+    if (bf) return g_p8_sched ? launch_p8<bf16_t, 1, false>(a, st) : launch_p8<bf16_t, 0, false>(a, st);
+    return g_p8_sched ? launch_p8<float, 1, false>(a, st) : launch_p8<float, 0, false>(a, st);
+  }
+  if (bf) return g_p8_sched ? launch_p8<bf16_t, 1, true>(a, st) : launch_p8<bf16_t, 0, true>(a, st);
+  return g_p8_sched ? launch_p8<float, 1, true>(a, st) : launch_p8<float, 0, true>(a, st);
 }

@@ -116,11 +116,14 @@ class DropPath(nn.Module):
     def __init__(self, drop_prob=0.0):
         super().__init__()
         self.drop_prob = drop_prob
+        self.pinned_mask = None             # test hook: a fixed per-sample mask instead of the device RNG draw
 
     def mask(self, B, device):
         """ADP:18-26: per-sample Bernoulli(keep)/keep, or None when inactive."""
         if self.drop_prob == 0.0 or not self.training:
             return None
+        if self.pinned_mask is not None:            # parity tests feed the mask the reference was given (already / keep_prob)
+            return self.pinned_mask.to(device=device, dtype=torch.float32)
         keep = 1 - self.drop_prob
         m = torch.empty(B, device=device, dtype=torch.float32).bernoulli_(keep)
         if keep > 0.0:

@@ -101,6 +101,7 @@ class RopePositionEmbedding(nn.Module):
         self.D_head = embed_dim // num_heads
         self.base = base
         self.rescale_coords = rescale_coords
+        self.pinned_log_scales = None       # test hook: fixed log rescale factors instead of the device RNG draw
         n = self.D_head // 4
         self.register_buffer("periods", base ** (2 * torch.arange(n, dtype=torch.float32) / (self.D_head // 2)), persistent=True)
         self._cache = {}
@@ -137,7 +138,11 @@ class RopePositionEmbedding(nn.Module):
             return sin[None].expand(nblocks, -1, -1), cos[None].expand(nblocks, -1, -1)
         base = self._cache[(H, W, str(device))][0]
         mx = float(np.log(self.rescale_coords))
-        scale = torch.empty(nblocks, device=device, dtype=torch.float32).uniform_(-mx, mx).exp()
+        if self.pinned_log_scales is not None:      # parity tests feed the draws the reference was given (one per block)
+            scale = self.pinned_log_scales.to(device=device, dtype=torch.float32).exp()
+            assert scale.numel() == nblocks
+        else:
+            scale = torch.empty(nblocks, device=device, dtype=torch.float32).uniform_(-mx, mx).exp()
         ang = (base[None] * scale[:, None, None, None]).flatten(2, 3).tile(2)
         return torch.sin(ang), torch.cos(ang)
 

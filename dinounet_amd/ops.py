@@ -115,6 +115,9 @@ PROFILE = None
 _MODE_NAMES = {(0, 0): "linear", (0, 1): "linear_dgrad", (1, 1): "linear_wgrad", (2, 0): "conv_im2col", (1, 3): "conv_wgrad"}
 
 
+_ROUTE_NAMES = {0: "gemm_kernel", 1: "gemm_bf16_kernel", 2: "gemm_nt_glds_kernel", 3: "gemm_nt_p8_kernel", 4: "gemm_nt_p8n_kernel"}
+
+
 def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat, ldc, batch=1, abs_=0, bbs=0, cbs=0,
              split_k=1, alpha=1.0, bias=None, act=ACT_NONE, gamma=None, row_scale=None, rs_rows=0, residual=None, ldr=0,
              store_mode=0, ps=(0, 0, 0), geom=None):
@@ -147,13 +150,8 @@ def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat,
         es = 2 if dtype == DU_BF16 else 4
         eo = 2 if out_dtype == DU_BF16 else 4
         kin = K if geom is None else K // max(geom.KH * geom.KW, 1) if a_mode == IM2COL_ROW else K
-        # mirror of the C-side dispatch (gemm.hip -> gemm_bf16.hip -> gemm_glds.hip) so the bench names the kernel that actually ran
-        if dtype != DU_BF16:
-            kname = "gemm_kernel"
-        elif a_mode == PLAIN_ROW and b_mode == PLAIN_ROW and K % 64 == 0 and N >= 96 and M >= 64 and split_k <= 1:
-            kname = "gemm_nt_glds_kernel"
-        else:
-            kname = "gemm_bf16_kernel"
+        # the library names the kernel family it ran for this product (du_gemm_route): no mirror of the C-side dispatch here
+        kname = _ROUTE_NAMES[int(_lib.lib().du_gemm_route(C.byref(a)))]
         tag = f"{kname}<{'bf16' if dtype == DU_BF16 else 'f32'},{_MODE_NAMES.get((a_mode, b_mode), 'other')}>"
         if PROFILE.detail:
             tag += f" M{M} N{N} K{K} b{batch} sk{split_k}" + (f" k{geom.KH}s{geom.stride}t{geom.transposed}" if geom is not None else "")

@@ -109,6 +109,10 @@ int du_gemm(const du_gemm_args* args, void* stream);
    leaves a short ragged last tile row on an otherwise exactly filled GPU (the ViT's M = 8 * 1029): those rows then go through a
    K-parallel skinny kernel pair instead of opening a nearly empty extra round of 128 x 128 tiles. */
 int64_t du_gemm_ws_elems(const du_gemm_args* args);
+/* Kernel family du_gemm runs for the bulk of `args` (for profilers: names the kernel without mirroring the dispatch): 0 generic,
+   1 bf16 tile engine (gemm_bf16.hip), 2 128 x 128 direct-to-LDS NT kernel (gemm_glds.hip), 3 / 4 the 256 x 256 / 256 x 128
+   multi-phase NT kernels (gemm_p8.hip). */
+int du_gemm_route(const du_gemm_args* args);
 
 /* ---- LDS-tiled direct 3x3 convolution (stride 1, pad 1), bf16 NHWC: decoder / FAPM / SPM-stem convs (dinounet_training.py:581-592,
         dinov3_adapter.py:243-249) and, with flipped + transposed weights, their data gradients --------------------------------------- */

@@ -60,6 +60,53 @@ def test_gemm_plain_epilogues(dt, M, N, K):
     assert rel(y, (x @ w.t() + b) * gam + res) < TOL[dt]
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("M,N,K,f32out,epi", [(8232, 3072, 1024, False, "bias"), (8232, 4096, 1024, False, "gelu"),
+                                              (8232, 1024, 4096, True, "ls_res"), (8232, 1024, 1024, True, "ls_res"),
+                                              (1000, 516, 512, True, "bias"), (768, 640, 384, False, "none"), (2048, 384, 1536, False, "rs")])
+def test_gemm_multiphase_nt(mode, M, N, K, f32out, epi):
+    """256 x 256 (mode 1) and 256 x 128 (mode 2) multi-phase NT kernels (gemm_p8.hip) forced through du_set_option, on the ViT-L
+    products and ragged shapes: full-matrix check against the fp32 product of the same bf16 operands, every epilogue the ViT uses, and
+    a repeat-run screen (the kernels are deterministic: a run-to-run difference is a pipeline race)."""
+    from dinounet_amd import ops, _lib
+    from dinounet_amd._lib import ACT_GELU
+    d = dev()
+    bf = torch.bfloat16
+    x, w = q(gen(M, K, seed=1), bf).to(d, bf), q(gen(N, K, seed=2, scale=K ** -0.5), bf).to(d, bf)
+    b, gam, res = gen(N, seed=3).to(d), gen(N, seed=4).to(d), gen(M, N, seed=5).to(d)
+    rows = 8
+    rs = (torch.arange((M + rows - 1) // rows, device=d) % 3 != 0).float() * 1.5
+    ref = x.float() @ w.float().t()
+    kw = {}
+    if epi in ("bias", "gelu", "ls_res"):
+        kw["bias"] = b
+        ref = ref + b
+    if epi == "gelu":
+        kw["act"] = ACT_GELU
+        ref = F.gelu(ref)
+    if epi == "ls_res":
+        kw.update(gamma=gam, residual=res)
+        ref = ref * gam + res
+    if epi == "rs":
+        kw.update(row_scale=rs, rs_rows=rows)
+        ref = ref * rs.repeat_interleave(rows)[:M, None]
+    od = torch.float32 if f32out else bf
+    L = _lib.lib()
+    try:
+        L.du_set_option(0, mode)
+        outs = []
+        for _ in range(6):
+            out = torch.empty((M, N), dtype=od, device=d)
+            if epi == "ls_res":
+                kw["residual"] = res.clone() if od == torch.float32 else res.to(od)
+            outs.append(ops.mm(x, w, out=out, **kw).float())
+    finally:
+        L.du_set_option(0, -1)
+    assert rel(outs[0], ref) < (2e-4 if f32out and epi != "ls_res" else TOL[bf])
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "run-to-run difference: pipeline race"
+
+
 @pytest.mark.parametrize("N,K", [(1024, 1024), (3072, 1024), (1024, 4096)])
 def test_gemm_ragged_tail_split(N, K):
     """The ViT-L products (M = 8 * 1029 = 64 * 128 + 40): for proj / fc2 the last 40 rows leave the tile grid and run on the K-parallel
