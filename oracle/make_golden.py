@@ -158,16 +158,20 @@ def train_case(name, model_name, B, H, W, num_classes=2):
 
 
 class pin_reference_randomness:
-    """Feed fixed draws to the reference's own train-mode random ops: `torch.empty(1).uniform_(lo, hi)` of the RoPE rescale
-    (LAY/rope_position_encoding.py:96) returns the next pinned log-scale, `x.new_empty((B,1,1)).bernoulli_(keep)` of drop_path
-    (ADP:23) the next pinned 0/1 mask.  Nothing else in the forward calls these two methods (asserted by shape)."""
+    """Feed fixed draws to the reference's own train-mode random ops.  RoPE: `torch.empty(1).uniform_(lo, hi)` of the rescale
+    (LAY/rope_position_encoding.py:96) returns the next pinned log-scale (the ViT runs once, under no_grad).  DropPath: the extractors
+    run under torch.utils.checkpoint (ADP:151), which RE-RUNS their forward during backward with fresh bernoulli_ draws unless the RNG
+    stream is the only source of randomness -- so each DropPath instance (ADP:29-37) gets its pinned mask as a per-module constant:
+    forward(x) = x * mask, mask = Bernoulli(keep) / keep drawn once (exactly what drop_path :18-26 computes for that draw)."""
 
-    def __init__(self, log_scales, masks, keep):
-        self.ls, self.masks, self.keep = [float(v) for v in log_scales], [m.clone() for m in masks], keep
-        self.i = self.j = 0
+    def __init__(self, net, log_scales, masks):
+        self.ls, self.i = [float(v) for v in log_scales], 0
+        self.dps = [m for m in net.modules() if m.__class__.__name__ == "DropPath"]
+        assert len(self.dps) == len(masks), (len(self.dps), len(masks))
+        self.masks = [m.clone() for m in masks]
 
     def __enter__(self):
-        self._u, self._b = torch.Tensor.uniform_, torch.Tensor.bernoulli_
+        self._u = torch.Tensor.uniform_
         outer = self
 
         def uniform_(t, a=0.0, b=1.0, **kw):
@@ -176,16 +180,15 @@ class pin_reference_randomness:
             assert a - 1e-6 <= v <= b + 1e-6
             return t.fill_(v)
 
-        def bernoulli_(t, p=0.5, **kw):
-            m = outer.masks[outer.j]; outer.j += 1
-            assert t.numel() == m.numel(), (t.shape, m.shape)
-            return t.copy_((m > 0).to(t.dtype).view(t.shape))
-
-        torch.Tensor.uniform_, torch.Tensor.bernoulli_ = uniform_, bernoulli_
+        torch.Tensor.uniform_ = uniform_
+        for m, mk in zip(self.dps, self.masks):
+            m.forward = (lambda x, mk=mk: x * mk.to(x.dtype).view((-1,) + (1,) * (x.ndim - 1)))
         return self
 
     def __exit__(self, *a):
-        torch.Tensor.uniform_, torch.Tensor.bernoulli_ = self._u, self._b
+        torch.Tensor.uniform_ = self._u
+        for m in self.dps:
+            del m.forward
 
 
 def train_case_pinned(name, model_name, B, H, W, num_classes=2, sample=65536, check_oracle=True):
@@ -199,11 +202,11 @@ def train_case_pinned(name, model_name, B, H, W, num_classes=2, sample=65536, ch
     log_scales, masks = weights.pinned_randomness(depth, B, seed=2)
     x = weights.make_input(B, 3, H, W, seed=2)
     tgt = weights.make_target(B, H, W, num_classes, seed=2)
-    with pin_reference_randomness(log_scales, masks, 0.7) as pr:
+    with pin_reference_randomness(net, log_scales, masks) as pr:
         y_ref = net(x)
-        assert pr.i == depth and pr.j == len(masks), (pr.i, pr.j)
-    loss_ref = O.dc_and_ce_loss(y_ref, tgt)
-    loss_ref.backward()
+        assert pr.i == depth, pr.i
+        loss_ref = O.dc_and_ce_loss(y_ref, tgt)
+        loss_ref.backward()                       # inside the context: checkpointed extractors re-run their forward here
     named = dict(net.named_parameters())
     g_ref = {k: p.grad for k, p in named.items() if p.requires_grad and p.grad is not None}
     print(f"[{name}] reference train step done ({time.time() - t0:.1f}s), loss {loss_ref.item():.6f}")

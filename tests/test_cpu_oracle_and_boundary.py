@@ -178,6 +178,48 @@ def test_host_glue_train_mode_and_grads():
     assert sorted(k for k, p in named.items() if p.requires_grad and p.grad is None) == meta["unused"]
 
 
+def test_host_glue_pinned_train_randomness():
+    """train() with the per-block RoPE rescale draws and the DropPath masks pinned to the values the reference was given
+    (oracle/make_golden.py: pin_reference_randomness): the product's wiring of both random ops (device-side draws replaced through the
+    `pinned_*` hooks) reproduces the reference's logits, loss and every gradient -- SURVEY rows a6 / a15."""
+    import _cpu_op_shim as shim
+    from dinounet_amd.network_architecture import DinoUNet
+    from dinounet_amd.dinov3.adapter import DropPath
+    g, meta = _load("dinounet_s_64_train_pinned")
+    net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name="dinounet_s", precision="fp32")
+    net.load_state_dict(_sd("dinounet_s"), strict=True)
+    net.train()
+    bb = net.encoder.dinov3_adapter.backbone
+    log_scales, masks = weights.pinned_randomness(len(bb.blocks), meta["B"], seed=2)
+    bb.rope_embed.pinned_log_scales = log_scales
+    dps = [m for m in net.modules() if isinstance(m, DropPath)]
+    assert len(dps) == len(masks)
+    for m, mk in zip(dps, masks):
+        m.pinned_mask = mk
+    x = weights.make_input(meta["B"], 3, meta["H"], meta["W"], seed=2)
+    tgt = weights.make_target(meta["B"], meta["H"], meta["W"], 2, seed=2)
+    with shim.patched_ops():
+        y = net.decoder(net.encoder(x))
+        loss = O.dc_and_ce_loss(y, tgt)
+        loss.backward()
+    assert rel(y.detach(), torch.from_numpy(g["logits"])) < 2e-5
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    gmax = max(meta["grad_norms"].values())
+    named = dict(net.named_parameters())
+    n = 0
+    for key in g.files:
+        if key.startswith("grad:"):
+            k = key[5:]
+            ref = torch.from_numpy(g[key])
+            got = named[k].grad.flatten()
+            if got.numel() > meta["sample"]:
+                got = got[weights.sample_indices(k, got.numel(), meta["sample"])]
+            denom = max(float(ref.norm()), 1e-3 * gmax * (ref.numel() / named[k].numel()) ** 0.5)
+            assert float((got - ref).norm()) / denom < 5e-3, k
+            n += 1
+    assert n == len(meta["grad_norms"])
+
+
 def test_zero_pool_one_buffer_per_step_without_aliasing():
     """ops.ZeroPool: the second step with the same request sequence is served from ONE zero-filled buffer; a later step never hands
     out memory that an earlier step's gradients still own; a deviating request falls back to plain zeros."""
