@@ -18,6 +18,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("DINOUNET_ALLOW_RANDOM_BACKBONE", "1")   # synthetic benchmark: random-init weights of the named architecture
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -28,15 +28,31 @@ DINOv3_MODEL_INFO = {                                                           
 }
 
 
-def load_dinov3_model(model_name: str, pretrained_path: str = None):
-    """DT:51-75.  With a checkpoint path the upstream DINOv3 state_dict is loaded strict=True; without one the
-    backbone keeps its seeded random init (there is no network for the hub download, hub/backbones.py:140)."""
+def load_dinov3_model(model_name: str, pretrained_path: str = None, allow_random_backbone: bool = None):
+    """DT:51-75.  With a checkpoint path the upstream DINOv3 state_dict is loaded strict=True.  The reference falls back to the hub
+    download when the path is missing (`model_factory(pretrained=True)`, hub/backbones.py:140); there is no network here, and a
+    training run on a randomly initialised FROZEN backbone is silently useless, so:
+      * a non-None path that does not exist raises FileNotFoundError;
+      * no path at all keeps the seeded random init only for callers that ask for it (`allow_random_backbone=True`, or the
+        environment variable DINOUNET_ALLOW_RANDOM_BACKBONE=1 that tests / bench.py / smoke() set) and warns loudly otherwise."""
     if model_name not in DINOv3_MODEL_FACTORIES:
         raise ValueError(f"Unsupported model: {model_name}. Supported models: {list(DINOv3_MODEL_FACTORIES.keys())}")
     model = build_backbone(model_name)
-    if pretrained_path and os.path.exists(pretrained_path):
+    if pretrained_path:
+        if not os.path.exists(pretrained_path):
+            raise FileNotFoundError(f"DINOv3 checkpoint {pretrained_path!r} not found (the frozen backbone would stay randomly "
+                                    f"initialised; the reference would download the default weights here, which this offline "
+                                    f"build cannot)")
         state_dict = torch.load(pretrained_path, map_location="cpu")
         model.load_state_dict(state_dict, strict=True)
+        return model
+    if allow_random_backbone is None:
+        allow_random_backbone = os.environ.get("DINOUNET_ALLOW_RANDOM_BACKBONE") == "1"
+    if not allow_random_backbone:
+        import warnings
+        warnings.warn(f"load_dinov3_model({model_name!r}): no pretrained_path -- the FROZEN DINOv3 backbone keeps its random "
+                      f"initialisation (fine for parity tests and synthetic benchmarks, useless for training); pass "
+                      f"allow_random_backbone=True / set DINOUNET_ALLOW_RANDOM_BACKBONE=1 to silence this", RuntimeWarning, stacklevel=2)
     return model
 
 
@@ -61,6 +77,8 @@ def _norm_act(x, norm_mod, act, training, stats_part=None):
             raise NotImplementedError("non-affine InstanceNorm")
         return ops.norm_act(x, norm_mod.weight, norm_mod.bias, "in", act, norm_mod.eps, True, stats_part=stats_part)
     if isinstance(norm_mod, nn.modules.batchnorm._BatchNorm):
+        if training and norm_mod.track_running_stats and norm_mod.num_batches_tracked is not None:
+            norm_mod.num_batches_tracked += 1          # nn.BatchNorm2d.forward does (state_dict parity with the reference)
         return ops.norm_act(x, norm_mod.weight, norm_mod.bias, "bn", act, norm_mod.eps, training, norm_mod.running_mean,
                             norm_mod.running_var, norm_mod.momentum or 0.1, None, stats_part=stats_part if training else None)
     raise NotImplementedError(f"norm {type(norm_mod)}")

@@ -250,6 +250,13 @@ class WeightPack:
             return None
         return e["dst"]
 
+    def invalidate(self):
+        """Every packed copy is stale until the next refresh() (called by FusedClipSGD.step(): HIP kernels that write parameters
+        through raw pointers do not bump the autograd version counters get() compares).  get() then declines and callers pack with
+        torch ops, so sub-modules called outside DinoUNet.forward after an optimizer step still see the current weights."""
+        for e in self.order:
+            e["vers"] = None
+
     def _drop(self, key):
         e = self.entries.pop(key, None)
         if e is not None:

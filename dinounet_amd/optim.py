@@ -31,6 +31,10 @@ class FusedClipSGD(torch.optim.Optimizer):
         self._sig = None
         self._tab_host = self._tab_host_cap = self._tab_dev = self._pre_dev = None
         self._hyper_host = self._hyper_dev = None
+        self._hyper_evt = None
+        self._tab_evt = [None, None]
+        self._flip = 0
+        self._retired = []
         self._nblocks = 0
 
     # ------------------------------------------------------------------------------------------------
@@ -43,8 +47,23 @@ class FusedClipSGD(torch.optim.Optimizer):
         h[3] = float("inf") if mn is None or math.isinf(mn) else float(mn)
         h[4] = 1.0 if g["nesterov"] else 0.0
 
+    def load_state_dict(self, state_dict):
+        """torch replaces state[p]['momentum_buffer'] by new tensors here: the cached device-pointer table must be rebuilt."""
+        super().load_state_dict(state_dict)
+        self._sig = None
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._sig = None
+
     def _tables(self, active, dev):
-        sig = (tuple(id(p) for p in active), str(dev))
+        # the table holds raw device pointers: its signature covers the storage of every parameter AND momentum buffer, so
+        # load_state_dict / net.to() / a reallocated p.data can never leave it pointing at freed memory
+        for p in active:
+            st = self.state[p]
+            if "momentum_buffer" not in st or st["momentum_buffer"] is None:
+                st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        sig = (tuple((id(p), p.data_ptr(), self.state[p]["momentum_buffer"].data_ptr()) for p in active), str(dev))
         if sig != self._sig:
             n = len(active)
             pre = torch.zeros(n + 1, dtype=torch.int64)
@@ -52,14 +71,18 @@ class FusedClipSGD(torch.optim.Optimizer):
                 pre[i + 1] = pre[i] + (p.numel() + _CHUNK - 1) // _CHUNK
             self._nblocks = int(pre[n])
             self._pre_dev = pre.to(dev)
-            self._tab_host = torch.zeros((n, 4), dtype=torch.int64).pin_memory()
+            # two pinned tables for eager steps (the host may run a step ahead of the GPU: the copy of step k must not read what step
+            # k+1 writes), one more that a captured graph keeps re-reading; tables of an earlier signature stay alive in _retired
+            # because a graph captured back then still copies from their pinned addresses
+            self._retired = getattr(self, "_retired", []) + [t for t in (self._tab_host_cap,) if t is not None]
+            self._tab_host = [torch.zeros((n, 4), dtype=torch.int64).pin_memory() for _ in range(2)]
+            self._tab_evt = [None, None]
+            self._flip = 0
             self._tab_host_cap = torch.zeros((n, 4), dtype=torch.int64).pin_memory()   # the table a captured graph keeps reading
             self._tab_dev = torch.zeros((n, 4), dtype=torch.int64, device=dev)
             for i, p in enumerate(active):
                 st = self.state[p]
-                if "momentum_buffer" not in st or st["momentum_buffer"] is None:
-                    st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                for t in (self._tab_host, self._tab_host_cap):
+                for t in (*self._tab_host, self._tab_host_cap):
                     t[i, 0] = p.data_ptr()
                     t[i, 2] = st["momentum_buffer"].data_ptr()
                     t[i, 3] = p.numel()
@@ -69,10 +92,21 @@ class FusedClipSGD(torch.optim.Optimizer):
             self._sig = sig
         # a hipGraph capture records the host->device copy of the table; replays re-read the pinned source, so the capture gets its own
         # (its gradient addresses, from the graph's private pool, stay valid) and later eager steps cannot overwrite it
-        t = self._tab_host_cap if torch.cuda.is_current_stream_capturing() else self._tab_host
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            t = self._tab_host_cap
+        else:
+            self._flip ^= 1
+            t = self._tab_host[self._flip]
+            if self._tab_evt[self._flip] is not None:
+                self._tab_evt[self._flip].synchronize()       # the copy that last read this pinned table (two steps ago) has finished
         for i, p in enumerate(active):
             t[i, 1] = p.grad.data_ptr()
         self._tab_dev.copy_(t, non_blocking=True)
+        if not capturing:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._tab_evt[self._flip] = ev
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -90,12 +124,20 @@ class FusedClipSGD(torch.optim.Optimizer):
             if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous() or p.device != dev:
                 raise RuntimeError("FusedClipSGD needs contiguous fp32 parameters and gradients on one device")
         self._tables(active, dev)
+        if not torch.cuda.is_current_stream_capturing() and self._hyper_evt is not None:
+            self._hyper_evt.synchronize()                      # the previous step's copy of the pinned hyper-parameters is done
         self.refresh_hyper()
         self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        if not torch.cuda.is_current_stream_capturing():
+            self._hyper_evt = torch.cuda.Event()
+            self._hyper_evt.record()
         L = _lib.lib()
         n_ws = int(L.du_clip_sgd_ws_elems(self._nblocks))
         ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
         _lib.check(L.du_clip_sgd(self._tab_dev.data_ptr(), self._pre_dev.data_ptr(), len(active), self._nblocks, self._hyper_dev.data_ptr(),
                                  ws.data_ptr(), n_ws, torch.cuda.current_stream().cuda_stream), "du_clip_sgd")
         self.total_norm = ws[self._nblocks]
+        # the kernels wrote the parameters through raw pointers (no autograd version bump): packed / bf16 copies of them are stale
+        from . import ops
+        ops.PACK.invalidate()
         return loss

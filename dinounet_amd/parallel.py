@@ -10,17 +10,56 @@ hot path:
     keeps every collective bandwidth-bound rather than latency-bound;
   * parameters that never receive a gradient (decoder.seg_layers.{0,1} without deep supervision) are
     skipped, so there is no "unused parameter" hazard;
-  * SUM then divide by world size == DDP's gradient averaging; grad-clip 12 runs afterwards on identical gradients.
+  * SUM then divide by world size == DDP's gradient averaging; grad-clip 12 runs afterwards on identical gradients;
+  * like DDP's constructor, the reducer first broadcasts rank 0's parameters AND buffers (BatchNorm running statistics,
+    num_batches_tracked) to every rank: nnU-Net does not seed ranks identically, so replicas would otherwise start -- and stay --
+    different.
 Works on CPU tensors with the gloo backend (used by the world_size-2 tests).
 """
 import torch
 import torch.distributed as dist
 
 
+def broadcast_module_state(module, group=None, src=0):
+    """Rank `src`'s parameters and buffers -> every rank, in flat chunks per dtype (what torch DDP does at construction,
+    nnUNetTrainer.py:218).  Frozen backbone weights are included: every rank loads the same checkpoint, but a rank that failed to
+    (or was seeded differently in a test) must not silently train against different features."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    by_dtype = {}
+    seen = set()
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.data_ptr() in seen:
+            continue
+        seen.add(t.data_ptr())
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    with torch.no_grad():
+        for (dt, dev), ts in by_dtype.items():
+            chunk, n = [], 0
+            def flush():
+                if not chunk:
+                    return
+                flat = torch.cat([t.detach().reshape(-1) for t in chunk])
+                dist.broadcast(flat, src=src, group=group)
+                off = 0
+                for t in chunk:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+            for t in ts:
+                chunk.append(t)
+                n += t.numel()
+                if n >= 64 * 1024 * 1024:
+                    flush()
+                    chunk, n = [], 0
+            flush()
+
+
 class GradAllReducer:
-    def __init__(self, module, world_size=None, bucket_elems=4 * 1024 * 1024, group=None, skip=()):
+    def __init__(self, module, world_size=None, bucket_elems=4 * 1024 * 1024, group=None, skip=(), broadcast=True):
         self.group = group
         self.world = world_size or dist.get_world_size(group)
+        if broadcast:
+            broadcast_module_state(module, group)
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         ds = getattr(getattr(module, "decoder", None), "deep_supervision", True)
         if not ds:

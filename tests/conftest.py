@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("DINOUNET_ALLOW_RANDOM_BACKBONE", "1")   # parity tests run on seeded random backbones by design
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

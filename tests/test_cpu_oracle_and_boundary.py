@@ -91,6 +91,9 @@ def test_plugin_surface():
         assert hasattr(DT, n), n
     T = DT.get_dinov3_trainer("dinounet_s")
     T.set_network_config(PLANS_2D, dinov3_pretrained_path="/nonexistent.pth")
+    with pytest.raises(FileNotFoundError):                 # a wrong checkpoint path must not silently train on a random frozen ViT
+        T.build_network_architecture("ignored", {}, [], 3, 2, enable_deep_supervision=False)
+    DT.DinoUNetTrainer._dinov3_pretrained_path = T._dinov3_pretrained_path = None
     net = T.build_network_architecture("ignored", {}, [], 3, 2, enable_deep_supervision=False)
     assert isinstance(net, DT.DinoUNet) and net.decoder.deep_supervision is False
     enc = net.encoder

@@ -5,6 +5,7 @@ usage: python tools/bench_backbone.py [--model dinounet_7b] [--size 1024] [--bat
 import argparse
 import json
 import os
+os.environ.setdefault("DINOUNET_ALLOW_RANDOM_BACKBONE", "1")
 import sys
 import time
 

@@ -5,6 +5,7 @@ usage: python tools/bench_inference.py [--model dinounet_l] [--slices 4] [--size
 import argparse
 import json
 import os
+os.environ.setdefault("DINOUNET_ALLOW_RANDOM_BACKBONE", "1")
 import sys
 import time
 

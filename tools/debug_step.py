@@ -4,6 +4,7 @@ parameters whose gradient is non-finite; then a per-GEMM-shape timing table (HIP
 usage: python tools/debug_step.py [--model dinounet_l] [--batch 8] [--steps 6] [--shapes]"""
 import argparse
 import os
+os.environ.setdefault("DINOUNET_ALLOW_RANDOM_BACKBONE", "1")
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -6,6 +6,7 @@ usage: python tools/glue_trace.py [--model dinounet_l] [--batch 8] [--top 60]"""
 import argparse
 import collections
 import os
+os.environ.setdefault("DINOUNET_ALLOW_RANDOM_BACKBONE", "1")
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
