@@ -677,8 +677,11 @@ int launch_p8(const du_gemm_args& a, hipStream_t st) {
 }  // namespace
 
 // debugging / A-B knobs (within-process variant switching for tools/gemm_p8_bench.py); not part of the hot-path contract
+extern int g_attn_w;      // attention.hip
+
 extern "C" int du_set_option(int key, int value) {
   switch (key) {
+    case 4: g_attn_w = value; return DU_OK;
     case 0: g_p8_mode = value; return DU_OK;
     case 1: g_p8_sched = value; return DU_OK;
     case 2: g_p8_group = value; return DU_OK;
