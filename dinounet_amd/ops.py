@@ -65,7 +65,7 @@ def _nhwc(t):
     assert t.dim() == 4 and t.stride(3) == 1, (t.shape, t.stride())
     B, H, W, Cc = t.shape
     ld = t.stride(2)
-    assert (W == 1 or True) and t.stride(1) == W * ld and (B == 1 or t.stride(0) == H * W * ld), (t.shape, t.stride())
+    assert (H == 1 or t.stride(1) == W * ld) and (B == 1 or t.stride(0) == H * W * ld), (t.shape, t.stride())
     return B, H, W, Cc, ld
 
 
@@ -663,7 +663,7 @@ def conv2d_stats(x, w, bias=None, stride=1, pad=1, x2=None):
     return y, (part if part.numel() else None)
 
 
-_DGRAD_NT = os.environ.get("DINOUNET_DGRAD_NT", "0") == "1"
+_DGRAD_NT = os.environ.get("DINOUNET_DGRAD_NT", "1") == "1"
 
 
 class _Linear(torch.autograd.Function):
@@ -679,9 +679,9 @@ class _Linear(torch.autograd.Function):
             elif wq.dim() != 2:
                 wq = wq.view(w.shape[0], -1)
         y = mm(x, wq, bias=_f32(bias), residual=residual, row_scale=row_scale, rs_rows=rs_rows, out_dtype=out_dtype)
-        # W^T (K, N) from the weight pack would turn the data gradient into a contraction-contiguous product for the direct-to-LDS
-        # kernel; measured on the dinounet_l step it is a wash against the transpose-read ROW x COL kernel (-1.4 ms / +1.7 ms), so it
-        # stays off by default (DINOUNET_DGRAD_NT=1 enables it)
+        # W^T (K, N) from the weight pack turns the data gradient into a contraction-contiguous product, i.e. one the 256-wide
+        # multi-phase NT kernels (gemm_p8.hip) serve: 39 of the 58 linear data gradients of a dinounet_l step move there, -0.75 ms per
+        # step (against the 128 x 128 kernel of round 1 it was a wash; DINOUNET_DGRAD_NT=0 restores the transpose-read ROW x COL kernel)
         ctx.wT = PACK.get(w, PK_TRANSPOSE, x.dtype) if (_DGRAD_NT and w.dtype != x.dtype and w.shape[0] % 64 == 0) else None
         ctx.save_for_backward(x, wq, row_scale)
         ctx.rs_rows = rs_rows

@@ -1,7 +1,7 @@
 """Synthetic-data training-step harness replicating the reference trainer's `train_step`
 (dinounet/training/nnUNetTrainer/nnUNetTrainer.py:899-929): forward -> DC+CE loss -> backward -> clip_grad_norm_(12)
--> SGD(nesterov, momentum 0.99, wd 3e-5).  The loss is the reference's formula on the fp32 logits (SURVEY.md 8f "next"
-row: not yet a fused kernel, stock torch reductions)."""
+-> SGD(nesterov, momentum 0.99, wd 3e-5).  On the GPU the loss is the fused Dice+CE kernel pair (csrc/loss.hip) and clip + SGD the
+fused three-launch optimiser (csrc/optim.hip); the torch formula below serves the CPU / many-class path of the gloo tests."""
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
