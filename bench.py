@@ -130,7 +130,11 @@ def main():
         if prof is not None:
             try:
                 out["roofline"], out["kernel_breakdown"] = prof.roofline(MFMA_BF16_PEAK_TFLOPS, HBM_PEAK_GBS, 2)
-                pmc_traffic(out["roofline"])
+                r = out["roofline"]
+                meas = MFMA_BF16_MEASURED_TFLOPS if r.get("bound") == "mfma" else HBM_MEASURED_GBS
+                r["measured_peak"] = meas                      # what a micro-benchmark reaches on this chip (same unit as peak)
+                r["frac_of_measured_peak"] = round(r["achieved"] / meas, 4)
+                pmc_traffic(r)
             except Exception as e:  # noqa: BLE001
                 out["roofline"] = {"error": repr(e)}
         if not a.no_cpu_baseline and world == 1:
@@ -140,39 +144,58 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1 or force_pg:
-        # The captured step holds RCCL kernels; tearing the process group down while the graph objects are still alive made the
-        # watchdog thread abort at interpreter exit on some runs (observed once in three, after the JSON line was out).  Everything is
-        # synchronised and printed at this point, so leave without running the teardown.
+        # Ordered teardown.  The captured step holds RCCL kernel nodes and the reducer a side stream with hooks into the module: if the
+        # interpreter tears these down in arbitrary order at exit (process group first, or never destroyed), ProcessGroupNCCL's watchdog
+        # can abort after the JSON line is out.  So: quiesce, drop the graph, detach the reducer, then destroy the process group.
         torch.cuda.synchronize()
         dist.barrier()
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+        if ts.graph is not None:
+            ts.graph.reset()
+            ts.graph = None
+        if reducer is not None:
+            reducer.remove()
+        ts.reducer = None
+        del reducer
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
 
 
-def pmc_traffic(roof, tag="v12"):
-    """roofline.traffic = memory-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate runs, profiles/r01_pmc_*_eager_<tag>.txt; counters cannot
-    be collected from inside the process being timed).  FETCH_SIZE / WRITE_SIZE are kilobytes; on gfx950 FETCH_SIZE counts 128-byte
-    requests at 64 B, hence the factor 2 (MI355X_MICROARCH.md, HBM section).  Left null when the summaries are not there."""
+MFMA_BF16_MEASURED_TFLOPS = 2382.0   # MI355X_MICROARCH.md: micro-benchmark ceiling of v_mfma_f32_32x32x16_bf16
+HBM_MEASURED_GBS = 6290.0            # same guide: float4 copy
+
+
+def pmc_traffic(roof):
+    """roofline.traffic = memory-side bytes per launch of the dominant kernel, from rocprofv3 PMC passes of this same command
+    (tools/pmc_traffic.py: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate runs of `bench.py --graph off`; counters cannot be
+    collected from inside the process being timed).  The summaries record the digest of the kernel sources they were measured on
+    (dinounet_amd/_build.py: sha256 over csrc/, the C-ABI header and the compiler flags): a summary taken on other kernels is ignored and
+    traffic stays null.  FETCH_SIZE / WRITE_SIZE are kilobytes; on gfx950 FETCH_SIZE counts 128-byte requests at 64 B, hence the factor 2
+    (MI355X_MICROARCH.md, HBM section)."""
+    from dinounet_amd import _build
     here = os.path.dirname(os.path.abspath(__file__))
     key = roof.get("kernel", "").split("<")[0]
-    tot = {}
+    digest = _build._digest()
+    tot, src = {}, []
     for name, mult in (("fetch", 2.0), ("write", 1.0)):
-        path = os.path.join(here, "profiles", f"r01_pmc_{name}_size_eager_{tag}.txt")
+        path = os.path.join(here, "profiles", f"r02_pmc_{name}_size_eager.txt")
         if not key or not os.path.exists(path):
             return
+        lines = open(path).read().splitlines()
+        if not any(l.startswith("# csrc-digest") and digest in l for l in lines[:6]):
+            roof["traffic_note"] = "profiles/r02_pmc_*_size_eager.txt were measured on other kernel sources (digest mismatch): ignored"
+            return
         calls, kb = 0, 0.0
-        for line in open(path):
+        for line in lines:
             f = line.split(None, 2)
             if len(f) == 3 and f[0].isdigit() and key in f[2]:
                 calls += int(f[0]); kb += int(f[0]) * float(f[1])
         if not calls:
             return
         tot[name] = kb / calls * 1024.0 * mult
+        src.append(os.path.basename(path))
     roof["traffic"] = round(tot["fetch"] + tot["write"])
     roof["traffic_unit"] = "bytes/launch"
-    roof["traffic_source"] = f"profiles/r01_pmc_{{fetch,write}}_size_eager_{tag}.txt (separate rocprofv3 --pmc passes of bench.py --graph off; FETCH_SIZE x2)"
+    roof["traffic_source"] = f"profiles/{{{','.join(src)}}} (separate rocprofv3 --pmc passes of bench.py --graph off on csrc digest {digest[:12]}; FETCH_SIZE x2)"
 
 
 def cpu_baseline(net, a):

@@ -329,5 +329,12 @@ class DINOv3_Adapter(nn.Module):
         if self.add_vit_feature:                                                            # ADP:469-476
             cs = [ops.bilinear_add(layers[j][0].view(B, H_t, W_t, D), cs[j]) for j in range(4)]
         norms = [self.norm1, self.norm2, self.norm3, self.norm4]
-        fs = [bn_act(cs[j], norms[j], ACT_NONE, self.training, group) for j in range(4)]    # ADP:479-482
+        if (self.training and group is not None and torch.distributed.get_world_size(group) > 1
+                and all(bn.track_running_stats for bn in norms)):
+            for bn in norms:                                                                # ADP:479-482, one packed collective each way
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+            fs = ops.sync_bn_multi(cs, norms, ACT_NONE, group)
+        else:
+            fs = [bn_act(cs[j], norms[j], ACT_NONE, self.training, group) for j in range(4)]    # ADP:479-482
         return {"1": fs[0], "2": fs[1], "3": fs[2], "4": fs[3]}

@@ -1001,6 +1001,86 @@ def norm_act(x, w, b, kind, act=ACT_NONE, eps=1e-5, training=True, running_mean=
     return _NormAct.apply(x, w, b, kind, act, eps, training, running_mean, running_var, momentum, group, stats_part)
 
 
+class _SyncBNMulti(torch.autograd.Function):
+    """Several independent SyncBatchNorm layers (the adapter's four output norms, dinov3_adapter.py:361-364,479-482) with ONE
+    statistics all-reduce in the forward and ONE in the backward instead of one per layer: the per-layer (sum, sum of squares) /
+    (sum dy, sum dy*xhat) vectors are produced straight into slices of a single flat buffer.  (The six BatchNorms of the SPM stem
+    cannot be packed: each one normalises the input of the next convolution.)"""
+
+    @staticmethod
+    def forward(ctx, group, act, n, *args):
+        xs, ws, bs = args[:n], args[n:2 * n], args[2 * n:3 * n]
+        mods = args[3 * n]                       # [(eps, running_mean, running_var, momentum)] * n
+        L = _lib.lib()
+        world = torch.distributed.get_world_size(group)
+        geo = [_nhwc(x) for x in xs]
+        offs, tot = [], 0
+        for (_, _, _, Cc, _) in geo:
+            offs.append(tot)
+            tot += 2 * Cc
+        flat = torch.empty(tot, dtype=torch.float32, device=xs[0].device)
+        for x, (B, H, W, Cc, ld), o in zip(xs, geo, offs):
+            wsb, nws = _reduce_ws(x.dtype, 1, B * H * W, Cc, x.device)
+            _lib.check(L.du_chan_stats(_code(x.dtype), _p(x), ld, C.c_void_p(flat.data_ptr() + 4 * o), 1, B * H * W, Cc, _p(wsb), nws, _st()),
+                       "du_chan_stats")
+        torch.distributed.all_reduce(flat, group=group)
+        ys, saved = [], []
+        for j, (x, (B, H, W, Cc, ld), o) in enumerate(zip(xs, geo, offs)):
+            eps, rm, rv, mom = mods[j]
+            count = float(B * H * W * world)
+            mean = torch.empty((1, Cc), dtype=torch.float32, device=x.device)
+            rstd = torch.empty((1, Cc), dtype=torch.float32, device=x.device)
+            _lib.check(L.du_norm_stats_finalize(C.c_void_p(flat.data_ptr() + 4 * o), count, eps, _p(mean), _p(rstd), 1, Cc,
+                                                _p(rm) if rm is not None else None, _p(rv) if rm is not None else None, float(mom), _st()),
+                       "du_norm_stats_finalize")
+            wf, bf = _f32(ws[j]), _f32(bs[j])
+            ys.append(_norm_fwd(x, mean, rstd, wf, bf, 1, B * H * W, act))
+            saved += [x, mean, rstd, wf, bf]
+        ctx.save_for_backward(*saved)
+        ctx.conf = (group, act, n, world, geo, offs, tot)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        group, act, n, world, geo, offs, tot = ctx.conf
+        sv = ctx.saved_tensors
+        L = _lib.lib()
+        dev = sv[0].device
+        flat = torch.empty(tot, dtype=torch.float32, device=dev)
+        dws, dbs, dyc = [], [], []
+        for j in range(n):
+            x, mean, rstd, wf, bf = sv[5 * j:5 * j + 5]
+            B, H, W, Cc, ld = geo[j]
+            dy = dys[j].contiguous()
+            dyc.append(dy)
+            wsb, nws = _reduce_ws(x.dtype, 1, B * H * W, Cc, dev)
+            bsj = C.c_void_p(flat.data_ptr() + 4 * offs[j])
+            _lib.check(L.du_norm_act_bwd_stats(_code(x.dtype), _p(x), ld, _p(dy), Cc, _p(mean), _p(rstd), _p(wf), _p(bf), bsj, 1, B * H * W,
+                                               Cc, act, _p(wsb), nws, _st()), "du_norm_act_bwd_stats")
+            dw = torch.empty(Cc, dtype=torch.float32, device=dev)
+            db = torch.empty(Cc, dtype=torch.float32, device=dev)
+            _lib.check(L.du_norm_param_grads(bsj, _p(dw), _p(db), 1, Cc, _st()), "du_norm_param_grads")    # local sums: DDP averages them
+            dws.append(dw); dbs.append(db)
+        torch.distributed.all_reduce(flat, group=group)
+        dxs = []
+        for j in range(n):
+            x, mean, rstd, wf, bf = sv[5 * j:5 * j + 5]
+            B, H, W, Cc, ld = geo[j]
+            dx = torch.empty((B, H, W, Cc), dtype=x.dtype, device=dev)
+            _lib.check(L.du_norm_act_bwd_dx(_code(x.dtype), _p(x), ld, _p(dyc[j]), Cc, _p(dx), Cc, _p(mean), _p(rstd), _p(wf), _p(bf),
+                                            C.c_void_p(flat.data_ptr() + 4 * offs[j]), 1, B * H * W, Cc, act, float(B * H * W * world), 1, _st()),
+                       "du_norm_act_bwd_dx")
+            dxs.append(dx)
+        return (None, None, None, *dxs, *dws, *dbs, None)
+
+
+def sync_bn_multi(xs, bns, act, group):
+    """Training-mode SyncBatchNorm (+ activation) of several independent NHWC tensors with packed statistics collectives."""
+    n = len(xs)
+    mods = [(bn.eps, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1) for bn in bns]
+    return list(_SyncBNMulti.apply(group, act, n, *xs, *[bn.weight for bn in bns], *[bn.bias for bn in bns], mods))
+
+
 def layernorm_raw(x2d, w, b, eps, out_dtype, want_stats=False):
     rows, D, ld = _rows2d(x2d)
     y = torch.empty((rows, D), dtype=out_dtype, device=x2d.device)

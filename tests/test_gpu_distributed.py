@@ -1,0 +1,119 @@
+"""Multi-rank GPU paths exercised on ONE MI355X: two processes share cuda:0 and talk over the gloo backend (gloo all-reduces /
+broadcasts CUDA tensors through host staging; RCCL refuses two ranks on one device).  Every rank-aware HIP path of the product runs
+with world = 2 -- the SyncBatchNorm statistics all-reduces of the SPM stem and the adapter's output norms (forward + backward,
+dinov3_adapter.py:242-270,361-364 after nnUNetTrainer.py:217 convert_sync_batchnorm), the fused Dice+CE loss with global Dice sums
+(dinounet/utilities/ddp_allgather.py:25-48), GradAllReducer's parameter broadcast, bucket gather kernel and averaged gradients
+(DDP, nnUNetTrainer.py:218) -- and is compared with a single-process step on the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _build(seed, precision="fp32"):
+    from oracle import weights
+    from oracle.refshim import PLANS_2D
+    from dinounet_amd.network_architecture import DinoUNet
+    from dinounet_amd.dinov3.adapter import DropPath
+    net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name="dinounet_s", precision=precision)
+    ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    net.load_state_dict(weights.make_state_dict(ks, seed=seed), strict=True)
+    net = net.cuda().train()
+    for m in net.modules():
+        if isinstance(m, DropPath):
+            m.drop_prob = 0.0
+    net.encoder.dinov3_adapter.backbone.rope_embed.rescale_coords = None
+    return net
+
+
+def _batch():
+    from oracle import weights
+    return weights.make_input(4, 3, 64, 64, seed=5), weights.make_target(4, 64, 64, 2, seed=5)
+
+
+def _bn_buffers(net):
+    return {k: v.detach().float().cpu().clone() for k, v in net.state_dict().items()
+            if k.endswith(("running_mean", "running_var", "num_batches_tracked")) and not k.startswith("decoder.encoder.")}
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DINOUNET_ALLOW_RANDOM_BACKBONE="1")
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from dinounet_amd.parallel import GradAllReducer
+        from dinounet_amd.training import dc_and_ce_loss
+        net = _build(seed=rank)                    # DIFFERENT weights per rank: the reducer's broadcast must make them rank 0's
+        red = GradAllReducer(net, world, bucket_elems=1 << 20)
+        assert len(red.buckets) >= 2
+        chk = torch.stack([p.detach().double().sum() for p in net.parameters()]).sum().reshape(1).cpu()
+        both = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk)
+        assert torch.equal(both[0], both[1]), "parameters differ across ranks after the constructor broadcast"
+        X, T = _batch()
+        x, t = X[rank * 2:(rank + 1) * 2].cuda(), T[rank * 2:(rank + 1) * 2].cuda()
+        y = net(x)
+        loss = dc_and_ce_loss(y, t)                # process group initialised: global Dice sums
+        loss.backward()
+        red.finish()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.detach().float().cpu() for n, p in net.named_parameters() if p.grad is not None}
+        q.put((rank, y.detach().float().cpu(), float(loss), grads, _bn_buffers(net)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "ERROR", traceback.format_exc(), None, None))
+        raise e
+
+
+def test_two_ranks_on_one_gpu_match_the_full_batch_step():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    [p.join(timeout=120) for p in procs]
+    for r in res:
+        assert not (isinstance(r[1], str) and r[1] == "ERROR"), r[2]
+    assert all(p.exitcode == 0 for p in procs)
+    # single-process reference on the concatenated batch (no process group in this process: plain BatchNorm / local Dice)
+    from dinounet_amd.training import dc_and_ce_loss
+    net = _build(seed=0)
+    X, T = _batch()
+    y = net(X.cuda())
+    loss = dc_and_ce_loss(y, T.cuda())
+    loss.backward()
+    yr = y.detach().float().cpu()
+    scale = float(yr.abs().max())
+    for rank, yy, _, _, _ in res:
+        assert float((yy - yr[rank * 2:(rank + 1) * 2]).abs().max()) < 1e-4 * scale, f"rank {rank} logits (SyncBN statistics?)"
+    assert abs(sum(r[2] for r in res) / world - float(loss)) < 1e-5
+    named = dict(net.named_parameters())
+    gmax = max(float(p.grad.norm()) for p in named.values() if p.grad is not None)
+    worst = ("", 0.0)
+    for k, p in named.items():
+        if p.grad is None:
+            assert k not in res[0][3] or float(res[0][3][k].abs().max()) == 0.0, k
+            continue
+        ref = p.grad.detach().float().cpu()
+        for rank, _, _, grads, _ in res:
+            e = float((grads[k] - ref).norm()) / max(float(ref.norm()), 1e-3 * gmax)
+            if e > worst[1]:
+                worst = (f"{k}@rank{rank}", e)
+    print(f"worst averaged-gradient deviation vs the full-batch step: {worst[1]:.2e} at {worst[0]}")
+    assert worst[1] < 2e-3, worst
+    ref_bn = _bn_buffers(net)
+    for rank, _, _, _, bn in res:
+        for k, v in ref_bn.items():
+            assert torch.allclose(bn[k], v, rtol=1e-4, atol=1e-6), (rank, k)
