@@ -638,6 +638,60 @@ extern "C" int du_bilinear_add_fwd(int src_dtype, int dtype, const void* src, in
   return du_check_launch();
 }
 
+namespace {
+
+// SwiGLU gate on an interleaved projection (layers/ffn_layers.py:73-77): u (rows, 2h) with columns (2j, 2j+1) = (w1 x + b1, w2 x + b2)[j]
+// -> out (rows, h) = silu(u[2j]) * u[2j+1].  One 16-byte load = 8 / 4 inputs per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_pairs_kernel(const T* __restrict__ u, T* __restrict__ out, long npairs_vec) {
+  constexpr int V = Elem<T>::VEC;               // inputs per 16 bytes
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npairs_vec; i += (long)gridDim.x * 256) {
+    const Vec16<T> x = as_vec<T>(*(const uint4*)(u + i * V));
+    T o[V / 2];
+#pragma unroll
+    for (int j = 0; j < V / 2; j++) {
+      const float a = to_f32(x.v[2 * j]), b = to_f32(x.v[2 * j + 1]);
+      o[j] = from_f32<T>(a / (1.0f + __expf(-a)) * b);
+    }
+    if constexpr (sizeof(T) == 2) *(uint2*)(out + i * (V / 2)) = __builtin_bit_cast(uint2, o);
+    else *(float2*)(out + i * (V / 2)) = __builtin_bit_cast(float2, o);
+  }
+}
+
+// whole samples of a (B, n) fp32 tensor by index: gather dst[j] = src[idx[j]]  /  scatter dst[idx[j]] = src[j]
+// (batch-subset stochastic depth of the ViT-7B blocks, layers/block.py:126-187)
+__global__ __launch_bounds__(256) void sample_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, const long* __restrict__ idx,
+                                                          long n4, int scatter) {
+  const int j = blockIdx.y;
+  const long s = idx[j];
+  const float4* sp = (const float4*)src + (scatter ? (long)j : s) * n4;
+  float4* dp = (float4*)dst + (scatter ? s : (long)j) * n4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) dp[i] = sp[i];
+}
+
+}  // namespace
+
+extern "C" int du_swiglu_pairs(int dtype, const void* u, void* out, int64_t rows, int64_t h, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == DU_BF16 ? 8 : 4;
+  if (!u || !out || rows <= 0 || h <= 0 || (2 * h) % vec) return DU_ERR_BAD_ARG;
+  const long nv = rows * (2 * h) / vec;
+  long g = (nv + 255) / 256; if (g > 8192) g = 8192;
+  if (dtype == DU_BF16) hipLaunchKernelGGL(swiglu_pairs_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)u, (bf16_t*)out, nv);
+  else if (dtype == DU_F32) hipLaunchKernelGGL(swiglu_pairs_kernel<float>, dim3((unsigned)g), dim3(256), 0, st, (const float*)u, (float*)out, nv);
+  else return DU_ERR_BAD_ARG;
+  return du_check_launch();
+}
+
+extern "C" int du_sample_copy(const float* src, float* dst, const int64_t* idx, int k, int64_t n_per_sample, int scatter, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!src || !dst || !idx || k <= 0 || n_per_sample <= 0 || n_per_sample % 4) return DU_ERR_BAD_ARG;
+  const long n4 = n_per_sample / 4;
+  long g = (n4 + 255) / 256; if (g > 512) g = 512;
+  hipLaunchKernelGGL(sample_copy_kernel, dim3((unsigned)g, k), dim3(256), 0, st, src, dst, (const long*)idx, n4, scatter);
+  return du_check_launch();
+}
+
 extern "C" int du_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!src || !dst || n <= 0) return DU_ERR_BAD_ARG;

@@ -294,6 +294,7 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 }  // namespace
 
 int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st);   // gemm_bf16.hip
+int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st);       // gemm_p8.hip
 int du_gemm_ragged_rows(const du_gemm_args& a);                      // gemm_bf16.hip
 int64_t du_gemm_skinny_ws_elems(int N, int K);                      // gemm_skinny.hip
 
@@ -341,6 +342,10 @@ extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
   if (a.split_k > 1 && (a.out_dtype != DU_F32 || a.bias || a.act || a.gamma || a.row_scale || a.residual || a.store_mode)) return DU_ERR_BAD_ARG;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && a.residual && a.ldc % 1) return DU_ERR_BAD_ARG;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && (a.ps_C <= 0 || a.N != 4 * a.ps_C || a.M % (a.ps_H * a.ps_W))) return DU_ERR_BAD_ARG;
+  if (a.act == DU_ACT_SWIGLU) {          // gated epilogue: multi-phase bf16 NT kernels only (callers fall back to du_swiglu_pairs)
+    if (a.dtype != DU_BF16 || a.N % 2) return DU_ERR_UNSUPPORTED;
+    return du_gemm_nt_p8(a, st);
+  }
   if (a.dtype == DU_BF16) {
     static const bool generic_only = getenv("DU_GEMM_GENERIC") != nullptr;   // debugging aid: force the generic kernel
     if (!generic_only) {

@@ -382,6 +382,7 @@ bool du_gemm_glds_serves(const du_gemm_args& a);              // gemm_glds.hip
 int du_gemm_ragged_rows(const du_gemm_args& a) {
   static const bool off = getenv("DU_GEMM_NO_RAGGED_SPLIT") != nullptr;      // debugging / A-B aid
   if (off || a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.store_mode != DU_STORE_PLAIN) return 0;
+  if (a.act == DU_ACT_SWIGLU) return 0;      // the skinny kernels have no gate epilogue: the multi-phase kernel keeps the ragged rows
   if (a.batch > 1 || a.split_k > 1 || a.K % 64 || a.N < 96 || a.N % 4 || a.M < 1024 || a.lda % 8 || a.ldb % 8) return 0;
   {
     const int r = a.M % 256;

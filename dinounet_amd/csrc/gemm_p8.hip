@@ -114,20 +114,28 @@ __device__ __forceinline__ float gelu_fast(float v) {
   return 0.5f * v * (v < 0.f ? e : 2.0f - e);
 }
 
-// bf16 staging of one 32 x 32 block: bias (+ GELU) in registers, 4 columns packed into one ds_write_b64
+// bf16 staging of one 32 x 32 block: bias (+ GELU) in registers, 4 columns packed into one ds_write_b64.  ACT == SWIGLU: the 4 columns
+// are two (w1, w2) pairs of an interleaved projection -> 2 gated outputs, one ds_write_b32 at half the column offset
 template <int ACT>
 __device__ __forceinline__ void stage_block_bf16(const f32x16& a, const float4 (&bv)[4], bf16_t* stg, int ldb, int srow, int scol, int hi) {
 #pragma unroll
   for (int g = 0; g < 4; g++) {
     float o[4] = {a[4 * g] + bv[g].x, a[4 * g + 1] + bv[g].y, a[4 * g + 2] + bv[g].z, a[4 * g + 3] + bv[g].w};
-    if constexpr (ACT == DU_ACT_GELU) {
+    if constexpr (ACT == DU_ACT_SWIGLU) {
+      bf16x2 t;
+      t[0] = (bf16_t)(o[0] * __builtin_amdgcn_rcpf(1.0f + __expf(-o[0])) * o[1]);
+      t[1] = (bf16_t)(o[2] * __builtin_amdgcn_rcpf(1.0f + __expf(-o[2])) * o[3]);
+      *(unsigned*)(stg + srow * ldb + ((scol + 8 * g + 4 * hi) >> 1)) = __builtin_bit_cast(unsigned, t);
+    } else {
+      if constexpr (ACT == DU_ACT_GELU) {
 #pragma unroll
-      for (int e = 0; e < 4; e++) o[e] = gelu_fast(o[e]);
+        for (int e = 0; e < 4; e++) o[e] = gelu_fast(o[e]);
+      }
+      bf16x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; e++) t[e] = (bf16_t)o[e];
+      *(uint2*)(stg + srow * ldb + scol + 8 * g + 4 * hi) = __builtin_bit_cast(uint2, t);
     }
-    bf16x4 t;
-#pragma unroll
-    for (int e = 0; e < 4; e++) t[e] = (bf16_t)o[e];
-    *(uint2*)(stg + srow * ldb + scol + 8 * g + 4 * hi) = __builtin_bit_cast(uint2, t);
   }
 }
 // this lane's bias values for the block whose first column is ncol0 (zeros without a bias); columns past N are clamped (never stored)
@@ -144,23 +152,25 @@ __device__ __forceinline__ void stage_block_f32(const f32x16& a, float* stg, int
   for (int g = 0; g < 4; g++)
     *(float4*)(stg + srow * ldf + scol + 8 * g + 4 * hi) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
 }
-// rows [0, nrows) of the bf16 staging tile -> C rows mrow0 + ...: 16 bytes per lane, whole rows per wave
+// rows [0, nrows) of the bf16 staging tile -> C rows mrow0 + ...: 16 bytes per lane, whole rows per wave.  TBN = staged columns,
+// n0 / ncols = first column / column count of C they map to (half the GEMM's for the SwiGLU gate)
 template <int TBN>
-__device__ __forceinline__ void readout_bf16(const GemmParams& P, const bf16_t* stg, int ldb, int nrows, int mrow0, int n0, bf16_t* Cb, int tid) {
+__device__ __forceinline__ void readout_bf16(const GemmParams& P, const bf16_t* stg, int ldb, int nrows, int mrow0, int n0, int ncols,
+                                             bf16_t* Cb, int tid) {
   constexpr int C8 = TBN / 8;
   const bool wide = (P.ldc % 8 == 0) && ((((uintptr_t)Cb) & 15) == 0);
 #pragma unroll 4
   for (int v = tid; v < nrows * C8; v += 512) {
     const int row = v / C8, c8 = v % C8;
     const int m = mrow0 + row, n = n0 + c8 * 8;
-    if (m >= P.M || n >= P.N) continue;
+    if (m >= P.M || n >= ncols) continue;
     const uint4 t = *(const uint4*)(stg + row * ldb + c8 * 8);
     if ((P.ps_H & 1) && t.x != 0x12345678u) continue;      // measurement aid (du_set_option key 3): staging without the global stores
     bf16_t* dst = Cb + (long)m * P.ldc + n;
-    if (wide && n + 8 <= P.N) *(uint4*)dst = t;
+    if (wide && n + 8 <= ncols) *(uint4*)dst = t;
     else {
       *(uint2*)dst = make_uint2(t.x, t.y);
-      if (n + 8 <= P.N) *(uint2*)(dst + 4) = make_uint2(t.z, t.w);
+      if (n + 4 < ncols) *(uint2*)(dst + 4) = make_uint2(t.z, t.w);
     }
   }
 }
@@ -227,7 +237,7 @@ __device__ __forceinline__ void readout_f32_any(const GemmParams& P, const float
 }
 // bf16 result whose epilogue is bias (+ GELU) only: staged as bf16 (the ViT's qkv and fc1)
 __device__ __forceinline__ bool bf16_simple(const GemmParams& P, const void* Rb) {
-  return !Rb && !P.gamma && !P.row_scale && P.alpha == 1.0f && (P.act == DU_ACT_NONE || P.act == DU_ACT_GELU);
+  return !Rb && !P.gamma && !P.row_scale && P.alpha == 1.0f && (P.act == DU_ACT_NONE || P.act == DU_ACT_GELU || P.act == DU_ACT_SWIGLU);
 }
 
 constexpr int P8_STG_LDB = PBN + 8;            // bf16 staging row, elements (528 B: 16-byte aligned rows, 2-way ds_write_b64 conflicts)
@@ -428,9 +438,15 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
             for (int b = 0; b < 2; b++)
               stage_block_bf16<ACT>(acc[i][j][b], bv[j], stg, P8_STG_LDB, i * 128 + wm * 64 + b * 32 + (lane & 31), j * 128 + wn * 32, hi);
       };
+      if (P.act == DU_ACT_SWIGLU) {
+        stage_all(IC<DU_ACT_SWIGLU>{});
+        __syncthreads();
+        readout_bf16<PBN / 2>(P, stg, P8_STG_LDB, 256, m0, n0 / 2, P.N / 2, (bf16_t*)Cb, tid);
+        return;
+      }
       if (P.act == DU_ACT_GELU) stage_all(IC<DU_ACT_GELU>{}); else stage_all(IC<DU_ACT_NONE>{});
       __syncthreads();
-      readout_bf16<PBN>(P, stg, P8_STG_LDB, 256, m0, n0, (bf16_t*)Cb, tid);
+      readout_bf16<PBN>(P, stg, P8_STG_LDB, 256, m0, n0, P.N, (bf16_t*)Cb, tid);
       done = true;
     }
   }
@@ -631,9 +647,15 @@ __global__ __launch_bounds__(512) void gemm_nt_p8n_kernel(GemmParams P) {
           for (int c = 0; c < 2; c++)
             stage_block_bf16<ACT>(acc[i][c], bv[c], stg, N_STG_LDB, i * 128 + wm * 32 + (lane & 31), wn * 64 + c * 32, hi);
       };
+      if (P.act == DU_ACT_SWIGLU) {
+        stage_all(IC<DU_ACT_SWIGLU>{});
+        __syncthreads();
+        readout_bf16<NBN / 2>(P, stg, N_STG_LDB, 256, m0, n0 / 2, P.N / 2, (bf16_t*)Cb, tid);
+        return;
+      }
       if (P.act == DU_ACT_GELU) stage_all(IC<DU_ACT_GELU>{}); else stage_all(IC<DU_ACT_NONE>{});
       __syncthreads();
-      readout_bf16<NBN>(P, stg, N_STG_LDB, 256, m0, n0, (bf16_t*)Cb, tid);
+      readout_bf16<NBN>(P, stg, N_STG_LDB, 256, m0, n0, P.N, (bf16_t*)Cb, tid);
       done = true;
     }
   }
@@ -698,6 +720,8 @@ static bool p8_legal(const du_gemm_args& a) {
   if (a.lda % 8 || a.ldb % 8 || (((uintptr_t)a.A) & 15) || (((uintptr_t)a.B) & 15)) return false;
   if (a.a_batch_stride % 8 || a.b_batch_stride % 8) return false;
   if ((long)a.lda * 2 * 256 > 0x7fffffffL || (long)a.ldb * 2 * 256 > 0x7fffffffL) return false;
+  if (a.act == DU_ACT_SWIGLU &&
+      (a.out_dtype != DU_BF16 || a.residual || a.gamma || a.row_scale || a.alpha != 1.0f || a.N % 16 || a.ldc % 4)) return false;
   return true;
 }
 
@@ -719,7 +743,9 @@ bool du_gemm_p8_wants(const du_gemm_args& a) { return du_gemm_p8_choice(a) != 0;
 
 // returns DU_ERR_UNSUPPORTED when these kernels cannot serve the product; the caller then uses gemm_glds.hip
 int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st) {
-  const int c = du_gemm_p8_choice(a);
+  int c = du_gemm_p8_choice(a);
+  if (c == 0 && a.act == DU_ACT_SWIGLU && p8_legal(a)) c = 2;     // the gate epilogue exists only here: take the narrow tile when the
+                                                                  // heuristic would have preferred another kernel family
   if (c == 0) return DU_ERR_UNSUPPORTED;
   const bool bf = a.out_dtype == DU_BF16;
   if (c == 1) {

@@ -28,7 +28,7 @@ VIT_CONFIGS = {
     "dinounet_b": dict(embed_dim=768, depth=12, num_heads=12, ffn_layer="mlp", ffn_ratio=4.0, qkv_bias=True),
     "dinounet_l": dict(embed_dim=1024, depth=24, num_heads=16, ffn_layer="mlp", ffn_ratio=4.0, qkv_bias=True),
     "dinounet_7b": dict(embed_dim=4096, depth=40, num_heads=32, ffn_layer="swiglu64", ffn_ratio=3.0, qkv_bias=False,
-                        untie_global_and_local_cls_norm=True),
+                        untie_global_and_local_cls_norm=True, drop_path_rate=0.4),
 }
 
 
@@ -150,8 +150,12 @@ class RopePositionEmbedding(nn.Module):
 class DinoVisionTransformer(nn.Module):
     def __init__(self, *, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, ffn_ratio=4.0, qkv_bias=True,
                  ffn_layer="mlp", n_storage_tokens=4, mask_k_bias=True, untie_global_and_local_cls_norm=False,
-                 rope_rescale_coords=2.0, **ignored):
+                 rope_rescale_coords=2.0, drop_path_rate=0.0, **ignored):
         super().__init__()
+        # train-mode batch-subset stochastic depth of every block (layers/block.py:126-187; 0.4 for the 7B model, hub/backbones.py:480,
+        # 0 otherwise).  The backbone is frozen but nnUNetTrainer.py:890 puts the whole network in train(), so the reference applies it.
+        self.drop_path_rate = float(drop_path_rate)
+        self.pinned_subsets = None          # test hook: [(idx_attn, idx_ffn)] per block instead of torch.randperm draws
         self.num_features = self.embed_dim = embed_dim
         self.n_blocks = depth
         self.num_heads = num_heads
@@ -221,8 +225,9 @@ class DinoVisionTransformer(nn.Module):
                      n2b=f(blk.norm2.bias), g2=f(blk.ls2.gamma))
             if isinstance(blk.mlp, Mlp):
                 d.update(fc1_w=g(blk.mlp.fc1.weight), fc1_b=f(blk.mlp.fc1.bias), fc2_w=g(blk.mlp.fc2.weight), fc2_b=f(blk.mlp.fc2.bias))
-            else:
-                d.update(w1=g(blk.mlp.w1.weight), b1=f(blk.mlp.w1.bias), w2=g(blk.mlp.w2.weight), b2=f(blk.mlp.w2.bias),
+            else:   # SwiGLU: w1 / w2 interleaved row by row -> one product whose epilogue applies the gate (ops.mm_swiglu)
+                d.update(w12=g(ops.interleave_pairs(blk.mlp.w1.weight.detach(), blk.mlp.w2.weight.detach())),
+                         b12=f(ops.interleave_pairs(blk.mlp.w1.bias.detach(), blk.mlp.w2.bias.detach())),
                          w3=g(blk.mlp.w3.weight), b3=f(blk.mlp.w3.bias))
             pk["blocks"].append(d)
         self._cache = (key, pk)
@@ -248,20 +253,46 @@ class DinoVisionTransformer(nn.Module):
         take = list(n)
         outs = []
         sin_all, cos_all = self.rope_embed.sincos_all(hp, wp, x.device, self.training, len(pk["blocks"]))   # vision_transformer.py:271-272
-        for i, d in enumerate(pk["blocks"]):
-            h, _, _ = ops.layernorm_raw(x2, d["n1w"], d["n1b"], 1e-5, dtype)
+        sd = self.training and self.drop_path_rate > 0.0
+        k_sub = max(int(B * (1 - self.drop_path_rate)), 1)                                 # layers/block.py:92-93
+        if sd:
+            alpha = torch.full((1,), B / k_sub, dtype=torch.float32, device=x.device)        # residual_scale_factor
+
+        def attn_branch(xr, Bs, i, d, scale):
+            """xr (Bs*N, D) fp32 += [scale *] ls1(attn(norm1(xr)))   in place (layers/block.py:189-193)"""
+            h, _, _ = ops.layernorm_raw(xr, d["n1w"], d["n1b"], 1e-5, dtype)
             qkv = ops.mm(h, d["qkv_w"], bias=d["qkv_b"])
-            a = ops.attention(qkv, sin_all[i], cos_all[i], B, N, nh, dh, npre, self._ws)
-            ops.mm(a, d["proj_w"], bias=d["proj_b"], gamma=d["g1"], residual=x2, out=x2)
-            h, _, _ = ops.layernorm_raw(x2, d["n2w"], d["n2b"], 1e-5, dtype)
+            a = ops.attention(qkv, sin_all[i], cos_all[i], Bs, N, nh, dh, npre, self._ws)
+            ops.mm(a, d["proj_w"], bias=d["proj_b"], gamma=d["g1"], residual=xr, out=xr, row_scale=scale, rs_rows=xr.shape[0] if scale is not None else 0)
+
+        def ffn_branch(xr, d, scale):
+            h, _, _ = ops.layernorm_raw(xr, d["n2w"], d["n2b"], 1e-5, dtype)
+            rs = xr.shape[0] if scale is not None else 0
             if "fc1_w" in d:
                 u = ops.mm(h, d["fc1_w"], bias=d["fc1_b"], act=ACT_GELU)
-                ops.mm(u, d["fc2_w"], bias=d["fc2_b"], gamma=d["g2"], residual=x2, out=x2)
+                ops.mm(u, d["fc2_w"], bias=d["fc2_b"], gamma=d["g2"], residual=xr, out=xr, row_scale=scale, rs_rows=rs)
             else:                                                                          # SwiGLU, ffn_layers.py:73-77
-                u1 = ops.mm(h, d["w1"], bias=d["b1"])
-                u2 = ops.mm(h, d["w2"], bias=d["b2"])
-                u = torch.nn.functional.silu(u1).mul_(u2)
-                ops.mm(u, d["w3"], bias=d["b3"], gamma=d["g2"], residual=x2, out=x2)
+                u = ops.mm_swiglu(h, d["w12"], d["b12"])
+                ops.mm(u, d["w3"], bias=d["b3"], gamma=d["g2"], residual=xr, out=xr, row_scale=scale, rs_rows=rs)
+
+        for i, d in enumerate(pk["blocks"]):
+            if not sd:
+                attn_branch(x2, B, i, d, None)
+                ffn_branch(x2, d, None)
+            else:
+                # batch-subset stochastic depth (layers/block.py:126-187): each branch runs on a random subset of k_sub samples and its
+                # residual is added back scaled by B / k_sub; the subset is gathered, updated in place and scattered back
+                if self.pinned_subsets is not None:
+                    i1, i2 = (t.to(x.device) for t in self.pinned_subsets[i])
+                else:
+                    i1 = torch.randperm(B, device=x.device)[:k_sub]
+                    i2 = torch.randperm(B, device=x.device)[:k_sub]
+                xsub = ops.sample_gather(xs, i1)
+                attn_branch(xsub.view(k_sub * N, D), k_sub, i, d, alpha)
+                ops.sample_scatter_(xs, xsub, i1)
+                xsub = ops.sample_gather(xs, i2)
+                ffn_branch(xsub.view(k_sub * N, D), d, alpha)
+                ops.sample_scatter_(xs, xsub, i2)
             if i in take:
                 if norm:
                     o, _, _ = ops.layernorm_raw(x2, pk["norm_w"], pk["norm_b"], 1e-5, dtype)   # vision_transformer.py:300

@@ -15,7 +15,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, DU_BF16, DU_F32, IM2COL_COL, IM2COL_ROW, PLAIN_COL,
+from ._lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SWIGLU, DU_BF16, DU_F32, IM2COL_COL, IM2COL_ROW, PLAIN_COL,
                    PLAIN_ROW, STORE_PIXEL_SHUFFLE2, ConvGeom, GemmArgs)
 
 __all__ = ["mm", "linear", "conv2d", "conv_transpose2x2", "norm_act", "layer_norm", "msda", "dwconv3x3",
@@ -331,6 +331,60 @@ def mm(x, w, *, out=None, out_dtype=None, bias=None, act=ACT_NONE, gamma=None, r
              bias=_dp(bias), act=act, gamma=_dp(gamma), row_scale=_dp(row_scale), rs_rows=rs_rows,
              residual=_dp(residual), ldr=ldr)
     return out
+
+
+def interleave_pairs(w1, w2):
+    """(h, K) + (h, K) -> (2h, K) with rows (2j, 2j+1) = (w1[j], w2[j]) (also for 1-D biases): the operand layout of mm_swiglu."""
+    return torch.stack((w1, w2), dim=1).reshape((2 * w1.shape[0],) + tuple(w1.shape[1:])).contiguous()
+
+
+def mm_swiglu(x, w12, b12=None):
+    """SwiGLU hidden activation silu(x w1^T + b1) * (x w2^T + b2) (layers/ffn_layers.py:73-77) from the INTERLEAVED projection
+    w12 = interleave_pairs(w1, w2): one product; on the bf16 multi-phase NT kernels the gate runs in the GEMM epilogue (the (M, 2h)
+    projection never reaches HBM), otherwise the product is followed by the du_swiglu_pairs kernel."""
+    _req(x, w12)
+    M, K, lda = _rows2d(x)
+    N2, K2, ldb = _rows2d(w12)
+    assert K == K2 and N2 % 2 == 0 and x.dtype == w12.dtype
+    h = N2 // 2
+    out = torch.empty((M, h), dtype=x.dtype, device=x.device)
+    if x.dtype == torch.bfloat16:
+        a = GemmArgs()
+        a.dtype = a.out_dtype = DU_BF16
+        a.a_mode = a.b_mode = PLAIN_ROW
+        a.M, a.N, a.K = M, N2, K
+        a.A, a.lda, a.B, a.ldb, a.C, a.ldc = x.data_ptr(), lda, w12.data_ptr(), ldb, out.data_ptr(), h
+        a.batch, a.split_k, a.alpha, a.act = 1, 1, 1.0, ACT_SWIGLU
+        a.bias = _dp(b12)
+        e0 = PROFILE.start() if PROFILE is not None else None
+        rc = _lib.lib().du_gemm(C.byref(a), _st())
+        if rc == 0:
+            if PROFILE is not None:
+                PROFILE.stop("gemm_nt_p8_kernel<bf16,swiglu>", e0, 2.0 * M * N2 * K, 2.0 * (M * K + N2 * K + M * h))
+            return out
+        if rc != -2:
+            _lib.check(rc, "du_gemm (swiglu)")
+    u = mm(x, w12, bias=b12)
+    _lib.check(_lib.lib().du_swiglu_pairs(_code(x.dtype), _p(u), _p(out), M, h, _st()), "du_swiglu_pairs")
+    return out
+
+
+def sample_gather(x, idx):
+    """x (B, n) fp32 contiguous, idx (k,) int64 on the device -> (k, n) = x[idx]"""
+    _req(x, idx)
+    assert x.dtype == torch.float32 and x.is_contiguous() and idx.dtype == torch.int64
+    n = x[0].numel()
+    out = torch.empty((idx.numel(),) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().du_sample_copy(_p(x), _p(out), _p(idx), idx.numel(), n, 0, _st()), "du_sample_copy")
+    return out
+
+
+def sample_scatter_(x, src, idx):
+    """x[idx] = src, in place (rows of idx are distinct)"""
+    _req(x, src, idx)
+    assert x.dtype == torch.float32 and src.dtype == torch.float32 and x.is_contiguous() and src.is_contiguous()
+    _lib.check(_lib.lib().du_sample_copy(_p(src), _p(x), _p(idx), idx.numel(), x[0].numel(), 1, _st()), "du_sample_copy")
+    return x
 
 
 def mm_dgrad(dy, w, out=None):

@@ -111,7 +111,11 @@ class TrainStep:
             torch.cuda.synchronize()
             try:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # With a process group alive, ProcessGroupNCCL's watchdog thread polls its work events (hipEventQuery) while this
+                # thread captures; under the default "global" capture mode that call is illegal and the watchdog aborts the process
+                # ("operation not permitted when stream is capturing").  thread_local confines the capture restrictions to this thread.
+                mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+                with torch.cuda.graph(graph, capture_error_mode=mode):
                     self.loss = self._step()
                 self.graph = graph
             except Exception as e:  # noqa: BLE001   capture is an optimisation: a step that cannot be captured still has to train

@@ -61,6 +61,10 @@ extern "C" {
 #define DU_ACT_GELU 1    /* exact erf GELU (nn.GELU default) */
 #define DU_ACT_RELU 2
 #define DU_ACT_LEAKY 3   /* LeakyReLU(0.01) */
+#define DU_ACT_SWIGLU 4  /* gate of SwiGLUFFN (layers/ffn_layers.py:73-77) on an INTERLEAVED projection: B rows (2j, 2j+1) = (w1[j], w2[j]),
+                            bias likewise; the result has N/2 columns, C[m][j] = silu(v[2j]) * v[2j+1], v = alpha*acc + bias; ldc / the
+                            stored row length refer to those N/2 columns.  Served by the multi-phase bf16 NT kernels only (du_gemm
+                            returns DU_ERR_UNSUPPORTED otherwise: run the product without activation + du_swiglu_pairs) */
 
 /* du_gemm store modes */
 #define DU_STORE_PLAIN 0
@@ -269,6 +273,11 @@ int du_film_fwd(int dtype, const void* gb, const void* z2, void* z, int64_t rows
 int du_film_bwd(int dtype, const void* dz, const void* gb, const void* z2, void* dgb, void* dz2, int64_t rows, int R, void* stream);
 
 /* ---- elementwise helpers --------------------------------------------------------------------------- */
+/* SwiGLU gate of an interleaved projection u (rows, 2h): out (rows, h) = silu(u[:, 2j]) * u[:, 2j+1]   (layers/ffn_layers.py:73-77) */
+int du_swiglu_pairs(int dtype, const void* u, void* out, int64_t rows, int64_t h, void* stream);
+/* whole samples of an fp32 (B, n_per_sample) tensor by int64 index: scatter = 0: dst[j] = src[idx[j]], 1: dst[idx[j]] = src[j]
+   (batch-subset stochastic depth of the ViT-7B blocks in train mode, layers/block.py:126-187) */
+int du_sample_copy(const float* src, float* dst, const int64_t* idx, int k, int64_t n_per_sample, int scatter, void* stream);
 int du_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
 /* NCHW fp32 image -> NHWC `dtype` with channels zero-padded to Cpad */
 int du_nchw_to_nhwc_pad(int dst_dtype, const float* src, void* dst, int B, int C, int H, int W, int Cpad, void* stream);

@@ -116,17 +116,30 @@ def vit_ffn(x, p: SD, kind: str):
     return F.linear(h, p["w3.weight"], p["w3.bias"])
 
 
-def vit_block(x, p: SD, cfg, sin, cos):
-    """LAY/block.py:189-194 (eval / drop-path 0 branch); LayerScale LAY/layer_scale.py:28."""
+def vit_block(x, p: SD, cfg, sin, cos, subset=None):
+    """LAY/block.py:189-194 (eval / drop-path 0 branch); LayerScale LAY/layer_scale.py:28.
+    subset = (idx_attn, idx_ffn): the train-mode batch-subset stochastic depth of LAY/block.py:126-187 -- each branch runs on the
+    samples idx only and its LayerScale-d output is added back scaled by B / len(idx) (torch.index_add with alpha)."""
     D = x.shape[-1]
-    h = F.layer_norm(x, (D,), p["norm1.weight"], p["norm1.bias"], VIT_LN_EPS)
-    x = x + p["ls1.gamma"] * vit_attention(h, p.sub("attn."), cfg["num_heads"], sin, cos)
-    h = F.layer_norm(x, (D,), p["norm2.weight"], p["norm2.bias"], VIT_LN_EPS)
-    x = x + p["ls2.gamma"] * vit_ffn(h, p.sub("mlp."), cfg["ffn"])
-    return x
+
+    def attn(t):
+        h = F.layer_norm(t, (D,), p["norm1.weight"], p["norm1.bias"], VIT_LN_EPS)
+        return p["ls1.gamma"] * vit_attention(h, p.sub("attn."), cfg["num_heads"], sin, cos)
+
+    def ffn(t):
+        h = F.layer_norm(t, (D,), p["norm2.weight"], p["norm2.bias"], VIT_LN_EPS)
+        return p["ls2.gamma"] * vit_ffn(h, p.sub("mlp."), cfg["ffn"])
+
+    if subset is None:
+        x = x + attn(x)
+        return x + ffn(x)
+    i1, i2 = subset
+    scale = x.shape[0] / i1.numel()
+    x = torch.index_add(x, 0, i1, attn(x[i1]), alpha=scale)
+    return torch.index_add(x, 0, i2, ffn(x[i2]), alpha=scale)
 
 
-def vit_intermediate(x, p: SD, cfg, rope_rescale=None):
+def vit_intermediate(x, p: SD, cfg, rope_rescale=None, subsets=None):
     """VIT:281-318 get_intermediate_layers(n=interaction_indexes, return_class_token=True, norm=True)
     via VIT:265-279 and prepare_tokens_with_masks VIT:186-216.  Returns [(patch (B,hw,D), cls (B,D))]."""
     B = x.shape[0]
@@ -143,7 +156,7 @@ def vit_intermediate(x, p: SD, cfg, rope_rescale=None):
     for i in range(cfg["depth"]):
         if per_block:                                                                        # train mode: one draw per block, VIT:271-272
             sin, cos = rope_sincos(H, W, p["rope_embed.periods"], float(rope_rescale[i]))
-        t = vit_block(t, p.sub(f"blocks.{i}."), cfg, sin, cos)
+        t = vit_block(t, p.sub(f"blocks.{i}."), cfg, sin, cos, None if subsets is None else subsets[i])
         if i in cfg["interaction_indexes"]:
             o = F.layer_norm(t, (D,), p["norm.weight"], p["norm.bias"], VIT_LN_EPS)          # VIT:300
             outs.append((o[:, N_STORAGE + 1:], o[:, 0]))

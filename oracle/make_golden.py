@@ -233,6 +233,68 @@ def train_case_pinned(name, model_name, B, H, W, num_classes=2, sample=65536, ch
                                                       sample=sample, grad_norms=norms, unused=unused))), **out)
 
 
+VIT7B_STYLE = dict(embed_dim=256, depth=3, num_heads=2, ffn_ratio=3.0, qkv_bias=False, drop_path_rate=0.4, ffn_layer="swiglu64",
+                   n_storage_tokens=4, mask_k_bias=True, untie_global_and_local_cls_norm=True)
+
+
+def vit7b_style_case(name="vit7b_style_64"):
+    """The code paths only the 7B backbone takes (hub/backbones.py:452-496), on the reference's own DinoVisionTransformer with 7B-style
+    hyper-parameters at toy width: head dim 128, no qkv bias under a K-masked-bias Linear, SwiGLU-64 FFN (ffn_layers.py:52-77), and the
+    train-mode batch-subset stochastic depth (layers/block.py:126-187) with rate 0.4.  get_intermediate_layers (the adapter's call,
+    ADP:424-426) in eval mode and in train mode with the random ops pinned (per-block RoPE rescale draws, torch.randperm subsets)."""
+    refshim.install()
+    from dinounet.dinov3.models.vision_transformer import DinoVisionTransformer as RefViT
+    cfg = VIT7B_STYLE
+    torch.manual_seed(0)
+    net = RefViT(patch_size=16, pos_embed_rope_base=100, pos_embed_rope_normalize_coords="separate", pos_embed_rope_rescale_coords=2,
+                 pos_embed_rope_dtype="fp32", layerscale_init=1.0e-5, norm_layer="layernormbf16", ffn_bias=True, proj_bias=True, **cfg)
+    net.init_weights()
+    ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    sd = weights.make_state_dict(ks, seed=0)
+    net.load_state_dict(sd, strict=True)
+    B, depth = 5, cfg["depth"]
+    x = weights.make_input(B, 3, 64, 64, seed=6)
+    idx = list(range(depth))
+    ocfg = dict(embed_dim=cfg["embed_dim"], depth=depth, num_heads=cfg["num_heads"], ffn="swiglu", qkv_bias=False, interaction_indexes=idx)
+    out = {"meta": np.array(json.dumps(dict(cfg=cfg, B=B, H=64, W=64, keys=[[k, list(s_)] for k, s_ in ks])))}
+    net.eval()
+    with torch.no_grad():
+        ref = net.get_intermediate_layers(x, n=idx, return_class_token=True)
+        orc = O.vit_intermediate(x, O.SD(sd), ocfg)
+    for i, ((rp, rc), (op, oc)) in enumerate(zip(ref, orc)):
+        assert rel(op, rp) < TOL and rel(oc, rc) < TOL, i
+        out[f"eval_patch{i}"], out[f"eval_cls{i}"] = rp.numpy().astype(np.float32), rc.numpy().astype(np.float32)
+    net.train()
+    log_scales, _ = weights.pinned_randomness(depth, B, seed=3)
+    subsets = weights.pinned_subsets(depth, B, cfg["drop_path_rate"], seed=3)
+    perms = [t for pair in subsets for t in pair]
+    real_randperm = torch.randperm
+    state = {"i": 0}
+
+    def randperm(n, **kw):            # the k-prefix of the pinned permutation is what block.py:97,113 slices off
+        t = perms[state["i"]]; state["i"] += 1
+        rest = torch.tensor([j for j in range(n) if j not in t.tolist()], dtype=torch.int64)
+        return torch.cat([t, rest])
+
+    class _Pin(pin_reference_randomness):
+        pass
+
+    torch.randperm = randperm
+    try:
+        with torch.no_grad(), pin_reference_randomness(net, log_scales, []) as pr:
+            ref = net.get_intermediate_layers(x, n=idx, return_class_token=True)
+            assert pr.i == depth and state["i"] == 2 * depth, (pr.i, state["i"])
+    finally:
+        torch.randperm = real_randperm
+    with torch.no_grad():
+        orc = O.vit_intermediate(x, O.SD(sd), ocfg, rope_rescale=log_scales.exp(), subsets=subsets)
+    for i, ((rp, rc), (op, oc)) in enumerate(zip(ref, orc)):
+        assert rel(op, rp) < TOL and rel(oc, rc) < TOL, (i, rel(op, rp))
+        out[f"train_patch{i}"], out[f"train_cls{i}"] = rp.numpy().astype(np.float32), rc.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[{name}] 7B-style ViT (Dh 128, SwiGLU-64, subset stochastic depth 0.4): oracle == reference in eval and pinned train mode (<{TOL})")
+
+
 def msda_cases():
     """ops/test.py fixture (N,M,D=1,2,2; Lq,L,P=2,2,2; shapes (6,4),(3,2); manual_seed(3)) evaluated with the
     reference's own ms_deform_attn_core_pytorch in fp64 + its gradients, for the gradcheck channel list."""
@@ -280,7 +342,7 @@ def msda_cases():
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["msda", "s", "b", "l", "train", "s512", "misc", "b512", "l512", "pinned"]
+    which = sys.argv[1:] or ["msda", "s", "b", "l", "train", "s512", "misc", "b512", "l512", "pinned", "vit7b"]
     if "msda" in which:
         msda_cases()
     if "s" in which:
@@ -304,6 +366,8 @@ def main():
         eval_case("dinounet_b_512_eval", "dinounet_b", 1, 3, 512, 512)
     if "l512" in which:     # the headline config's shape: N = 1029 tokens, Lq = 5376 queries, 512^2 decoder
         eval_case("dinounet_l_512_eval", "dinounet_l", 1, 3, 512, 512)
+    if "vit7b" in which:
+        vit7b_style_case()
     if "pinned" in which:   # train mode with the random ops pinned on both sides
         train_case_pinned("dinounet_s_64_train_pinned", "dinounet_s", 2, 64, 64, sample=4096)
         train_case_pinned("dinounet_l_256_train_pinned", "dinounet_l", 2, 256, 256, sample=16384)

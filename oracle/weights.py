@@ -104,3 +104,11 @@ def sample_indices(key: str, numel: int, n: int) -> torch.Tensor:
     """Deterministic element sample of a flattened tensor (gradient fixtures of tensors too large to commit in full)."""
     g = _gen("sample:" + canonical_key(key), 0)
     return torch.randperm(numel, generator=g)[:n].sort().values
+
+
+def pinned_subsets(depth, batch, drop_rate, seed=0):
+    """Fixed sample subsets for the ViT blocks' batch-subset stochastic depth (LAY/block.py:126-187): per block the first k entries of
+    two random permutations of the batch (attention branch, FFN branch), k = max(int(B (1 - rate)), 1)."""
+    g = torch.Generator(device="cpu"); g.manual_seed(4000 + seed)
+    k = max(int(batch * (1 - drop_rate)), 1)
+    return [(torch.randperm(batch, generator=g)[:k].clone(), torch.randperm(batch, generator=g)[:k].clone()) for _ in range(depth)]

@@ -51,6 +51,28 @@ def test_oracle_matches_reference_golden(name):
     assert (am != gold_am).mean() < 1e-4
 
 
+def test_oracle_vit7b_style_matches_reference_golden():
+    """The paths only the 7B backbone takes (head dim 128, no qkv bias, SwiGLU-64, train-mode batch-subset stochastic depth 0.4 with
+    pinned subsets + pinned per-block RoPE rescale): the restatement against the reference's own DinoVisionTransformer outputs."""
+    g = np.load(os.path.join(GOLD, "vit7b_style_64.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg, B = meta["cfg"], meta["B"]
+    sd = weights.make_state_dict([(k, tuple(s)) for k, s in meta["keys"]], seed=0)
+    depth = cfg["depth"]
+    ocfg = dict(embed_dim=cfg["embed_dim"], depth=depth, num_heads=cfg["num_heads"], ffn="swiglu", qkv_bias=False,
+                interaction_indexes=list(range(depth)))
+    x = weights.make_input(B, 3, meta["H"], meta["W"], seed=6)
+    with torch.no_grad():
+        ev = O.vit_intermediate(x, O.SD(sd), ocfg)
+        log_scales, _ = weights.pinned_randomness(depth, B, seed=3)
+        subsets = weights.pinned_subsets(depth, B, cfg["drop_path_rate"], seed=3)
+        tr = O.vit_intermediate(x, O.SD(sd), ocfg, rope_rescale=log_scales.exp(), subsets=subsets)
+    for i in range(depth):
+        assert rel(ev[i][0], torch.from_numpy(g[f"eval_patch{i}"])) < 2e-5 and rel(ev[i][1], torch.from_numpy(g[f"eval_cls{i}"])) < 2e-5
+        assert rel(tr[i][0], torch.from_numpy(g[f"train_patch{i}"])) < 2e-5 and rel(tr[i][1], torch.from_numpy(g[f"train_cls{i}"])) < 2e-5
+    assert rel(tr[depth - 1][0], ev[depth - 1][0]) > 1e-3      # the pinned train-mode path really differs from eval
+
+
 def test_oracle_msda_loops_match_reference_fixture():
     """ops/test.py fixture (seed 3): scalar restatement of the CUDA loop == reference grid_sample core (fp64)."""
     g = np.load(os.path.join(GOLD, "msda_testpy.npz"))

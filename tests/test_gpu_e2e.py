@@ -258,3 +258,62 @@ def test_train_step_pinned_randomness_vs_reference(name):
     assert n_cmp == len(norms)
     assert worst[1] < 2e-2, worst
     assert sorted(k for k, p in named.items() if p.requires_grad and p.grad is None) == meta["unused"]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_vit7b_style_paths_vs_reference(precision):
+    """the code paths only the 7B backbone takes -- head dim 128 attention, no qkv bias, the SwiGLU gate (fused into
+    the GEMM epilogue in bf16, du_swiglu_pairs in fp32) and the train-mode batch-subset stochastic depth (du_sample_copy gather /
+    scatter, scaled residual epilogue) -- on a 7B-style ViT at toy width against the reference's own DinoVisionTransformer
+    (tests/golden/vit7b_style_64.npz: eval, and train mode with pinned RoPE draws + pinned subsets)."""
+    from dinounet_amd.dinov3.vision_transformer import DinoVisionTransformer
+    g = np.load(os.path.join(GOLD, "vit7b_style_64.npz"))
+    meta = json.loads(str(g["meta"]))
+    cfg, B, depth = meta["cfg"], meta["B"], meta["cfg"]["depth"]
+    net = DinoVisionTransformer(**cfg)
+    net.load_state_dict(weights.make_state_dict([(k, tuple(s)) for k, s in meta["keys"]], seed=0), strict=True)
+    net = net.cuda()
+    dt = torch.float32 if precision == "fp32" else torch.bfloat16
+    tol = 1e-3 if precision == "fp32" else 4e-2
+    x = weights.make_input(B, 3, meta["H"], meta["W"], seed=6).cuda()
+    net.eval()
+    ev = net.get_intermediate_layers(x, n=list(range(depth)), return_class_token=True, dtype=dt)
+    net.train()
+    log_scales, _ = weights.pinned_randomness(depth, B, seed=3)
+    net.rope_embed.pinned_log_scales = log_scales
+    net.pinned_subsets = weights.pinned_subsets(depth, B, cfg["drop_path_rate"], seed=3)
+    tr = net.get_intermediate_layers(x, n=list(range(depth)), return_class_token=True, dtype=dt)
+    worst = 0.0
+    for i in range(depth):
+        for mode, outs in (("eval", ev), ("train", tr)):
+            worst = max(worst, rel(outs[i][0], torch.from_numpy(g[f"{mode}_patch{i}"])), rel(outs[i][1], torch.from_numpy(g[f"{mode}_cls{i}"])))
+    print(f"[vit7b-style {precision}] worst rel err over {depth} blocks x (eval, pinned train) x (patch, cls): {worst:.2e}")
+    assert worst < tol
+    # un-pinned train mode draws its own subsets on the device: runs, finite, differs from eval
+    net.pinned_subsets = None
+    net.rope_embed.pinned_log_scales = None
+    rnd = net.get_intermediate_layers(x, n=[depth - 1], return_class_token=True, dtype=dt)
+    assert torch.isfinite(rnd[0][0].float()).all()
+
+
+def test_vit7b_width_block_vs_torch_fp32():
+    """One block at the true 7B width (D 4096, 32 heads x Dh 128, SwiGLU hidden 8192, no qkv bias) in bf16 against plain torch fp32 of
+    the same bf16-rounded weights: the multi-phase GEMMs with the gate epilogue and the Dh-128 attention at production width."""
+    from dinounet_amd.dinov3.vision_transformer import DinoVisionTransformer
+    cfg = dict(embed_dim=4096, depth=1, num_heads=32, ffn_ratio=3.0, qkv_bias=False, ffn_layer="swiglu64", n_storage_tokens=4,
+               mask_k_bias=True)
+    net = DinoVisionTransformer(**cfg)
+    ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    sd = weights.make_state_dict(ks, seed=1)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    B, H = 4, 256                                         # 4 x (5 + 256) tokens = 1044 rows: ragged against the 256-row tiles
+    x = weights.make_input(B, 3, H, H, seed=8).cuda()
+    (patch, cls), = net.get_intermediate_layers(x, n=[0], return_class_token=True, dtype=torch.bfloat16)
+    ocfg = dict(embed_dim=4096, depth=1, num_heads=32, ffn="swiglu", qkv_bias=False, interaction_indexes=[0])
+    sdq = {k: (v.to(torch.bfloat16).float() if (v.dim() == 2 or k.endswith("patch_embed.proj.weight")) else v).cuda() for k, v in sd.items()}
+    with torch.no_grad():
+        (rp, rc), = O.vit_intermediate(x, O.SD(sdq), ocfg)
+    e = max(rel(patch, rp), rel(cls, rc))
+    print(f"[7B-width block bf16 vs torch fp32] rel err {e:.2e}")
+    assert e < 4e-2
