@@ -311,9 +311,9 @@ def test_vit7b_width_block_vs_torch_fp32():
     x = weights.make_input(B, 3, H, H, seed=8).cuda()
     (patch, cls), = net.get_intermediate_layers(x, n=[0], return_class_token=True, dtype=torch.bfloat16)
     ocfg = dict(embed_dim=4096, depth=1, num_heads=32, ffn="swiglu", qkv_bias=False, interaction_indexes=[0])
-    sdq = {k: (v.to(torch.bfloat16).float() if (v.dim() == 2 or k.endswith("patch_embed.proj.weight")) else v).cuda() for k, v in sd.items()}
+    sdq = {k: (v.to(torch.bfloat16).float() if (v.dim() == 2 or k.endswith("patch_embed.proj.weight")) else v) for k, v in sd.items()}
     with torch.no_grad():
-        (rp, rc), = O.vit_intermediate(x, O.SD(sdq), ocfg)
+        (rp, rc), = O.vit_intermediate(x.cpu(), O.SD(sdq), ocfg)          # the oracle runs on the host
     e = max(rel(patch, rp), rel(cls, rc))
     print(f"[7B-width block bf16 vs torch fp32] rel err {e:.2e}")
     assert e < 4e-2
