@@ -158,15 +158,15 @@ template <int TBN>
 __device__ __forceinline__ void readout_bf16(const GemmParams& P, const bf16_t* stg, int ldb, int nrows, int mrow0, int n0, int ncols,
                                              bf16_t* Cb, int tid) {
   constexpr int C8 = TBN / 8;
-  const bool wide = (P.ldc % 8 == 0) && ((((uintptr_t)Cb) & 15) == 0);
+  const bool wide = (P.ldc % 8 == 0) && ((((uintptr_t)Cb) & 15) == 0) && (P.store_mode == DU_STORE_PLAIN || P.ps_C % 8 == 0);
 #pragma unroll 4
   for (int v = tid; v < nrows * C8; v += 512) {
     const int row = v / C8, c8 = v % C8;
     const int m = mrow0 + row, n = n0 + c8 * 8;
     if (m >= P.M || n >= ncols) continue;
     const uint4 t = *(const uint4*)(stg + row * ldb + c8 * 8);
-    if ((P.ps_H & 1) && t.x != 0x12345678u) continue;      // measurement aid (du_set_option key 3): staging without the global stores
-    bf16_t* dst = Cb + (long)m * P.ldc + n;
+    if ((P.dbg & 1) && t.x != 0x12345678u) continue;      // measurement aid (du_set_option key 3): staging without the global stores
+    bf16_t* dst = Cb + out_offset(P, m, n, P.ldc);
     if (wide && n + 8 <= ncols) *(uint4*)dst = t;
     else {
       *(uint2*)dst = make_uint2(t.x, t.y);
@@ -175,65 +175,108 @@ __device__ __forceinline__ void readout_bf16(const GemmParams& P, const bf16_t* 
   }
 }
 // rows of the fp32 staging tile -> C with the full du_gemm epilogue (alpha, bias, act, gamma, row_scale, residual).  ACT: the
-// activation when it is known at compile time (NONE / GELU), -1 = read P.act per element.  Four 16-byte pieces per thread and trip:
-// the residual loads of a trip are all issued before the first is consumed.
-template <typename TC, int TBN, int ACT>
+// activation when it is known at compile time (NONE / GELU), -1 = read P.act per element.  An item = W consecutive columns of one row
+// (16 bytes of C: 4 fp32, or 8 bf16 when the row strides allow 16-byte accesses); four items per thread and trip, the residual loads of
+// a trip all issued before the first is consumed.
+template <typename TC, int W> struct RowVec;
+template <> struct RowVec<float, 4> {
+  static __device__ __forceinline__ void load(const float* p, float* v) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  static __device__ __forceinline__ void store(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct RowVec<bf16_t, 4> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float* v) { Out4p<bf16_t>::load(p, v); }
+  static __device__ __forceinline__ void store(bf16_t* p, const float* v) { Out4p<bf16_t>::store(p, v); }
+};
+template <> struct RowVec<bf16_t, 8> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float* v) {
+    const bf16x8 t = __builtin_bit_cast(bf16x8, *(const uint4*)p);
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (float)t[j];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
+    bf16x8 t;
+#pragma unroll
+    for (int j = 0; j < 8; j++) t[j] = (bf16_t)v[j];
+    *(uint4*)p = __builtin_bit_cast(uint4, t);
+  }
+};
+
+template <typename TC, int TBN, int ACT, int W>
 __device__ __forceinline__ void readout_f32(const GemmParams& P, const float* stg, int ldf, int nrows, int mrow0, int n0, TC* Cb, const TC* Rb,
                                             int tid) {
-  constexpr int C4 = TBN / 4, U = 4;
-  const int total = nrows * C4;
+  constexpr int CW = TBN / W, U = W == 8 ? 2 : 4;        // 16 residual floats in flight either way (the 256 x 256 kernel still holds
+                                                          // half of its accumulators during the first pass)
+  const int total = nrows * CW;
   for (int v0 = tid; v0 < total; v0 += 512 * U) {
-    float rr[U][4];
+    float rr[U][W];
     bool live[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int v = v0 + u * 512;
-      const int row = v / C4, c4 = v % C4;
-      const int m = mrow0 + row, n = n0 + c4 * 4;
+      const int row = v / CW, cw = v % CW;
+      const int m = mrow0 + row, n = n0 + cw * W;
       live[u] = v < total && m < P.M && n < P.N;
-      rr[u][0] = rr[u][1] = rr[u][2] = rr[u][3] = 0.f;
-      if (Rb && live[u]) Out4p<TC>::load(Rb + (long)m * P.ldr + n, rr[u]);
+#pragma unroll
+      for (int e = 0; e < W; e++) rr[u][e] = 0.f;
+      if (Rb && live[u]) RowVec<TC, W>::load(Rb + out_offset(P, m, n, P.ldr), rr[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
       if (!live[u]) continue;
       const int v = v0 + u * 512;
-      const int row = v / C4, c4 = v % C4;
-      const int m = mrow0 + row, n = n0 + c4 * 4;
-      const float4 tt = *(const float4*)(stg + row * ldf + c4 * 4);
-      float o[4] = {tt.x * P.alpha, tt.y * P.alpha, tt.z * P.alpha, tt.w * P.alpha};
-      if (P.bias) {
-        const float4 bb = *(const float4*)(P.bias + n);
-        o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
+      const int row = v / CW, cw = v % CW;
+      const int m = mrow0 + row, n = n0 + cw * W;
+      float o[W];
+#pragma unroll
+      for (int h = 0; h < W / 4; h++) {
+        const float4 tt = *(const float4*)(stg + row * ldf + cw * W + 4 * h);
+        o[4 * h] = tt.x * P.alpha; o[4 * h + 1] = tt.y * P.alpha; o[4 * h + 2] = tt.z * P.alpha; o[4 * h + 3] = tt.w * P.alpha;
+        if (P.bias) {
+          const float4 bb = *(const float4*)(P.bias + n + 4 * h);
+          o[4 * h] += bb.x; o[4 * h + 1] += bb.y; o[4 * h + 2] += bb.z; o[4 * h + 3] += bb.w;
+        }
       }
       if constexpr (ACT == DU_ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) o[e] = apply_act(o[e], DU_ACT_GELU);
+        for (int e = 0; e < W; e++) o[e] = apply_act(o[e], DU_ACT_GELU);
       } else if constexpr (ACT < 0) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) o[e] = apply_act(o[e], P.act);
+        for (int e = 0; e < W; e++) o[e] = apply_act(o[e], P.act);
       }
       if (P.gamma) {
-        const float4 gg = *(const float4*)(P.gamma + n);
-        o[0] *= gg.x; o[1] *= gg.y; o[2] *= gg.z; o[3] *= gg.w;
+#pragma unroll
+        for (int h = 0; h < W / 4; h++) {
+          const float4 gg = *(const float4*)(P.gamma + n + 4 * h);
+          o[4 * h] *= gg.x; o[4 * h + 1] *= gg.y; o[4 * h + 2] *= gg.z; o[4 * h + 3] *= gg.w;
+        }
       }
       if (P.row_scale) {
         const float rs = P.row_scale[m / P.rs_rows];
 #pragma unroll
-        for (int e = 0; e < 4; e++) o[e] *= rs;
+        for (int e = 0; e < W; e++) o[e] *= rs;
       }
 #pragma unroll
-      for (int e = 0; e < 4; e++) o[e] += rr[u][e];
-      Out4p<TC>::store(Cb + (long)m * P.ldc + n, o);
+      for (int e = 0; e < W; e++) o[e] += rr[u][e];
+      RowVec<TC, W>::store(Cb + out_offset(P, m, n, P.ldc), o);
     }
   }
 }
 template <typename TC, int TBN>
 __device__ __forceinline__ void readout_f32_any(const GemmParams& P, const float* stg, int ldf, int nrows, int mrow0, int n0, TC* Cb,
                                                 const TC* Rb, int tid) {
-  if (P.act == DU_ACT_NONE) readout_f32<TC, TBN, DU_ACT_NONE>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
-  else if (P.act == DU_ACT_GELU) readout_f32<TC, TBN, DU_ACT_GELU>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
-  else readout_f32<TC, TBN, -1>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
+  if constexpr (sizeof(TC) == 2) {
+    // 8 bf16 per item when every access is 16-byte aligned and an item cannot straddle N or a pixel-shuffle segment
+    const bool w8 = P.N % 8 == 0 && P.ldc % 8 == 0 && ((((uintptr_t)Cb) & 15) == 0) && (!Rb || (P.ldr % 8 == 0 && ((((uintptr_t)Rb) & 15) == 0))) &&
+                    (P.store_mode == DU_STORE_PLAIN || P.ps_C % 8 == 0);
+    if (w8) {
+      if (P.act == DU_ACT_NONE) readout_f32<TC, TBN, DU_ACT_NONE, 8>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
+      else readout_f32<TC, TBN, -1, 8>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
+      return;
+    }
+  }
+  if (P.act == DU_ACT_NONE) readout_f32<TC, TBN, DU_ACT_NONE, 4>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
+  else if (P.act == DU_ACT_GELU) readout_f32<TC, TBN, DU_ACT_GELU, 4>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
+  else readout_f32<TC, TBN, -1, 4>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
 }
 // bf16 result whose epilogue is bias (+ GELU) only: staged as bf16 (the ViT's qkv and fc1)
 __device__ __forceinline__ bool bf16_simple(const GemmParams& P, const void* Rb) {
@@ -419,7 +462,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
   TC* Cb = (TC*)P.C + (long)batch * P.cbs;
   const TC* Rb = (const TC*)P.residual;
   if (Rb) Rb += (long)batch * P.cbs;
-  if (P.ps_H & 2) return;            // measurement aid (du_set_option key 3): no epilogue at all
+  if (P.dbg & 2) return;            // measurement aid (du_set_option key 3): no epilogue at all
   bool done = false;
   if constexpr (sizeof(TC) == 2) {
     if (bf16_simple(P, Rb)) {        // the whole 256 x 256 tile staged as bf16, one pass
@@ -630,7 +673,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8n_kernel(GemmParams P) {
   TC* Cb = (TC*)P.C + (long)batch * P.cbs;
   const TC* Rb = (const TC*)P.residual;
   if (Rb) Rb += (long)batch * P.cbs;
-  if (P.ps_H & 2) return;
+  if (P.dbg & 2) return;
   bool done = false;
   if constexpr (sizeof(TC) == 2) {
     if (bf16_simple(P, Rb)) {
@@ -683,7 +726,7 @@ int launch_p8(const du_gemm_args& a, hipStream_t st) {
   GemmParams P = make_params(a, DU_PLAIN_ROW, DU_PLAIN_ROW, PBM, TBN, PBK);
   P.tiles_m = (a.M + PBM - 1) / PBM;
   P.group_m = g_p8_group;
-  P.ps_H = g_p8_debug;           // pixel-shuffle geometry is unused by these kernels (plain stores only)
+  P.dbg = g_p8_debug;
   dim3 grid(P.tiles_m * P.tiles_n, a.batch < 1 ? 1 : a.batch);
   void (*kfn)(GemmParams);
   if constexpr (NARROW) kfn = gemm_nt_p8n_kernel<TC, SCHED>; else kfn = gemm_nt_p8_kernel<TC, SCHED>;
@@ -715,7 +758,8 @@ extern "C" int du_set_option(int key, int value) {
 // true when the multi-phase kernels can run this product at all
 static bool p8_legal(const du_gemm_args& a) {
   if (a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.dtype != DU_BF16) return false;
-  if (a.store_mode != DU_STORE_PLAIN || a.split_k > 1) return false;
+  if (a.split_k > 1) return false;
+  if (a.store_mode != DU_STORE_PLAIN && (a.store_mode != DU_STORE_PIXEL_SHUFFLE2 || a.ps_C % 4 || a.act == DU_ACT_SWIGLU)) return false;
   if (a.K % 128 || a.K < 256 || a.M < 256 || a.N < 128 || a.N % 4) return false;
   if (a.lda % 8 || a.ldb % 8 || (((uintptr_t)a.A) & 15) || (((uintptr_t)a.B) & 15)) return false;
   if (a.a_batch_stride % 8 || a.b_batch_stride % 8) return false;

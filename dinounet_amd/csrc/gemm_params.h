@@ -23,7 +23,18 @@ struct GemmParams {
   int store_mode, ps_H, ps_W, ps_C;
   int tiles_n;
   int tiles_m, group_m;   // grouped tile order (gemm_glds.hip): bands of group_m tile rows are walked column by column; 0 = row-major
+  int dbg;                // measurement aids of gemm_p8.hip (du_set_option key 3); 0 in production
 };
+
+// element offset of C / residual element (m, n) for row stride ld: plain rows, or the pixel-shuffle store of ConvTranspose2d k2 s2
+// (column n = (dy*2+dx)*Cout + co of input pixel m = (b, y, x) -> output pixel (b, 2y+dy, 2x+dx), channel co)
+__device__ __forceinline__ long out_offset(const GemmParams& P, int m, int n, long ld) {
+  if (P.store_mode != DU_STORE_PIXEL_SHUFFLE2) return (long)m * ld + n;
+  const int q = n / P.ps_C, co = n - q * P.ps_C;
+  const int x = m % P.ps_W, t2 = m / P.ps_W, y = t2 % P.ps_H, b = t2 / P.ps_H;
+  const long opix = ((long)b * 2 * P.ps_H + 2 * y + (q >> 1)) * (2 * P.ps_W) + 2 * x + (q & 1);
+  return opix * ld + co;
+}
 
 __device__ __forceinline__ int div_small(int x, int d) {
   if (d == 3) return (x * 11) >> 5;  // exact for x < 32

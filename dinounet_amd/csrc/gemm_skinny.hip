@@ -16,12 +16,19 @@
 
 namespace {
 
+// epilogue of the single-slice (fused) form, by value in constant memory: the kernel-argument copy of it
+struct SkinnyEpi {
+  void* C; long ldc; const void* residual; long ldr;
+  const float* bias; const float* gamma; const float* row_scale;
+  float alpha; int act, rs_rows, out_bf16;
+};
+
 constexpr int SK_BN = 32;          // output columns per workgroup
 constexpr int SK_CHUNK = 64;       // contraction elements per wave step (4 MFMAs)
 
 __global__ __launch_bounds__(256) void gemm_skinny_partial_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                                   long ldb, float* __restrict__ part, int M, int N, int K,
-                                                                  int k_per_slice) {
+                                                                  int k_per_slice, SkinnyEpi P, int fused) {
   __shared__ float red[64][SK_BN + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * SK_BN;
@@ -66,6 +73,50 @@ __global__ __launch_bounds__(256) void gemm_skinny_partial_kernel(const bf16_t* 
       }
     }
     __syncthreads();
+  }
+  if (fused) {
+    // single K slice: the du_gemm epilogue right here (alpha, bias, act, gamma, row_scale, residual), no partial buffer, no second launch
+    for (int i = tid; i < 64 * (SK_BN / 4); i += 256) {
+      const int m = i / (SK_BN / 4), c = (i % (SK_BN / 4)) * 4;
+      const int n = n0 + c;
+      if (m >= M || n >= N) continue;
+      float o[4] = {red[m][c] * P.alpha, red[m][c + 1] * P.alpha, red[m][c + 2] * P.alpha, red[m][c + 3] * P.alpha};
+      if (P.bias) {
+        const float4 bb = *(const float4*)(P.bias + n);
+        o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
+      }
+      if (P.act != DU_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = apply_act(o[e], P.act);
+      }
+      if (P.gamma) {
+        const float4 gg = *(const float4*)(P.gamma + n);
+        o[0] *= gg.x; o[1] *= gg.y; o[2] *= gg.z; o[3] *= gg.w;
+      }
+      if (P.row_scale) {
+        const float rs = P.row_scale[m / P.rs_rows];
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] *= rs;
+      }
+      if (P.out_bf16) {
+        if (P.residual) {
+          const bf16_t* rp = (const bf16_t*)P.residual + (long)m * P.ldr + n;
+#pragma unroll
+          for (int e = 0; e < 4; e++) o[e] += (float)rp[e];
+        }
+        bf16x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; e++) t[e] = (bf16_t)o[e];
+        *(uint2*)((bf16_t*)P.C + (long)m * P.ldc + n) = __builtin_bit_cast(uint2, t);
+      } else {
+        if (P.residual) {
+          const float4 rr = *(const float4*)((const float*)P.residual + (long)m * P.ldr + n);
+          o[0] += rr.x; o[1] += rr.y; o[2] += rr.z; o[3] += rr.w;
+        }
+        *(float4*)((float*)P.C + (long)m * P.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    return;
   }
   float* dst = part + (long)blockIdx.y * 64 * N;
   for (int i = tid; i < 64 * SK_BN; i += 256) {
@@ -135,6 +186,17 @@ int du_gemm_skinny(const du_gemm_args& a, hipStream_t st) {
   if (a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.store_mode != DU_STORE_PLAIN) return DU_ERR_UNSUPPORTED;
   if (a.M < 1 || a.M > 64 || a.K % SK_CHUNK || a.N % 4 || a.batch > 1 || a.split_k > 1 || a.lda % 8 || a.ldb % 8) return DU_ERR_UNSUPPORTED;
   if ((((uintptr_t)a.A) | ((uintptr_t)a.B)) & 15) return DU_ERR_UNSUPPORTED;
+  SkinnyEpi E{};
+  E.C = a.C; E.ldc = a.ldc; E.residual = a.residual; E.ldr = a.ldr; E.bias = a.bias; E.gamma = a.gamma; E.row_scale = a.row_scale;
+  E.alpha = a.alpha; E.act = a.act; E.rs_rows = a.rs_rows > 0 ? a.rs_rows : 1; E.out_bf16 = a.out_dtype == DU_BF16;
+  static const bool no_fuse = getenv("DU_SKINNY_NO_FUSE") != nullptr;     // A-B aid
+  if (!no_fuse && a.K <= 8192) {
+    // one launch: every workgroup runs the whole contraction of its 32 columns (4 waves x K/4) and applies the epilogue itself.  The
+    // split-K pair below costs two launches + a partial round trip (12 us for 40 rows, 96 times per dinounet_l step)
+    hipLaunchKernelGGL(gemm_skinny_partial_kernel, dim3((a.N + SK_BN - 1) / SK_BN, 1), dim3(256), 0, st, (const bf16_t*)a.A, (long)a.lda,
+                       (const bf16_t*)a.B, (long)a.ldb, (float*)nullptr, a.M, a.N, a.K, a.K, E, 1);
+    return du_check_launch();
+  }
   const int slices = skinny_slices(a.N, a.K);
   if (!a.ws || a.ws_elems < (int64_t)slices * 64 * a.N) return DU_ERR_UNSUPPORTED;
   int kps = (a.K + slices - 1) / slices;
@@ -142,7 +204,7 @@ int du_gemm_skinny(const du_gemm_args& a, hipStream_t st) {
   const int used = (a.K + kps - 1) / kps;               // empty trailing slices are dropped
   dim3 grid((a.N + SK_BN - 1) / SK_BN, used);
   hipLaunchKernelGGL(gemm_skinny_partial_kernel, grid, dim3(256), 0, st, (const bf16_t*)a.A, (long)a.lda, (const bf16_t*)a.B, (long)a.ldb,
-                     a.ws, a.M, a.N, a.K, kps);
+                     a.ws, a.M, a.N, a.K, kps, E, 0);
   GemmParams P = make_params(a, DU_PLAIN_ROW, DU_PLAIN_ROW, 64, SK_BN, SK_CHUNK);
   const long total = (long)a.M * (a.N / 4);
   const int fg = (int)((total + 255) / 256);

@@ -321,6 +321,21 @@ def msda_cases():
         for n_, t in (("value", value), ("loc", loc), ("attn", aw), ("out", o), ("grad_out", go), ("grad_value", gv),
                       ("grad_loc", gl), ("grad_attn", ga)):
             out[f"D{D}_{n_}"] = t.detach().numpy()
+    # the wide channel counts of the reference's own gradcheck (ops/test.py:120: 1025, 2048, 3096), same fixture, stored as fp32
+    torch.manual_seed(4)
+    for D in [1025, 2048, 3096]:
+        value = (torch.rand(N, S, M, D) * 0.01).double().requires_grad_(True)
+        loc = torch.rand(N, Lq, M, L, P, 2).double().requires_grad_(True)
+        aw = torch.rand(N, Lq, M, L, P) + 1e-5
+        aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().requires_grad_(True)
+        o = core(value, shapes, loc, aw)
+        go = torch.rand(o.shape, dtype=torch.float64)
+        gv, gl, ga = torch.autograd.grad(o, (value, loc, aw), go)
+        o3 = O.msda_core(value.detach(), shapes.tolist(), loc.detach(), aw.detach())
+        assert (o3 - o.detach()).abs().max() < 1e-12
+        for n_, t in (("value", value), ("loc", loc), ("attn", aw), ("out", o), ("grad_out", go), ("grad_value", gv),
+                      ("grad_loc", gl), ("grad_attn", ga)):
+            out[f"D{D}_{n_}"] = t.detach().numpy().astype(np.float32)
     # out-of-range / border sampling: locations in [-0.3, 1.3] exercise every zero-padding branch (cuh:293, :60-84)
     torch.manual_seed(5)
     D = 8

@@ -352,7 +352,7 @@ def test_layernorm_fwd_bwd(dt, D):
 
 
 # ------------------------------------------------------------------------------------------------ MSDA
-@pytest.mark.parametrize("tag", ["D2", "D4", "D12", "D24", "D30", "D32", "D64", "D71", "D128", "border"])
+@pytest.mark.parametrize("tag", ["D2", "D4", "D12", "D24", "D30", "D32", "D64", "D71", "D128", "D1025", "D2048", "D3096", "border"])
 def test_msda_reference_fixture(tag):
     """ops/test.py fixture (seed 3) + out-of-range sampling: forward and all three gradients vs the reference's own fp64
     values (generated by oracle/make_golden.py from ms_deform_attn_core_pytorch), through the drop-in extension module."""
