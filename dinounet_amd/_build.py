@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdinounet_hip.so")
-SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_glds.hip", "gemm_p8.hip", "gemm_skinny.hip", "conv_halo.hip", "attention.hip", "norm.hip", "msda.hip", "elementwise.hip", "loss.hip", "optim.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_glds.hip", "gemm_p8.hip", "gemm_skinny.hip", "conv_halo.hip", "attention.hip", "norm.hip", "msda.hip", "elementwise.hip", "loss.hip", "optim.hip", "augment.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc"]
 # per-source extras.  attention.hip: MFMA results straight into VGPRs (the softmax reads every S^T accumulator with VALU ops; in the
 # accumulator half of the register file each one costs a v_accvgpr_read and a second register: 194 -> 166 registers, 2 -> 3 waves / SIMD)

@@ -291,6 +291,30 @@ int du_patchify16(int dst_dtype, const float* src, void* dst, int B, int C, int 
    Cp, n_out] (kinds: see elementwise.hip), bprefix: n+1 exclusive prefix sums of ceil(n_out / 4096) = workgroups per row. */
 int du_pack_weights(const int64_t* table, const int64_t* bprefix, int n, int64_t nblocks, void* stream);
 
+/* ---- GPU-side training augmentation for 2D slices: the transforms of nnUNetTrainer.get_training_transforms
+   (dinounet/training/nnUNetTrainer/nnUNetTrainer.py:684-776; the reference delegates them to the un-vendored `batchgenerators` package:
+   parity unpinned, algorithms restated from the package, see csrc/augment.hip).  All tensors NCHW fp32 on the device; a "plane" is one
+   (sample, channel) image of n = H * W elements; per-plane parameter arrays live on the device. -------------------------------------- */
+/* SpatialTransform (rotation + isotropic scale + centre crop) and MirrorTransform in one resampling pass.  params (B, 6) =
+   [m00, m01, m10, m11, flip_y, flip_x]: input coordinate = input centre + M (output coordinate - output centre), M = scale * R(angle).
+   data (B,C,Hi,Wi) -> data_out (B,C,Ho,Wo) bicubic, zero outside; seg (B,1,Hi,Wi) (nullable) -> seg_out by the order-1 label rule. */
+int du_aug_spatial(const float* data, const float* seg, const float* params, float* data_out, float* seg_out, int B, int C, int Hi, int Wi,
+                   int Ho, int Wo, void* stream);
+/* stats (planes, 4) = mean, population std, min, max of every plane (n % 4 == 0) */
+int du_aug_plane_stats(const float* x, float* stats, int planes, int64_t n, void* stream);
+/* GaussianNoiseTransform + BrightnessMultiplicativeTransform: x = (x + sigma[p] * N(0,1)) * mult[p]   (sigma 0 / mult 1 = off) */
+int du_aug_noise_mult(float* x, const float* sigma, const float* mult, int planes, int64_t n, int seed, void* stream);
+/* ContrastAugmentationTransform (preserve_range): x = clip((x - mean) * factor[p] + mean, min, max), stats of the current contents */
+int du_aug_contrast(float* x, const float* factor, const float* stats, int planes, int64_t n, void* stream);
+/* GammaTransform body on x (or on -x where invert[p] != 0): ((v - min) / (range + 1e-7))^gamma[p] * range + min; gamma <= 0 = off.
+   retain_stats and the final negation are a du_aug_plane_stats + du_aug_affine pair */
+int du_aug_gamma(float* x, const float* gamma, const float* invert, const float* stats, int planes, int64_t n, void* stream);
+int du_aug_affine(float* x, const float* a, const float* b, int planes, int64_t n, void* stream);
+/* GaussianBlurTransform: one separable pass along axis 0 (y) / 1 (x), radius int(4 sigma + 0.5), reflect borders; sigma[p] <= 0 copies */
+int du_aug_blur(const float* x, float* y, const float* sigma, int planes, int H, int W, int axis, void* stream);
+/* SimulateLowResolutionTransform: nearest-neighbour down to round(size * zoom[p]), cubic back up; zoom outside (0, 1) copies */
+int du_aug_lowres(const float* x, float* y, const float* zoom, int planes, int H, int W, void* stream);
+
 /* library self-description */
 const char* du_version(void);
 int du_device_ok(void); /* 1 if the current device is gfx950 */
