@@ -112,42 +112,47 @@ class GPUAugment2D:
         seg = None if seg is None else seg.contiguous().float()
         out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=dev)
         sout = None if seg is None else torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
-        _lib.check(L.du_aug_spatial(_p(data), _p(seg), _p(dv(d["spatial"])), _p(out), _p(sout), B, Cc, Hi, Wi, H, W, _st()), "du_aug_spatial")
+        # every parameter array is a named device tensor that outlives its launch (a temporary handed to ctypes as a raw pointer would be
+        # freed -- and its block re-used by the next upload -- before the kernel is even enqueued)
+        ones = np.ones((B, Cc), np.float32)
+        t_sp, t_noise, t_one, t_zero = dv(d["spatial"]), dv(d["noise_sigma"]), dv(ones), dv(0 * ones)
+        t_blur, t_mult, t_con, t_zoom = dv(d["blur_sigma"]), dv(d["mult"]), dv(d["contrast"]), dv(d["zoom"])
+        _lib.check(L.du_aug_spatial(_p(data), _p(seg), _p(t_sp), _p(out), _p(sout), B, Cc, Hi, Wi, H, W, _st()), "du_aug_spatial")
         P, n = B * Cc, H * W
         tmp = torch.empty_like(out)
         stats = torch.empty((P, 4), dtype=torch.float32, device=dev)
-        ones = np.ones((B, Cc), np.float32)
         # GaussianNoise (before blur and brightness in the reference order; the multiplier pass comes after the blur)
-        _lib.check(L.du_aug_noise_mult(_p(out), _p(dv(d["noise_sigma"])), _p(dv(ones)), P, n, d["seed"], _st()), "du_aug_noise_mult")
+        _lib.check(L.du_aug_noise_mult(_p(out), _p(t_noise), _p(t_one), P, n, d["seed"], _st()), "du_aug_noise_mult")
         if (d["blur_sigma"] > 0).any():
-            sg = dv(d["blur_sigma"])
-            _lib.check(L.du_aug_blur(_p(out), _p(tmp), _p(sg), P, H, W, 0, _st()), "du_aug_blur")
-            _lib.check(L.du_aug_blur(_p(tmp), _p(out), _p(sg), P, H, W, 1, _st()), "du_aug_blur")
-        _lib.check(L.du_aug_noise_mult(_p(out), _p(dv(0 * ones)), _p(dv(d["mult"])), P, n, 0, _st()), "du_aug_noise_mult")
+            _lib.check(L.du_aug_blur(_p(out), _p(tmp), _p(t_blur), P, H, W, 0, _st()), "du_aug_blur")
+            _lib.check(L.du_aug_blur(_p(tmp), _p(out), _p(t_blur), P, H, W, 1, _st()), "du_aug_blur")
+        _lib.check(L.du_aug_noise_mult(_p(out), _p(t_zero), _p(t_mult), P, n, 0, _st()), "du_aug_noise_mult")
         if (d["contrast"] != 1).any():
             _lib.check(L.du_aug_plane_stats(_p(out), _p(stats), P, n, _st()), "du_aug_plane_stats")
-            _lib.check(L.du_aug_contrast(_p(out), _p(dv(d["contrast"])), _p(stats), P, n, _st()), "du_aug_contrast")
+            _lib.check(L.du_aug_contrast(_p(out), _p(t_con), _p(stats), P, n, _st()), "du_aug_contrast")
         if ((d["zoom"] > 0) & (d["zoom"] < 1)).any():
-            _lib.check(L.du_aug_lowres(_p(out), _p(tmp), _p(dv(d["zoom"])), P, H, W, _st()), "du_aug_lowres")
+            _lib.check(L.du_aug_lowres(_p(out), _p(tmp), _p(t_zoom), P, H, W, _st()), "du_aug_lowres")
             out, tmp = tmp, out
+        keep = []
         for key, inv in (("gamma_inv", 1.0), ("gamma", 0.0)):
             g = d[key]
             if not (g > 0).any():
                 continue
             on = (g > 0).astype(np.float32)
+            t_g, t_inv, onv = dv(g), dv(on * inv), dv(on).view(-1)
             _lib.check(L.du_aug_plane_stats(_p(out), _p(stats), P, n, _st()), "du_aug_plane_stats")       # mean / std to retain, range
             before = stats.clone()
-            _lib.check(L.du_aug_gamma(_p(out), _p(dv(g)), _p(dv(on * inv)), _p(stats), P, n, _st()), "du_aug_gamma")
+            _lib.check(L.du_aug_gamma(_p(out), _p(t_g), _p(t_inv), _p(stats), P, n, _st()), "du_aug_gamma")
             _lib.check(L.du_aug_plane_stats(_p(out), _p(stats), P, n, _st()), "du_aug_plane_stats")
             # retain_stats on the (possibly negated) image: x = (x - mean') / (std' + 1e-8) * std + mean, then negate back
-            sgn = 1.0 - 2.0 * dv(on * inv).view(-1)
+            sgn = 1.0 - 2.0 * t_inv.view(-1)
             mean_b, std_b = before[:, 0] * sgn, before[:, 1]
             a = std_b / (stats[:, 1] + 1e-8)
             bb = mean_b - stats[:, 0] * a
-            onv = dv(on).view(-1)
-            a = (a * sgn) * onv + (1 - onv)
-            bb = (bb * sgn) * onv
-            _lib.check(L.du_aug_affine(_p(out), _p(a.contiguous()), _p(bb.contiguous()), P, n, _st()), "du_aug_affine")
+            a = ((a * sgn) * onv + (1 - onv)).contiguous()
+            bb = ((bb * sgn) * onv).contiguous()
+            _lib.check(L.du_aug_affine(_p(out), _p(a), _p(bb), P, n, _st()), "du_aug_affine")
+            keep += [t_g, t_inv, onv, a, bb, before]
         return out, sout
 
     def __call__(self, data, seg=None):
