@@ -8,8 +8,9 @@
 // batchgenerators calls scipy.ndimage.map_coordinates(order=3) (cubic B-spline with prefilter); the two agree to O(h^3) on smooth data.
 //
 //   du_aug_spatial      SpatialTransform (rotation, isotropic scale, centre crop) + MirrorTransform folded into one resampling pass;
-//                       labels follow batchgenerators' order-1 rule (per label: bilinear weight of its one-hot map >= 0.5, ascending
-//                       labels overwrite, out-of-image counts for nobody => 0 after RemoveLabelTransform(-1, 0))
+//                       labels follow batchgenerators' order-1 rule (per label: bilinear interpolation of its one-hot map >= 0.5 with
+//                       cval -1 outside the image, ascending labels overwrite; pixels no label claims are 0, which is also what
+//                       RemoveLabelTransform(-1, 0) leaves)
 //   du_aug_plane_stats  per (sample, channel) plane: mean, std (population), min, max
 //   du_aug_noise_mult   GaussianNoiseTransform (x + N(0, var)) then BrightnessMultiplicativeTransform (x * m)
 //   du_aug_contrast     ContrastAugmentationTransform, preserve_range: clip((x - mean) * f + mean, min, max)
@@ -75,10 +76,13 @@ __global__ __launch_bounds__(256) void aug_spatial_kernel(const float* __restric
         lab[k] = (yy >= 0 && yy < Hi && xx >= 0 && xx < Wi) ? sp[(long)yy * Wi + xx] : -1.f;
       }
       float best = 0.f;        // result starts at 0; labels are visited in ascending order and overwrite
+      float wout = 0.f;        // a neighbour outside the image reads cval = -1 in EVERY one-hot map: it counts against each label
+#pragma unroll
+      for (int j = 0; j < 4; j++) wout += lab[j] < 0.f ? w[j] : 0.f;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         if (lab[k] < 0.f) continue;
-        float s = 0.f;
+        float s = -wout;
 #pragma unroll
         for (int j = 0; j < 4; j++) s += (lab[j] == lab[k]) ? w[j] : 0.f;
         if (s >= 0.5f && lab[k] > best) best = lab[k];

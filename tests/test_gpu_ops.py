@@ -779,7 +779,9 @@ def test_augmentation_kernels_vs_numpy_restatement():
     out, sout = aug.apply(data.to(d), seg.to(d), dict(off, spatial=prm))
     ro, rs = AO.spatial(data.numpy(), seg.numpy(), prm, (H, W))
     assert rel(out, torch.from_numpy(ro).float()) < 1e-4
-    assert float((sout.cpu() != torch.from_numpy(rs).float()).float().mean()) < 2e-3      # exact 0.5 ties may round either way
+    mism = float((sout.cpu() != torch.from_numpy(rs).float()).float().mean())
+    print(f"label resampling: {mism:.2e} of the pixels differ from the scipy restatement (fp32 vs fp64 coordinates at exact 0.5 ties)")
+    assert mism < 2e-3
     dev3 = float(np.abs(out.cpu().numpy() - AO.spatial_scipy_order3(smooth.numpy(), prm, (H, W))).max())   # vs the B-spline batchgenerators uses
     print(f"Keys bicubic (ours, noisy input) vs scipy order-3 spline (batchgenerators, noise-free input): max abs diff {dev3:.3f} on data of amplitude 1")
     ident = np.tile(np.array([1, 0, 0, 1, 0, 0], np.float32), (B, 1))
