@@ -49,6 +49,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {s}")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     subprocess.check_call(cmd)
+    # a kernel whose host stub the compiler dropped (seen once: a helper-lambda call inside an LDS-DMA builtin's arguments) links as an
+    # undefined file-local symbol and only fails at dlopen on the GPU box: catch it here
+    und = subprocess.run(["nm", "-D", "--undefined-only", LIB], capture_output=True, text=True).stdout
+    bad = [ln.split()[-1] for ln in und.splitlines() if "_GLOBAL__N_" in ln]
+    if bad:
+        os.remove(LIB)
+        raise RuntimeError("undefined file-local symbols in libdinounet_hip.so (dropped kernel stubs?): " + ", ".join(bad[:4]))
     open(stamp, "w").write(dig)
     return LIB
 

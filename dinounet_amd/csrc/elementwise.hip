@@ -904,6 +904,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const int64_t* __rest
   }
   for (int e = e0 + threadIdx.x; e < e1; e += 256) {
     float v;
+    long d = e;            // destination element
     switch (kind) {
       case 1: { const int co = e / (T * Cp); const int rr = e - co * (T * Cp); const int t = rr / Cp, ci = rr - t * Cp;
                 v = ci < B ? src[((long)co * B + ci) * T + t] : 0.f; break; }
@@ -914,10 +915,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const int64_t* __rest
                 v = src[((long)ci * B + co) * 4 + q]; break; }
       case 5: { const int ci = e / (4 * B); const int rr = e - ci * (4 * B); const int q = rr / B, co = rr - q * B;
                 v = src[((long)ci * B + co) * 4 + q]; break; }
-      case 6: { const int k = e / A; const int nn = e - k * A; v = src[(long)nn * B + k]; break; }   // TRANSPOSE: src (A, B) -> dst (B, A)
+      // TRANSPOSE: src (A, B) -> dst (B, A); T > 0: dst is a column block of a wider (B, T) matrix (transposed row-concatenation)
+      case 6: { const int k = e / A; const int nn = e - k * A; v = src[(long)nn * B + k]; if (T > 0) d = (long)k * T + nn; break; }
       default: v = src[e];
     }
-    if (f32) df[e] = v; else db[e] = (bf16_t)v;
+    if (f32) df[d] = v; else db[d] = (bf16_t)v;
   }
 }
 }  // namespace

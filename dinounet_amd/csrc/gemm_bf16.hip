@@ -371,6 +371,8 @@ int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st);     // gemm_p8.hip
 bool du_gemm_p8_wants(const du_gemm_args& a);
 int du_gemm_p8_choice(const du_gemm_args& a);
 bool du_gemm_glds_serves(const du_gemm_args& a);              // gemm_glds.hip
+int du_gemm_tn_p8(const du_gemm_args& a, hipStream_t st);     // gemm_p8.hip (weight gradients)
+int du_gemm_tn_p8_splits(const du_gemm_args& a);
 
 // Rows of a tall bf16 NT product that should leave the tile grid for the K-parallel skinny kernels (gemm_skinny.hip).
 //  * products served by the 256 x 256 multi-phase kernel (gemm_p8.hip): r = M % 256 when 0 < r <= 64 (the ViT: M = 8 * 1029 =
@@ -424,6 +426,10 @@ int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
   if (a.residual && (a.ldr % 4 || (((uintptr_t)a.residual) & 15))) return DU_ERR_UNSUPPORTED;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && a.ps_C % 4) return DU_ERR_UNSUPPORTED;
   if (a.c_batch_stride % 4) return DU_ERR_UNSUPPORTED;
+  if (a.a_mode == DU_PLAIN_COL && (a.b_mode == DU_PLAIN_COL || a.b_mode == DU_IM2COL_COL)) {     // weight gradients: the multi-phase kernel where it is legal
+    int rc = du_gemm_tn_p8(a, st);
+    if (rc != DU_ERR_UNSUPPORTED) return rc;
+  }
   {
     const int r = du_gemm_ragged_rows(a);
     if (r > 0 && a.ws && a.ws_elems >= du_gemm_skinny_ws_elems(a.N, a.K)) {
@@ -459,10 +465,11 @@ int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
 
 // which kernel family du_gemm runs for the bulk of this product (measurement tools name the kernel from this, not from a mirror of the
 // dispatch): 0 generic (gemm.hip), 1 bf16 tile engine (this file), 2 128 x 128 direct-to-LDS (gemm_glds.hip), 3 / 4 the 256 x 256 /
-// 256 x 128 multi-phase kernels (gemm_p8.hip)
+// 256 x 128 multi-phase kernels (gemm_p8.hip), 5 the multi-phase weight-gradient kernel (gemm_p8.hip, TN form)
 int du_gemm_route_bf16(const du_gemm_args& a) {
   if (a.dtype != DU_BF16) return 0;
   if (a.N % 4 || a.ldc % 4 || (((uintptr_t)a.C) & 15)) return 0;
+  if (a.a_mode == DU_PLAIN_COL && du_gemm_tn_p8_splits(a)) return 5;
   du_gemm_args head = a;
   const int r = du_gemm_ragged_rows(a);
   if (r > 0) head.M = a.M - r;

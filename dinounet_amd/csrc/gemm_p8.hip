@@ -287,29 +287,88 @@ constexpr int P8_STG_LDB = PBN + 8;            // bf16 staging row, elements (52
 constexpr int P8_STG_LDF = PBN + 4;            // fp32 staging row, floats (1040 B: conflict-free ds_write_b128)
 constexpr int P8_LDS = 256 * P8_STG_LDB * 2;   // 135 168 B >= 2 * BUF_B and >= 128 * P8_STG_LDF * 4
 
-template <typename TC, int SCHED>
+// GA ("gather"): the ConvTranspose2d k2 s2 backward products read their im2col operand in place -- NT: A(m = input pixel, k = (tap, co)) =
+// dy[out pixel (2y + tap/2, 2x + tap%2)][co] (data gradient); TN: B(k = input pixel, n = (tap, co)) likewise (weight gradient).
+template <typename TC, int SCHED, bool TN, bool GA>
 __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   int tm, tn;
-  tile_coords(P, tm, tn);
+  int nk = P.K / PBK;
+  long kbeg = 0;                      // TN: first contraction row of this workgroup's split
+  if constexpr (TN) {
+    // workgroup -> (split, tile): the XCD-contiguous linear index walks the tiles of one split before the next split, so the
+    // workgroups that share a K range (and with it the A / B panels) sit on one XCD's L2
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int ntiles = P.tiles_m * P.tiles_n;
+    const int split = lin / ntiles, tile = lin - split * ntiles;
+    tm = tile / P.tiles_n; tn = tile - tm * P.tiles_n;
+    // K-tile PAIRS (128 contraction rows) are dealt out evenly: the first `extra` splits take one more
+    const int npairs = P.K / (2 * PBK), base = npairs / P.split_k, extra = npairs - base * P.split_k;
+    const int first = split * base + min(split, extra);
+    kbeg = (long)first * (2 * PBK);
+    nk = 2 * (base + (split < extra ? 1 : 0));
+  } else {
+    tile_coords(P, tm, tn);
+  }
   const int m0 = tm * PBM, n0 = tn * PBN;
   const int batch = blockIdx.y;
 
-  // ---- buffer descriptors based at the tile's first row; rows past the matrix fail the bounds check and load zeros ----
-  const bf16_t* Ab = (const bf16_t*)P.a.p + (long)batch * P.a.bstride + (long)m0 * P.a.ld;
-  const bf16_t* Bb = (const bf16_t*)P.b.p + (long)batch * P.b.bstride + (long)n0 * P.b.ld;
-  long abytes = ((long)(P.M - m0) * P.a.ld - (P.a.ld - P.K)) * 2, bbytes = ((long)(P.N - n0) * P.b.ld - (P.b.ld - P.K)) * 2;
+  // ---- buffer descriptors based at the tile's first row (TN: first contraction row + first tile column); reads past the matrix fail
+  // the bounds check and load zeros ----
+  const bf16_t *Ab, *Bb;
+  long abytes, bbytes;
+  if constexpr (TN) {
+    Ab = (const bf16_t*)P.a.p + (long)batch * P.a.bstride + kbeg * P.a.ld + m0;
+    abytes = ((P.K - kbeg - 1) * P.a.ld + (P.M - m0)) * 2;
+    if constexpr (GA) {       // the whole tile lies in one tap (C % 256 == 0): base = the tap's pixel offset + first channel
+      const int tapn = n0 / P.b.C, co0 = n0 - tapn * P.b.C;
+      const long off = ((long)(tapn >> 1) * P.b.Wi + (tapn & 1)) * P.b.ld + co0;
+      Bb = (const bf16_t*)P.b.p + off;
+      bbytes = ((long)(P.K / (P.b.Ho * P.b.Wo)) * P.b.Hi * P.b.Wi * P.b.ld - off) * 2;
+    } else {
+      Bb = (const bf16_t*)P.b.p + (long)batch * P.b.bstride + kbeg * P.b.ld + n0;
+      bbytes = ((P.K - kbeg - 1) * P.b.ld + (P.N - n0)) * 2;
+    }
+  } else {
+    if constexpr (GA) {
+      Ab = (const bf16_t*)P.a.p;
+      abytes = (long)(P.M / (P.a.Ho * P.a.Wo)) * P.a.Hi * P.a.Wi * P.a.ld * 2;
+    } else {
+      Ab = (const bf16_t*)P.a.p + (long)batch * P.a.bstride + (long)m0 * P.a.ld;
+      abytes = ((long)(P.M - m0) * P.a.ld - (P.a.ld - P.K)) * 2;
+    }
+    Bb = (const bf16_t*)P.b.p + (long)batch * P.b.bstride + (long)n0 * P.b.ld;
+    bbytes = ((long)(P.N - n0) * P.b.ld - (P.b.ld - P.K)) * 2;
+  }
   if (abytes > 0x7fffffffL) abytes = 0x7fffffffL;
   if (bbytes > 0x7fffffffL) bbytes = 0x7fffffffL;
   const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)abytes, 0x00020000);
   const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)bbytes, 0x00020000);
 
-  // staging: piece (round r, wave w) of a half = its rows (r*8 + w)*8 .. +8 (1 KB, lane l -> row + l/8, physical chunk l%8)
+  // staging: piece (round r, wave w) of a half is 1 KB of its LDS image.
+  //   NT: tile rows (r*8 + w)*8 .. +8, lane l -> row + l/8, physical 16-byte chunk l%8 of the 128-byte row
+  //   TN: the half is [64 contraction rows][128 outer elements] (256-byte rows); the piece = contraction rows (r*8 + w)*4 .. +4,
+  //       lane l -> row + l/16, physical chunk l%16.  Logical chunk = physical ^ 4*(row & 3): the four rows a transpose read touches
+  //       then sit on four different 64-byte bank groups (256-byte rows would otherwise all start on bank 0)
   unsigned va[2][2], vb[2][2];
-  {
+  unsigned kstep_a = PBK * 2, kstep_b = PBK * 2;       // bytes from one K-tile to the next (buffer soffset)
+  if constexpr (TN) {
+    kstep_a = (unsigned)(P.a.ld * 2 * PBK); kstep_b = (unsigned)(P.b.ld * 2 * PBK);
+    const int r4 = lane >> 4, lc = (lane & 15) ^ (4 * r4);
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const int krow = (r * 8 + wave) * 4 + r4;
+        va[h][r] = (unsigned)krow * (unsigned)(P.a.ld * 2) + (h * 128 + lc * 8) * 2;
+        vb[h][r] = (unsigned)krow * (unsigned)(P.b.ld * 2) + (h * 128 + lc * 8) * 2;
+      }
+  } else {
     const int sw = ((wave & 1) << 2) | (lane >> 4);          // ((row >> 1) & 7) of this lane's row
     const int lc = (lane & 7) ^ sw;                          // logical k chunk stored at this lane's physical chunk
 #pragma unroll
@@ -317,30 +376,88 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         const int row = h * 128 + (r * 8 + wave) * 8 + (lane >> 3);
-        va[h][r] = (unsigned)row * (unsigned)(P.a.ld * 2) + lc * 16;
+        if constexpr (GA) {      // row = input pixel (b, y, x) -> byte offset of output pixel (b, 2y, 2x); rows past M re-read row M - 1
+          const int m = min(m0 + row, P.M - 1);
+          const int xo = m % P.a.Wo, t2 = m / P.a.Wo, yo = t2 % P.a.Ho, bb = t2 / P.a.Ho;
+          va[h][r] = (unsigned)(((bb * P.a.Hi + 2 * yo) * P.a.Wi + 2 * xo)) * (unsigned)(P.a.ld * 2) + lc * 16;
+        } else {
+          va[h][r] = (unsigned)row * (unsigned)(P.a.ld * 2) + lc * 16;
+        }
         vb[h][r] = (unsigned)row * (unsigned)(P.b.ld * 2) + lc * 16;
       }
   }
+  // TN gather: contraction row = input pixel; with Wo a power of two, pixel p = (yy, x) reads output pixel (2 yy, 2 x) (+ the tap offset
+  // folded into the descriptor base), yy = b * Ho + y
+  int logW = 0;
+  if constexpr (GA && TN) logW = __builtin_ctz(P.b.Wo);
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
   // which: 0 = A-half0, 1 = A-half1, 2 = B-half0, 3 = B-half1 of K-tile kt, into buffer buf
   auto stage = [&](auto which_c, auto buf_c, int kt) {
     constexpr int which = decltype(which_c)::value, buf = decltype(buf_c)::value;
     constexpr int h = which & 1;
+    // buffer soffset of K-tile kt.  NT gather: K runs over (tap, co); a K-tile lies inside one tap (C % 64 == 0, C a power of two).
+    // (plain statements, not a helper lambda: a lambda call inside the LDS-DMA builtin's argument list makes the HOST pass drop the
+    // kernel's stub without a diagnostic -- the library then fails to load with an undefined symbol)
+    unsigned soff = kt * (which < 2 ? kstep_a : kstep_b);
+    if constexpr (GA && !TN && which < 2) {
+      const int k = kt * PBK, tap = k >> P.a.logC, within = k - (tap << P.a.logC);
+      soff = (unsigned)((((tap >> 1) * P.a.Wi + (tap & 1)) * (int)P.a.ld + within) * 2);
+    }
+    if constexpr (GA && TN && which >= 2) soff = 0;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
+      unsigned voff = which < 2 ? va[h][r] : vb[h][r];
+      if constexpr (GA && TN && which >= 2) {
+        const int r4 = lane >> 4, lc = (lane & 15) ^ (4 * r4);
+        const int krow = (int)kbeg + kt * PBK + (r * 8 + wave) * 4 + r4;
+        const int yy = krow >> logW, x = krow & (P.b.Wo - 1);
+        voff = (unsigned)(2 * yy * P.b.Wi + 2 * x) * (unsigned)(P.b.ld * 2) + (h * 128 + lc * 8) * 2;
+      }
       unsigned char* dst = smem + buf * BUF_B + which * HALF_B + (r * 8 + wave) * 1024;
-      if constexpr (which < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, va[h][r], kt * (PBK * 2), 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)dst, 16, vb[h][r], kt * (PBK * 2), 0, 0);
+      if constexpr (TN) {
+        // inline asm: the compiler orders every ds_read_b64_tr_b16 behind ALL LDS-DMA it knows of (s_waitcnt vmcnt(0) in front of each
+        // phase's reads, which drains the ring); unseen, the counted waits below are the only ordering.  M0 saved / restored inside.
+        const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_base + buf * BUF_B + which * HALF_B + (r * 8 + wave) * 1024);
+        unsigned keep;
+        const auto srd = which < 2 ? ra : rb;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(lds_dst) : "memory");
+      } else {
+        if constexpr (which < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, voff, soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)dst, 16, voff, soff, 0, 0);
+      }
     }
   };
 
-  // fragment addresses: row (lane & 31) of a 32-row block, logical chunk kk*2 + (lane >> 5), physical = logical ^ ((row >> 1) & 7)
+  // fragment addresses.
+  //   NT: row (lane & 31) of a 32-row block, logical chunk kk*2 + (lane >> 5), physical = logical ^ ((row >> 1) & 7)
+  //   TN: ds_read_b64_tr_b16 pairs.  Lane (g = lane >> 4, p = lane & 15) reads 8 bytes of contraction row kk*16 + 8 (g >> 1) + (p >> 2)
+  //       (+ 4 for the second read) at outer element i0 + 16 (g & 1) + 4 (p & 3) and receives outer i0 + (lane & 31), contraction
+  //       kk*16 + 8 (lane >> 5) + 0..7 -- the same fragment as the NT ds_read_b128.  LT[x] = the lane's offset inside a half for the
+  //       32-outer block x (0..3) at kk = 0, first read; + kk * 4096 + 1024 * second
   int L[4];
-  {
+  int LT[3];                                               // TN: A row blocks b = 0, 1 and the B block
+  const int aoff = wm * 64 * 128, boff = wn * 32 * 128;    // NT only
+  if constexpr (TN) {
+    const int g = lane >> 4, p = lane & 15, r4 = p >> 2;
+    const int common = (g >> 1) * 2048 + r4 * 256 + (2 * (g & 1) + ((p >> 1) & 1)) * 16 + (p & 1) * 8;
+    LT[0] = common + (((wm * 2 + 0) ^ r4) << 6);
+    LT[1] = common + (((wm * 2 + 1) ^ r4) << 6);
+    LT[2] = common + ((wn ^ r4) << 6);
+  } else {
     const int x = (lane >> 5) ^ ((lane >> 1) & 7);
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) L[kk] = (lane & 31) * 128 + ((x ^ (2 * kk)) << 4);
   }
-  const int aoff = wm * 64 * 128, boff = wn * 32 * 128;
+  auto tr_frag = [&](const unsigned char* q) -> bf16x8 {
+    typedef short s16x4_t __attribute__((ext_vector_type(4)));
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) s16x4_t lds_v4;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)q);
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(q + 1024));
+    s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
 
   bf16x8 Af[2][2][4];     // [set = A half][row block][kk]
   bf16x8 Bf[2][4];        // [set][kk]
@@ -359,22 +476,30 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
 #pragma unroll
     for (int b = 0; b < 2; b++)
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++)
-        Af[set][b][kk] = *(const bf16x8*)(smem + buf * BUF_B + set * HALF_B + aoff + b * 4096 + L[kk]);
+      for (int kk = 0; kk < 4; kk++) {
+        if constexpr (TN) Af[set][b][kk] = tr_frag(smem + buf * BUF_B + set * HALF_B + kk * 4096 + LT[b]);
+        else Af[set][b][kk] = *(const bf16x8*)(smem + buf * BUF_B + set * HALF_B + aoff + b * 4096 + L[kk]);
+      }
   };
   auto readB = [&](auto set_c, auto half_c, auto buf_c) {    // B-half `half` of buffer `buf` -> Bf[set]
     constexpr int set = decltype(set_c)::value, half = decltype(half_c)::value, buf = decltype(buf_c)::value;
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++)
-      Bf[set][kk] = *(const bf16x8*)(smem + buf * BUF_B + (2 + half) * HALF_B + boff + L[kk]);
+    for (int kk = 0; kk < 4; kk++) {
+      if constexpr (TN) Bf[set][kk] = tr_frag(smem + buf * BUF_B + (2 + half) * HALF_B + kk * 4096 + LT[2]);
+      else Bf[set][kk] = *(const bf16x8*)(smem + buf * BUF_B + (2 + half) * HALF_B + boff + L[kk]);
+    }
   };
   auto mma = [&](auto i_c, auto j_c, auto bset_c) {
     constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value, bset = decltype(bset_c)::value;
 #pragma unroll
     for (int kk = 0; kk < 4; kk++)
 #pragma unroll
-      for (int b = 0; b < 2; b++)
-        acc[i][j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[bset][kk], Af[i][b][kk], acc[i][j][b], 0, 0, 0);
+      for (int b = 0; b < 2; b++) {
+        // NT: (B, A) operand order = transposed accumulators for the row-contiguous staged epilogue; TN: (A, B), lanes 0..31 = 32
+        // consecutive output columns for the split-K atomics
+        if constexpr (TN) acc[i][j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[i][b][kk], Bf[bset][kk], acc[i][j][b], 0, 0, 0);
+        else acc[i][j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[bset][kk], Af[i][b][kk], acc[i][j][b], 0, 0, 0);
+      }
   };
   // pin the issue order of a phase.  The compiler orders every ds_read of the phase before its LDS-DMA issues (it must assume they
   // alias), so the reads ride behind the first four MFMAs and the two DMA issues behind the next two.
@@ -384,13 +509,11 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
 #pragma unroll
       for (int m = 0; m < 8; m++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // 1 MFMA
-        if (m < 4) __builtin_amdgcn_sched_group_barrier(0x100, nrd / 4, 0);       // 1 or 2 DS reads
+        if (m < 4) __builtin_amdgcn_sched_group_barrier(0x100, (TN ? 2 : 1) * nrd / 4, 0);   // 1 or 2 ds_read_b128 (TN: tr_b64 pairs)
         if (m == 4 || m == 5) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 VMEM (LDS-DMA)
       }
     }
   };
-
-  const int nk = P.K / PBK;
 
   // one K-tile: PAR = t & 1 (compile time), TAIL = runtime guards + exact vmcnt for the last four tiles
   auto ktile = [&](auto par_c, auto tail_c, int t) {
@@ -463,6 +586,26 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
   const TC* Rb = (const TC*)P.residual;
   if (Rb) Rb += (long)batch * P.cbs;
   if (P.dbg & 2) return;            // measurement aid (du_set_option key 3): no epilogue at all
+  if constexpr (TN) {
+    // split-K partial: fp32 atomics into the (zeroed) result.  Register r of a 32 x 32 block = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5),
+    // lanes 0..31 = 32 consecutive columns (one 128-byte segment per row)
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int n = n0 + j * 128 + wn * 32 + (lane & 31);
+      if (n >= P.N) continue;
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int m = m0 + i * 128 + wm * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (m < P.M) atomic_add_f32((float*)Cb + (long)m * P.ldc + n, acc[i][j][b][r] * P.alpha);
+          }
+    }
+    return;
+  }
   bool done = false;
   if constexpr (sizeof(TC) == 2) {
     if (bf16_simple(P, Rb)) {        // the whole 256 x 256 tile staged as bf16, one pass
@@ -719,23 +862,45 @@ int g_p8_sched = 1;
 int g_p8_group = 4;
 int g_p8_debug = 0;      // bit 0: skip the bf16 global stores, bit 1: skip the whole epilogue (timing ablations only)
 
-template <typename TC, int SCHED, bool NARROW>
+template <typename TC, int SCHED, bool NARROW, bool GA = false>
 int launch_p8(const du_gemm_args& a, hipStream_t st) {
+  static_assert(!(NARROW && GA), "the gather form exists for the 256 x 256 kernel only");
   constexpr int LDS_BYTES = NARROW ? P8N_LDS : P8_LDS;
   constexpr int TBN = NARROW ? NBN : PBN;
-  GemmParams P = make_params(a, DU_PLAIN_ROW, DU_PLAIN_ROW, PBM, TBN, PBK);
+  GemmParams P = make_params(a, GA ? DU_IM2COL_ROW : DU_PLAIN_ROW, DU_PLAIN_ROW, PBM, TBN, PBK);
   P.tiles_m = (a.M + PBM - 1) / PBM;
   P.group_m = g_p8_group;
   P.dbg = g_p8_debug;
   dim3 grid(P.tiles_m * P.tiles_n, a.batch < 1 ? 1 : a.batch);
   void (*kfn)(GemmParams);
-  if constexpr (NARROW) kfn = gemm_nt_p8n_kernel<TC, SCHED>; else kfn = gemm_nt_p8_kernel<TC, SCHED>;
+  if constexpr (NARROW) kfn = gemm_nt_p8n_kernel<TC, SCHED>; else kfn = gemm_nt_p8_kernel<TC, SCHED, false, GA>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return DU_ERR_LAUNCH;
     attr_set = true;
   }
   hipLaunchKernelGGL(kfn, grid, dim3(512), LDS_BYTES, st, P);
+  return du_check_launch();
+}
+
+// weight-gradient form: C[m][n] += alpha * sum_k A[k][m] * B[k][n] (both operands contraction-major, fp32 atomics into a zeroed C)
+int g_p8_tn = 1;         // du_set_option key 5: 0 = keep these products on the 128 x 128 register-staged kernel, 1 = where it pays, 2 = wherever legal
+
+template <int SCHED, bool GA>
+int launch_p8_tn(const du_gemm_args& a, int splits, hipStream_t st) {
+  GemmParams P = make_params(a, DU_PLAIN_COL, GA ? DU_IM2COL_COL : DU_PLAIN_COL, PBM, PBN, PBK);
+  P.tiles_m = (a.M + PBM - 1) / PBM;
+  P.split_k = splits;
+  P.k_per_split = 0;       // unused: the kernel deals out K-tile pairs itself
+  P.dbg = g_p8_debug;
+  dim3 grid(P.tiles_m * P.tiles_n * splits, 1);
+  void (*kfn)(GemmParams) = GA ? gemm_nt_p8_kernel<float, SCHED, true, true> : gemm_nt_p8_kernel<float, SCHED, true, false>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS) != hipSuccess) return DU_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kfn, grid, dim3(512), P8_LDS, st, P);
   return du_check_launch();
 }
 
@@ -751,8 +916,28 @@ extern "C" int du_set_option(int key, int value) {
     case 1: g_p8_sched = value; return DU_OK;
     case 2: g_p8_group = value; return DU_OK;
     case 3: g_p8_debug = value; return DU_OK;
+    case 5: g_p8_tn = value; return DU_OK;
     default: return DU_ERR_BAD_ARG;
   }
+}
+
+// the im2col operand of a ConvTranspose2d k2 s2 backward product (a 2 x 2 stride-2 patch gather over dy) in the form the gather
+// kernels address in place: one source tensor, power-of-two channel count (a K- or N-tile lies inside one tap), < 2 GB
+static bool convt_gather_geom(const du_gemm_args& a, const void* src, long ld, long pixels_in) {
+  const du_conv_geom& g = a.geom;
+  if (g.KH != 2 || g.KW != 2 || g.stride != 2 || g.pad != 0 || g.transposed || g.p2) return false;
+  if (g.Hi != 2 * g.Ho || g.Wi != 2 * g.Wo || g.Ho <= 0 || g.Wo <= 0) return false;
+  if (g.C <= 0 || (g.C & (g.C - 1)) || g.C % 64 || ld % 8 || (((uintptr_t)src) & 15)) return false;
+  if (pixels_in % ((long)g.Ho * g.Wo)) return false;
+  return 4 * pixels_in * ld * 2 <= 0x7fffffffL;
+}
+// data gradient of ConvTranspose2d k2 s2 as an NT product with the A rows gathered from dy
+static bool p8_gather_legal(const du_gemm_args& a) {
+  if (a.a_mode != DU_IM2COL_ROW || a.b_mode != DU_PLAIN_ROW || a.dtype != DU_BF16 || a.out_dtype != DU_BF16) return false;
+  if (a.split_k > 1 || a.batch > 1 || a.store_mode != DU_STORE_PLAIN || a.act == DU_ACT_SWIGLU) return false;
+  if (!convt_gather_geom(a, a.A, a.lda, a.M) || a.K != 4 * a.geom.C) return false;
+  if (a.K % 128 || a.M < 256 || a.N < 128 || a.N % 4 || a.ldb % 8 || (((uintptr_t)a.B) & 15)) return false;
+  return (long)a.ldb * 2 * 256 <= 0x7fffffffL;
 }
 
 // true when the multi-phase kernels can run this product at all
@@ -771,6 +956,8 @@ static bool p8_legal(const du_gemm_args& a) {
 
 // 0: not served by gemm_p8.hip, 1: 256 x 256 tiles, 2: 256 x 128 tiles
 int du_gemm_p8_choice(const du_gemm_args& a) {
+  if (g_p8_mode != 0 && g_p8_tn && p8_gather_legal(a))      // ConvT data gradient: 256 x 256 tiles once they fill most of the CUs
+    return (g_p8_mode > 0 || (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 192) ? 1 : 0;
   if (g_p8_mode == 0 || !p8_legal(a)) return 0;
   if (g_p8_mode > 0) return g_p8_mode == 2 ? 2 : 1;
   // rounds of workgroups on the 256 CUs (one 8-wave workgroup per CU) x cost per workgroup (a 256 x 128 tile costs ~0.56 of a
@@ -791,6 +978,7 @@ int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st) {
   if (c == 0 && a.act == DU_ACT_SWIGLU && p8_legal(a)) c = 2;     // the gate epilogue exists only here: take the narrow tile when the
                                                                   // heuristic would have preferred another kernel family
   if (c == 0) return DU_ERR_UNSUPPORTED;
+  if (a.a_mode == DU_IM2COL_ROW) return g_p8_sched ? launch_p8<bf16_t, 1, false, true>(a, st) : launch_p8<bf16_t, 0, false, true>(a, st);
   const bool bf = a.out_dtype == DU_BF16;
   if (c == 1) {
     if (bf) return g_p8_sched ? launch_p8<bf16_t, 1, false>(a, st) : launch_p8<bf16_t, 0, false>(a, st);
@@ -798,4 +986,41 @@ int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st) {
   }
   if (bf) return g_p8_sched ? launch_p8<bf16_t, 1, true>(a, st) : launch_p8<bf16_t, 0, true>(a, st);
   return g_p8_sched ? launch_p8<float, 1, true>(a, st) : launch_p8<float, 0, true>(a, st);
+}
+
+// Weight gradients on the multi-phase kernel: 0 = not served, else the number of K splits it would run with.  Only products the caller
+// already runs split-K (fp32 result zeroed beforehand, no epilogue terms) are taken; the split count is re-chosen for ONE 8-wave
+// workgroup per CU: tiles x splits <= 256 workgroups, at least two K-tile pairs (256 contraction rows) per split.
+int du_gemm_tn_p8_splits(const du_gemm_args& a) {
+  if (!g_p8_tn || g_p8_mode == 0) return 0;
+  if (a.dtype != DU_BF16 || a.out_dtype != DU_F32 || a.a_mode != DU_PLAIN_COL) return 0;
+  if (a.b_mode != DU_PLAIN_COL && a.b_mode != DU_IM2COL_COL) return 0;
+  if (a.split_k <= 1 || a.batch > 1 || a.store_mode != DU_STORE_PLAIN) return 0;
+  if (a.bias || a.act || a.gamma || a.row_scale || a.residual) return 0;
+  if (a.K % 128 || a.K < 512 || a.M <= 128 || a.N <= 128) return 0;
+  if (a.lda % 8 || a.ldb % 8 || (((uintptr_t)a.A) & 15) || (((uintptr_t)a.B) & 15)) return 0;
+  if (a.b_mode == DU_IM2COL_COL) {     // ConvT weight gradient: B gathered from dy; an N-tile must lie inside one tap
+    if (!convt_gather_geom(a, a.B, a.ldb, a.K) || a.N != 4 * a.geom.C || a.geom.C % 256) return 0;
+    if (a.geom.Wo & (a.geom.Wo - 1)) return 0;
+  }
+  const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const int npairs = a.K / 128;
+  long s = tiles >= 256 ? 1 : 256 / tiles;
+  if (s > npairs / 2) s = npairs / 2;
+  if (s < 1) s = 1;
+  // every workgroup ends with 256 x 256 fp32 atomics whatever its K range (measured ~35-60 us for a 256-workgroup launch, more the
+  // more splits share a tile): below ~16 K-tile pairs per split the 128 x 128 kernel's smaller partial tiles win
+  // (tools/gemm_tn_bench.py: 43008-row adapter linears 88 vs 94 us; 131072 x 512 x 1024 237 -> 162 us, ConvT 1024 -> 1024 660 -> 249 us)
+  if (g_p8_tn < 2 && npairs / s < 16) return 0;
+  // a split may not run more than 2^31 bytes past its base (buffer offsets are 32-bit): (npairs / s + 1) pairs of 128 rows
+  const long ldmax = a.b_mode == DU_PLAIN_COL && a.ldb > a.lda ? a.ldb : a.lda;
+  if ((long)(npairs / s + 1) * 128 * ldmax * 2 > 0x7fffffffL) return 0;
+  return (int)s;
+}
+
+int du_gemm_tn_p8(const du_gemm_args& a, hipStream_t st) {
+  const int s = du_gemm_tn_p8_splits(a);
+  if (s == 0) return DU_ERR_UNSUPPORTED;
+  if (a.b_mode == DU_IM2COL_COL) return g_p8_sched ? launch_p8_tn<1, true>(a, s, st) : launch_p8_tn<0, true>(a, s, st);
+  return g_p8_sched ? launch_p8_tn<1, false>(a, s, st) : launch_p8_tn<0, false>(a, s, st);
 }

@@ -115,7 +115,12 @@ PROFILE = None
 _MODE_NAMES = {(0, 0): "linear", (0, 1): "linear_dgrad", (1, 1): "linear_wgrad", (2, 0): "conv_im2col", (1, 3): "conv_wgrad"}
 
 
-_ROUTE_NAMES = {0: "gemm_kernel", 1: "gemm_bf16_kernel", 2: "gemm_nt_glds_kernel", 3: "gemm_nt_p8_kernel", 4: "gemm_nt_p8n_kernel"}
+_ROUTE_NAMES = {0: "gemm_kernel", 1: "gemm_bf16_kernel", 2: "gemm_nt_glds_kernel", 3: "gemm_nt_p8_kernel", 4: "gemm_nt_p8n_kernel", 5: "gemm_tn_p8_kernel"}
+
+
+TRACK_ROUTE = False          # tests: record the kernel family of the last product (du_gemm_route) in LAST_GEMM_ROUTE
+LAST_GEMM_ROUTE = -1
+ROUTES = []                  # (a_mode, b_mode, route) of every product since TRACK_ROUTE was switched on
 
 
 def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat, ldc, batch=1, abs_=0, bbs=0, cbs=0,
@@ -144,6 +149,10 @@ def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat,
         if n_ws > 0:
             ws = torch.empty(n_ws, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
             a.ws, a.ws_elems = ws.data_ptr(), n_ws
+    global LAST_GEMM_ROUTE
+    if TRACK_ROUTE:
+        LAST_GEMM_ROUTE = int(_lib.lib().du_gemm_route(C.byref(a)))
+        ROUTES.append((a_mode, b_mode, LAST_GEMM_ROUTE))
     if PROFILE is not None:
         e0 = PROFILE.start()
         _lib.check(_lib.lib().du_gemm(C.byref(a), _st()), "du_gemm")
@@ -215,7 +224,7 @@ class WeightPack:
         return t._base if t._base is not None else t
 
     def get(self, srcs, kind, dt=torch.bfloat16, cp=0):
-        """srcs: weight tensor or tuple of tensors to concatenate along dim 0 (PK_CAST only).  Only (views of) leaf Parameters
+        """srcs: weight tensor or tuple of tensors to concatenate along dim 0 (PK_CAST, PK_TRANSPOSE).  Only (views of) leaf Parameters
         are packed; temporaries (padded / concatenated copies made by the caller) are declined."""
         if not self.enabled:
             return None
@@ -230,8 +239,6 @@ class WeightPack:
                 return None
         if kind == PK_CONV_FWD and cp == 0:
             cp = w.shape[1]
-        if kind == PK_TRANSPOSE and len(srcs) != 1:
-            return None
         key = (tuple(t.data_ptr() for t in srcs), tuple(w.shape), kind, dt, cp)
         e = self.entries.get(key)
         if e is not None and any(r() is None for r in e["refs"]):     # a source parameter died and its address was recycled
@@ -284,14 +291,16 @@ class WeightPack:
                     if k == PK_CAST:
                         A, B, T, Cp, n = 0, 0, 0, 0, nel
                     elif k == PK_TRANSPOSE:
-                        A, B, T, Cp, n = ws[0], nel // ws[0], 0, 0, nel
+                        # one source: (A, B) -> (B, A); several: every source fills its column block of the (B, sum A) result
+                        rows_i = nel // e["dst"].shape[0]
+                        A, B, T, Cp, n = rows_i, e["dst"].shape[0], (e["dst"].shape[1] if len(e["ptrs"]) > 1 else 0), 0, nel
                     elif k in (PK_CONV_FWD, PK_CONV_DGRAD, PK_CONV_DGRAD_FLIP):
                         A, B, T, Cp, n = ws[0], ws[1], ws[2] * ws[3], e["cp"], e["dst"].numel()
                     else:
                         A, B, T, Cp, n = ws[0], ws[1], 4, 0, e["dst"].numel()
                     rows.append([ptr, e["dst"].data_ptr() + off * e["dst"].element_size(),
                                  k | ((1 if e["dst"].dtype == torch.float32 else 0) << 8), A, B, T, Cp, n])
-                    off += n
+                    off += A if (k == PK_TRANSPOSE and T) else n
                     tot += (n + 4095) // 4096          # workgroups of this row (PACK_CHUNK outputs each)
                     prefix.append(tot)
                 e["built"] = True
@@ -786,6 +795,10 @@ class _LinearCat(torch.autograd.Function):
             if bq is None:
                 bq = torch.cat([b1, b2], 0).float()
         y = mm(x, wq, bias=bq, out_dtype=out_dtype)
+        # [w1; w2]^T from the weight pack: the data gradient becomes a contraction-contiguous product (see _Linear)
+        ctx.wT = None
+        if _DGRAD_NT and w1.dtype != x.dtype and (n1 + w2.shape[0]) % 64 == 0:
+            ctx.wT = PACK.get((w1.reshape(n1, -1), w2.reshape(w2.shape[0], -1)), PK_TRANSPOSE, x.dtype)
         ctx.save_for_backward(x, wq)
         ctx.conf = (n1, tuple(w1.shape), tuple(w2.shape), b1 is not None)
         return y
@@ -797,7 +810,9 @@ class _LinearCat(torch.autograd.Function):
         dyc = dy if dy.stride(1) == 1 else dy.contiguous()
         if dyc.dtype != x.dtype:
             dyc = cast(dyc, x.dtype)
-        dx = mm_dgrad(dyc, wq) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = mm(dyc, ctx.wT) if ctx.wT is not None else mm_dgrad(dyc, wq)
         dw = mm_wgrad(dyc, x)
         db1 = db2 = None
         if has_bias:
@@ -856,6 +871,10 @@ class _FAPMProject(torch.autograd.Function):
         wfq = PACK.get(wf.reshape(2 * R, -1), PK_CAST, dt)
         if wfq is None:
             wfq = wf.reshape(2 * R, -1).to(dt)
+        ctx.wqT = ctx.wfT = None
+        if _DGRAD_NT and ws.dtype != dt and (2 * R) % 64 == 0:
+            ctx.wqT = PACK.get((ws.reshape(R, -1), wp.reshape(R, -1)), PK_TRANSPOSE, dt)
+            ctx.wfT = PACK.get(wf.reshape(2 * R, -1), PK_TRANSPOSE, dt)
         z2 = mm(xm, wq, bias=bq)
         gb = mm(z2[:, :R], wfq, bias=_f32(bf))
         z = torch.empty((rows, R), dtype=dt, device=x.device)
@@ -874,10 +893,15 @@ class _FAPMProject(torch.autograd.Function):
         dgb = torch.empty((rows, 2 * R), dtype=dt, device=dz.device)
         dz2 = torch.empty((rows, 2 * R), dtype=dt, device=dz.device)
         _lib.check(_lib.lib().du_film_bwd(_code(dt), _p(dz), _p(gb), _p(z2), _p(dgb), _p(dz2), rows, R, _st()), "du_film_bwd")
-        mm_dgrad(dgb, wfq, out=dz2[:, :R])                       # d z_shared, written into the left half of dz2
+        if ctx.wfT is not None:                                  # d z_shared, written into the left half of dz2
+            mm(dgb, ctx.wfT, out=dz2[:, :R])
+        else:
+            mm_dgrad(dgb, wfq, out=dz2[:, :R])
         dwf = mm_wgrad(dgb, z2[:, :R])
         dbf = colsum(dgb) if has_bf else None
-        dx = mm_dgrad(dz2, wq).view(B, H, W, Cc) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (mm(dz2, ctx.wqT) if ctx.wqT is not None else mm_dgrad(dz2, wq)).view(B, H, W, Cc)
         dw = mm_wgrad(dz2, xm)
         dbs = dbp = None
         if has_b:

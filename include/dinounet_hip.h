@@ -321,7 +321,9 @@ int du_device_ok(void); /* 1 if the current device is gfx950 */
 /* Kernel-selection knobs for measurement tools (within-process A/B runs, tools/gemm_p8_bench.py); results never depend on them.
    key 0: 256 x 256 multi-phase NT GEMM (gemm_p8.hip): -1 heuristic (default), 0 never, 1 wherever legal;
    key 1: its pinned issue order on (1, default) / off (0);  key 2: its tile band height (default 4);
-   key 3: epilogue ablations of those kernels (timing only);  key 4: attention waves per workgroup (0 = per shape, 3, 4). */
+   key 3: epilogue ablations of those kernels (timing only);  key 4: attention waves per workgroup (0 = per shape, 3, 4);
+   key 5: weight gradients (contraction-major operands, split-K) on the multi-phase kernel: 1 where it pays (default), 2 wherever legal,
+          0 never (the 128 x 128 kernel). */
 int du_set_option(int key, int value);
 
 /* ---- sliding-window inference: predicted_logits[sl] += prediction * gaussian; n_predictions[sl] += gaussian

@@ -153,6 +153,31 @@ def test_gemm_dgrad_wgrad(dt):
     assert rel(ops.colsum(dy.to(d, dt)), dy.sum(0)) < TOL[dt]
 
 
+@pytest.mark.parametrize("rows,N,K", [(2048, 256, 1024), (4224, 192, 520), (43008, 512, 1024), (8192, 1024, 384), (2304, 320, 264)])
+def test_gemm_multiphase_wgrad(rows, N, K):
+    """Weight gradients on the multi-phase kernel's contraction-major form (gemm_p8.hip, TN: transpose-read fragments, K-tile pairs
+    dealt out over <= 256 workgroups, fp32 atomics) vs the fp32 product of the same bf16 operands, and vs the 128 x 128 kernel it
+    replaces (du_set_option key 5).  Shapes: the adapter's linears (43008 tokens), a ragged 192-row output, odd pair counts."""
+    from dinounet_amd import _lib, ops
+    d = dev()
+    dt = torch.bfloat16
+    dy, x = q(gen(rows, N, seed=1), dt), q(gen(rows, K, seed=2), dt)
+    ref = (dy.double().t() @ x.double()).float()
+    L = _lib.lib()
+    ops.TRACK_ROUTE = True
+    try:
+        outs = {}
+        for flag in (2, 0):
+            L.du_set_option(5, flag)
+            outs[flag] = ops.mm_wgrad(dy.to(d, dt), x.to(d, dt)).float().cpu()
+            assert (ops.LAST_GEMM_ROUTE == 5) == (flag == 2), ops.LAST_GEMM_ROUTE
+    finally:
+        L.du_set_option(5, 1)
+        ops.TRACK_ROUTE = False
+    assert rel(outs[2], ref) < 2e-5          # bf16 products are exact in fp32: only the summation order differs
+    assert rel(outs[0], ref) < 2e-5
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_linear_autograd_with_residual_and_droppath(dt):
     from dinounet_amd import ops
@@ -238,6 +263,46 @@ def test_conv_transpose2x2_fwd_bwd(dt, B, H, W, Cin, Cout):
     assert rel(gg[2], gr[2]) < TOL[dt]
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(8, 16, 16, 256, 256), (4, 16, 32, 384, 512)])
+def test_conv_transpose2x2_bwd_on_gather_kernels(B, H, W, Cin, Cout):
+    """ConvTranspose2d k2 s2 backward on the multi-phase kernels' gather forms (gemm_p8.hip): the data gradient reads the 2 x 2 patch
+    rows of dy in place (NT, A gathered), the weight gradient its columns (TN, B gathered).  Forced on at a size the CPU reference
+    finishes quickly (du_set_option key 0 = 1: wherever legal); compared with conv_transpose2d's autograd and with the im2col kernels."""
+    from dinounet_amd import _lib, ops
+    d = dev()
+    dt = torch.bfloat16
+    x, w = q(gen(B, Cin, H, W, seed=1), dt), gen(Cin, Cout, 2, 2, seed=2, scale=Cin ** -0.5)
+    xr, wr = x.clone().requires_grad_(True), q(w, dt).requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, stride=2)
+    go = q(gen(*yr.shape, seed=4), dt)
+    gr = torch.autograd.grad(yr, (xr, wr), go)
+    L = _lib.lib()
+    res = {}
+    try:
+        for mode in (1, 0):
+            L.du_set_option(0, mode)
+            L.du_set_option(5, 2 if mode else 0)
+            xg, wg = nhwc(x).to(d, dt).requires_grad_(True), w.to(d).requires_grad_(True)
+            y = ops.conv_transpose2x2(xg, wg, None)
+            ops.TRACK_ROUTE, ops.ROUTES[:] = True, []
+            res[mode] = [t.float().cpu() for t in torch.autograd.grad(y, (xg, wg), nhwc(go).to(d, dt))]
+            ops.TRACK_ROUTE = False
+            routes = {(am, bm): r for am, bm, r in ops.ROUTES}
+            if mode == 1:
+                assert routes[(ops.IM2COL_ROW, ops.PLAIN_ROW)] == 3 and routes[(ops.PLAIN_COL, ops.IM2COL_COL)] == 5, routes
+            else:
+                assert routes[(ops.IM2COL_ROW, ops.PLAIN_ROW)] == 1 and routes[(ops.PLAIN_COL, ops.IM2COL_COL)] == 1, routes
+    finally:
+        ops.TRACK_ROUTE = False
+        L.du_set_option(0, -1)
+        L.du_set_option(5, 1)
+    for mode in (1, 0):
+        assert rel(res[mode][0].permute(0, 3, 1, 2), gr[0]) < TOL[dt], mode
+        assert rel(res[mode][1], gr[1]) < TOL[dt], mode
+    assert rel(res[1][0], res[0][0]) < 1e-2         # same bf16 products, fp32 sums in another order, one bf16 rounding
+    assert rel(res[1][1], res[0][1]) < 1e-4
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_conv_transpose2x2_fused_residual(dt):
     """ConvTranspose + skip add in the epilogue (dinov3_adapter.py:467): the residual has the OUTPUT (pixel-shuffled) layout."""
@@ -275,6 +340,7 @@ def test_weight_pack_matches_torch_packing():
             ((lin, lin2), ops.PK_CAST, bf, 0, lambda: torch.cat([lin, lin2], 0).to(bf)),
             ((b1, b2), ops.PK_CAST, torch.float32, 0, lambda: torch.cat([b1, b2], 0)),
             ((lin,), ops.PK_TRANSPOSE, bf, 0, lambda: lin.t().contiguous().to(bf)),
+            ((lin, lin2), ops.PK_TRANSPOSE, bf, 0, lambda: torch.cat([lin, lin2], 0).t().contiguous().to(bf)),
             ((c11.view(48, 32),), ops.PK_CAST, bf, 0, lambda: c11.view(48, 32).to(bf)),
             ((cw,), ops.PK_CONV_FWD, bf, 0, lambda: ops.pack_conv_weight(cw, bf)),
             ((stem,), ops.PK_CONV_FWD, bf, 8, lambda: ops.pack_conv_weight(F.pad(stem, (0, 0, 0, 0, 0, 5)), bf)),
@@ -295,6 +361,40 @@ def test_weight_pack_matches_torch_packing():
     P.refresh()
     assert torch.equal(P.get((lin,), ops.PK_CAST, bf).float().cpu(), lin.to(bf).float().cpu())
     assert P.get(torch.cat([lin, lin2], 0), ops.PK_CAST, bf) is None     # temporaries are never packed
+
+
+def test_packed_transposes_serve_cat_and_fapm_data_gradients():
+    """From the second step on the data gradients of linear_cat (MSDeformAttn offsets + weights) and fapm_project (shared + specific
+    bases, FiLM generator) read [w1; w2]^T from the weight pack (contraction-contiguous NT products, no PLAIN_COL operand); results
+    must match the first, unpacked step's."""
+    from dinounet_amd import ops
+    d = dev()
+    bf = torch.bfloat16
+    mk = lambda *s, seed, scale=1.0: torch.nn.Parameter(gen(*s, seed=seed, scale=scale).to(d))
+    w1, w2, b1, b2 = mk(128, 256, seed=1, scale=0.06), mk(64, 256, seed=2, scale=0.06), mk(128, seed=3), mk(64, seed=4)
+    ws, wp, wf = mk(64, 256, 1, 1, seed=5, scale=0.06), mk(64, 256, 1, 1, seed=6, scale=0.06), mk(128, 64, 1, 1, seed=7, scale=0.12)
+    bs, bp, bfm = mk(64, seed=8), mk(64, seed=9), mk(128, seed=10)
+    x = gen(2, 16, 24, 256, seed=11).to(d, bf)
+    go1, go2 = gen(2 * 16 * 24, 192, seed=12).to(d, bf), gen(2, 16, 24, 64, seed=13).to(d, bf)
+
+    def step():
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ops.TRACK_ROUTE, ops.ROUTES[:] = True, []
+        try:
+            y1 = ops.linear_cat(xa.view(-1, 256), w1, w2, b1, b2)
+            y2 = ops.fapm_project(xb, ws, wp, bs, bp, wf, bfm)
+            g = torch.autograd.grad([y1, y2], [xa, xb, w1, w2, ws, wp, wf], [go1, go2])
+        finally:
+            ops.TRACK_ROUTE = False
+        return [t.float().cpu() for t in g], [(am, bm) for am, bm, _ in ops.ROUTES]
+
+    ops.PACK.refresh()
+    g0, r0 = step()                      # registers the packs; runs on torch-side packing + PLAIN_COL data gradients
+    ops.PACK.refresh()
+    g1, r1 = step()
+    assert (ops.PLAIN_ROW, ops.PLAIN_COL) in r0 and (ops.PLAIN_ROW, ops.PLAIN_COL) not in r1, (r0, r1)
+    for a, b in zip(g0, g1):
+        assert rel(b, a) < 1e-2
 
 
 # ------------------------------------------------------------------------------------------------ norms

@@ -22,5 +22,5 @@ roof, brk = ops.PROFILE.roofline(2500.0, 8000.0, 2)
 agg = {}
 for name, e0, e1, fl, nb in ops.PROFILE.rec:
     a = agg.setdefault(name, [0.0, 0]); a[0] += e0.elapsed_time(e1) * 1e3 / 2; a[1] += 0.5
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("DETAIL_TOP", "70"))]:
     print(f"{v[0]:9.1f} us/step  x{v[1]:4.1f}  {k}")
