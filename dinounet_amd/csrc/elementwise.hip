@@ -876,7 +876,8 @@ extern "C" int du_device_ok(void) {
 //        3 CONV_DGRAD_FLIP  same with t -> T-1-t (stride-1 data gradient as a convolution with the flipped filter)
 //        4 CONVT_FWD   src (A=Cin, B=Cout, 2, 2) -> dst (4*Cout, Cin), [(q, co)][ci] = src[ci][co][q]       (ConvTranspose2d k2 s2)
 //        5 CONVT_DGRAD -> dst (Cin, 4*Cout), [ci][(q, co)] = src[ci][co][q]
-//        6 TRANSPOSE   src (A, B) -> dst (B, A)   (linear-layer data gradient as an "NT" product: dX = dY . (W^T)^T)
+//        6 TRANSPOSE   src (A, B) -> dst (B, A), or with T > 0 a column block of a wider (B, T) matrix (transposed row-concatenation);
+//                      64 x 64 tiles through LDS, ceil(A/64) * ceil(B/64) workgroups   (linear-layer data gradient as an "NT" product)
 namespace {
 constexpr int PACK_CHUNK = 4096;   // output elements per workgroup
 __global__ __launch_bounds__(256) void pack_weights_kernel(const int64_t* __restrict__ table, const int64_t* __restrict__ bprefix, int n) {
@@ -890,10 +891,44 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const int64_t* __rest
   const bool f32 = (r[2] >> 8) & 1;
   const int A = (int)r[3], B = (int)r[4], T = (int)r[5], Cp = (int)r[6];
   const int nout = (int)r[7];
-  const int e0 = (int)(bid - bprefix[lo]) * PACK_CHUNK;
-  const int e1 = min(nout, e0 + PACK_CHUNK);
   float* df = (float*)r[1];
   bf16_t* db = (bf16_t*)r[1];
+  if (kind == 6) {
+    // TRANSPOSE through LDS, one 64 x 64 tile per workgroup (the row owns ceil(A/64) * ceil(B/64) workgroups): 256-byte row segments in,
+    // 128-byte (bf16) / 256-byte (fp32) row segments out.  (An element-per-thread transpose read src at a stride of B floats: the 40-odd
+    // W^T packs of a dinounet_l step made this kernel 281 us instead of 66.)
+    __shared__ float tile[64][65];
+    const int tiles_a = (A + 63) >> 6;
+    const int t = (int)(bid - bprefix[lo]);
+    const int a0 = (t % tiles_a) * 64, b0 = (t / tiles_a) * 64;
+    const long ldd = T > 0 ? T : A;                         // T > 0: dst is a column block of a wider (B, T) matrix
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int a = a0 + ty + 16 * i;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int b = b0 + tx * 4 + j;
+        tile[ty + 16 * i][tx * 4 + j] = (a < A && b < B) ? src[(long)a * B + b] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int b = b0 + ty + 16 * i;
+      if (b >= B) continue;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int a = a0 + tx * 4 + j;
+        if (a >= A) continue;
+        const float v = tile[tx * 4 + j][ty + 16 * i];
+        if (f32) df[(long)b * ldd + a] = v; else db[(long)b * ldd + a] = (bf16_t)v;
+      }
+    }
+    return;
+  }
+  const int e0 = (int)(bid - bprefix[lo]) * PACK_CHUNK;
+  const int e1 = min(nout, e0 + PACK_CHUNK);
   if (kind == 0 && !f32 && (nout & 3) == 0 && ((((uintptr_t)src) & 15) == 0) && ((((uintptr_t)db) & 7) == 0)) {
     for (int e = e0 + threadIdx.x * 4; e < e1; e += 1024) {
       const float4 v = *(const float4*)(src + e);
@@ -915,8 +950,6 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const int64_t* __rest
                 v = src[((long)ci * B + co) * 4 + q]; break; }
       case 5: { const int ci = e / (4 * B); const int rr = e - ci * (4 * B); const int q = rr / B, co = rr - q * B;
                 v = src[((long)ci * B + co) * 4 + q]; break; }
-      // TRANSPOSE: src (A, B) -> dst (B, A); T > 0: dst is a column block of a wider (B, T) matrix (transposed row-concatenation)
-      case 6: { const int k = e / A; const int nn = e - k * A; v = src[(long)nn * B + k]; if (T > 0) d = (long)k * T + nn; break; }
       default: v = src[e];
     }
     if (f32) df[d] = v; else db[d] = (bf16_t)v;

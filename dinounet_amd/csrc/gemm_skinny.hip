@@ -125,6 +125,118 @@ __global__ __launch_bounds__(256) void gemm_skinny_partial_kernel(const bf16_t* 
   }
 }
 
+// Single-launch form: one workgroup = 32 output columns x the WHOLE contraction, NW waves each taking every NW-th 64-wide K chunk (so a
+// K = 4096 product keeps 16 waves x 12 sixteen-byte loads per lane in flight instead of 4 waves walking 16 chunks each: the 40-row
+// tails are latency-bound, 96 of them per dinounet_l step).  Every wave parks its 64 x 32 fp32 tile in its own LDS slot; one barrier;
+// the epilogue threads sum the NW slots for their 4 columns and apply the du_gemm epilogue (alpha, bias, act, gamma, row_scale,
+// residual) -- no partial buffer, no second launch.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_fused_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
+                                                                    long ldb, int M, int N, int K, SkinnyEpi P) {
+  extern __shared__ __attribute__((aligned(16))) float sk_red[];      // [NW][64][SK_BN + 1]
+  constexpr int SLOT = 64 * (SK_BN + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * SK_BN;
+  const int nrb = (M + 31) >> 5;
+  const int kh = (lane >> 5) * 32;
+  const int n = n0 + (lane & 31);
+  const bf16_t* bp = B + (long)min(n, N - 1) * ldb + kh;
+  const bf16_t* ap0 = A + (long)min(lane & 31, M - 1) * lda + kh;
+  const bf16_t* ap1 = A + (long)min(32 + (lane & 31), M - 1) * lda + kh;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll 2
+  for (int k = wave * SK_CHUNK; k < K; k += NW * SK_CHUNK) {
+    bf16x8 fb[4], fa0[4], fa1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) fb[j] = *(const bf16x8*)(bp + k + j * 8);
+#pragma unroll
+    for (int j = 0; j < 4; j++) fa0[j] = *(const bf16x8*)(ap0 + k + j * 8);
+    if (nrb > 1) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) fa1[j] = *(const bf16x8*)(ap1 + k + j * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[j], fb[j], acc0, 0, 0, 0);
+    if (nrb > 1) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[j], fb[j], acc1, 0, 0, 0);
+    }
+  }
+  {   // D layout: column lane & 31, row (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* slot = sk_red + wave * SLOT;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      slot[row * (SK_BN + 1) + (lane & 31)] = acc0[r];
+      if (nrb > 1) slot[(32 + row) * (SK_BN + 1) + (lane & 31)] = acc1[r];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < M * (SK_BN / 4); i += NW * 64) {
+    const int m = i / (SK_BN / 4), c = (i % (SK_BN / 4)) * 4;
+    const int nn = n0 + c;
+    if (nn >= N) continue;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const float* q = sk_red + w * SLOT + m * (SK_BN + 1) + c;
+      o[0] += q[0]; o[1] += q[1]; o[2] += q[2]; o[3] += q[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] *= P.alpha;
+    if (P.bias) {
+      const float4 bb = *(const float4*)(P.bias + nn);
+      o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
+    }
+    if (P.act != DU_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] = apply_act(o[e], P.act);
+    }
+    if (P.gamma) {
+      const float4 gg = *(const float4*)(P.gamma + nn);
+      o[0] *= gg.x; o[1] *= gg.y; o[2] *= gg.z; o[3] *= gg.w;
+    }
+    if (P.row_scale) {
+      const float rs = P.row_scale[m / P.rs_rows];
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] *= rs;
+    }
+    if (P.out_bf16) {
+      if (P.residual) {
+        const bf16_t* rp = (const bf16_t*)P.residual + (long)m * P.ldr + nn;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] += (float)rp[e];
+      }
+      bf16x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; e++) t[e] = (bf16_t)o[e];
+      *(uint2*)((bf16_t*)P.C + (long)m * P.ldc + nn) = __builtin_bit_cast(uint2, t);
+    } else {
+      if (P.residual) {
+        const float4 rr = *(const float4*)((const float*)P.residual + (long)m * P.ldr + nn);
+        o[0] += rr.x; o[1] += rr.y; o[2] += rr.z; o[3] += rr.w;
+      }
+      *(float4*)((float*)P.C + (long)m * P.ldc + nn) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+template <int NW>
+int launch_skinny_fused(const du_gemm_args& a, const SkinnyEpi& E, hipStream_t st) {
+  constexpr int LDS = NW * 64 * (SK_BN + 1) * 4;
+  auto kfn = gemm_skinny_fused_kernel<NW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DU_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kfn, dim3((a.N + SK_BN - 1) / SK_BN), dim3(NW * 64), LDS, st, (const bf16_t*)a.A, (long)a.lda, (const bf16_t*)a.B,
+                     (long)a.ldb, a.M, a.N, a.K, E);
+  return du_check_launch();
+}
+
 template <typename TC>
 __global__ __launch_bounds__(256) void gemm_skinny_finish_kernel(const float* __restrict__ part, int slices, GemmParams P) {
   const int n4 = P.N >> 2;
@@ -190,12 +302,19 @@ int du_gemm_skinny(const du_gemm_args& a, hipStream_t st) {
   E.C = a.C; E.ldc = a.ldc; E.residual = a.residual; E.ldr = a.ldr; E.bias = a.bias; E.gamma = a.gamma; E.row_scale = a.row_scale;
   E.alpha = a.alpha; E.act = a.act; E.rs_rows = a.rs_rows > 0 ? a.rs_rows : 1; E.out_bf16 = a.out_dtype == DU_BF16;
   static const bool no_fuse = getenv("DU_SKINNY_NO_FUSE") != nullptr;     // A-B aid
-  if (!no_fuse && a.K <= 8192) {
+  // K > 2048 (fc2 of the ViT, K = 4096): a fragment load touches 32 rows at the SAME column offset, 8 KB apart -- every request of the
+  // launch lands on the same few memory channels and the fused form (all workgroups walk K in step) takes 21 us against 14 us for the
+  // split-K pair below, whose slices sit at different column offsets (tools/gemm_ragged.py)
+  if (!no_fuse && a.K <= 2048) {
     // one launch: every workgroup runs the whole contraction of its 32 columns (4 waves x K/4) and applies the epilogue itself.  The
     // split-K pair below costs two launches + a partial round trip (12 us for 40 rows, 96 times per dinounet_l step)
-    hipLaunchKernelGGL(gemm_skinny_partial_kernel, dim3((a.N + SK_BN - 1) / SK_BN, 1), dim3(256), 0, st, (const bf16_t*)a.A, (long)a.lda,
-                       (const bf16_t*)a.B, (long)a.ldb, (float*)nullptr, a.M, a.N, a.K, a.K, E, 1);
-    return du_check_launch();
+    // waves per workgroup: enough that a wave walks at most ~4 chunks (K = 1024: 16 waves x 1 chunk, 4096: 16 x 4)
+    static const int nw_env = getenv("DU_SKINNY_WAVES") ? atoi(getenv("DU_SKINNY_WAVES")) : 0;      // A-B aid: 4 / 8 / 16
+    const int chunks = a.K / SK_CHUNK;
+    const int nw = nw_env ? nw_env : (chunks >= 16 ? 16 : chunks >= 8 ? 8 : 4);
+    if (nw >= 16) return launch_skinny_fused<16>(a, E, st);
+    if (nw >= 8) return launch_skinny_fused<8>(a, E, st);
+    return launch_skinny_fused<4>(a, E, st);
   }
   const int slices = skinny_slices(a.N, a.K);
   if (!a.ws || a.ws_elems < (int64_t)slices * 64 * a.N) return DU_ERR_UNSUPPORTED;

@@ -10,10 +10,13 @@ dinounet/inference/sliding_window_prediction.py:10-60 Gaussian map and step posi
 Differences from the reference, all on purpose: windows are run through the network in batches (the reference predicts one window
 per forward); the accumulators are fp32 (the reference keeps fp16 buffers and aborts on overflow, :612-615); the weighted
 accumulate and the final division are two HIP kernels (csrc/elementwise.hip: du_window_accumulate, du_window_normalize) instead of
-two indexed read-modify-write torch ops per window.  Test-time mirroring is not implemented (the in-trainer validation the
-reference actually uses passes use_mirroring=False, nnUNetTrainer.py:1160).  There is no CPU path: the module needs the GPU.
+two indexed read-modify-write torch ops per window.  Test-time mirroring (predict_from_raw_data.py:537-552: the prediction is
+averaged with the un-flipped predictions of every non-empty combination of the allowed mirror axes) is available through
+mirror_axes=...; the in-trainer validation passes use_mirroring=False (nnUNetTrainer.py:1160), the stand-alone predictor defaults to
+the checkpoint's inference_allowed_mirroring_axes.  There is no CPU path: the module needs the GPU.
 `acvl_utils.pad_nd_image` (not vendored in the reference tree) is restated from its published behaviour: centred constant padding
 up to the patch size, extra pixel on the high side."""
+import itertools
 import math
 
 import numpy as np
@@ -102,11 +105,33 @@ def clear_window_cache(net):
     net.__dict__.pop("_sw_forward_cache", None)
 
 
+def mirror_axes_combinations(mirror_axes, ndim):
+    """predict_from_raw_data.py:541-548: tensor dims to flip for every non-empty subset of the allowed mirror axes (axis m of the
+    spatial dims = tensor dim m + 2 of the (b, c, *spatial) window batch)."""
+    if mirror_axes is None or len(mirror_axes) == 0:
+        return []
+    assert max(mirror_axes) <= ndim - 3, "mirror_axes does not match the dimension of the input!"
+    return [c for i in range(len(mirror_axes)) for c in itertools.combinations([m + 2 for m in mirror_axes], i + 1)]
+
+
+def _mirror_and_predict(forward, x, combos):
+    """predict_from_raw_data.py:537-552 around `forward` (which may hand back a buffer it reuses on the next call)."""
+    if not combos:
+        return forward(x)
+    pred = forward(x).clone()
+    for axes in combos:
+        pred += torch.flip(forward(torch.flip(x, axes)), axes)
+    pred /= (len(combos) + 1)
+    return pred
+
+
 @torch.no_grad()
-def predict_sliding_window_logits(net, data, patch_size, tile_step_size=0.5, use_gaussian=True, batch_size=8, graph=False):
+def predict_sliding_window_logits(net, data, patch_size, tile_step_size=0.5, use_gaussian=True, batch_size=8, graph=False,
+                                  mirror_axes=None):
     """data (C, D, H, W) on the GPU (or host: moved once) -> fp32 logits (K, D, H, W) on the GPU.
     predict_from_raw_data.py:680-727 with _internal_predict_sliding_window_return_logits :571-621.  graph=True replays a captured
-    forward of a full window batch (worth it from a few batches per volume on)."""
+    forward of a full window batch (worth it from a few batches per volume on).  mirror_axes: allowed_mirroring_axes of the
+    predictor (for this 2D path a subset of (0, 1) = the window's rows / columns), None = no test-time mirroring."""
     assert data.ndim == 4, "input_image must be a 4D tensor (c, d, y, x)"
     dev = next(net.parameters()).device
     if dev.type != "cuda":
@@ -125,6 +150,14 @@ def predict_sliding_window_logits(net, data, patch_size, tile_step_size=0.5, use
         coords_all = torch.tensor(origins, dtype=torch.int32).to(dev)        # one host->device copy for the whole volume
         L = _lib.lib()
         st = torch.cuda.current_stream().cuda_stream
+        combos = mirror_axes_combinations(mirror_axes, 4)
+
+        def eager_forward(xb):
+            out = net(xb)
+            if isinstance(out, (list, tuple)):
+                out = out[0]
+            return out.float().contiguous()
+
         for i0 in range(0, len(origins), batch_size):
             chunk = origins[i0:i0 + batch_size]
             x = torch.stack([data[:, d, y0:y0 + ph, x0:x0 + pw] for d, y0, x0 in chunk])           # (b, C, ph, pw)
@@ -137,12 +170,11 @@ def predict_sliding_window_logits(net, data, patch_size, tile_step_size=0.5, use
                     if key not in cache:
                         cache[key] = _WindowForward(net, (batch_size, Cc, ph, pw), dev)
                     fwd = cache[key]
-                logits = fwd(x)
+                logits = _mirror_and_predict(fwd, x, combos)
+                if combos:
+                    logits = logits[:len(chunk)].contiguous()
             else:
-                logits = net(x)
-                if isinstance(logits, (list, tuple)):
-                    logits = logits[0]
-                logits = logits.float().contiguous()
+                logits = _mirror_and_predict(eager_forward, x, combos)
             K = logits.shape[1]
             if pred is None:
                 pred = torch.zeros((K, D, H, W), dtype=torch.float32, device=dev)

@@ -301,7 +301,8 @@ class WeightPack:
                     rows.append([ptr, e["dst"].data_ptr() + off * e["dst"].element_size(),
                                  k | ((1 if e["dst"].dtype == torch.float32 else 0) << 8), A, B, T, Cp, n])
                     off += A if (k == PK_TRANSPOSE and T) else n
-                    tot += (n + 4095) // 4096          # workgroups of this row (PACK_CHUNK outputs each)
+                    # workgroups of this row: PACK_CHUNK outputs each; transposes: one 64 x 64 tile each
+                    tot += ((A + 63) // 64) * ((B + 63) // 64) if k == PK_TRANSPOSE else (n + 4095) // 4096
                     prefix.append(tot)
                 e["built"] = True
             self.table = torch.tensor(rows, dtype=torch.int64).to(dev)

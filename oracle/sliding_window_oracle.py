@@ -43,8 +43,26 @@ def pad_nd_image_2d(data, patch_size):
     return out, (slice(int(below[0]), int(new[0] - above[0])), slice(int(below[1]), int(new[1] - above[1])))
 
 
-def predict_sliding_window_logits(predict, data, patch_size, tile_step_size=0.5, use_gaussian=True, accum_dtype=torch.float32):
+def mirror_and_predict(predict, x, mirror_axes):
+    """predict_from_raw_data.py:537-552 (_internal_maybe_mirror_and_predict): the prediction plus the flipped-back predictions of every
+    non-empty combination of the allowed mirror axes (spatial axis m = tensor dim m + 2), divided by their number + 1."""
+    import itertools
+    prediction = predict(x)
+    if mirror_axes is not None:
+        assert max(mirror_axes) <= x.ndim - 3
+        combos = [c for i in range(len(mirror_axes)) for c in itertools.combinations([m + 2 for m in mirror_axes], i + 1)]
+        for axes in combos:
+            prediction = prediction + torch.flip(predict(torch.flip(x, (*axes,))), (*axes,))
+        prediction = prediction / (len(combos) + 1)
+    return prediction
+
+
+def predict_sliding_window_logits(predict, data, patch_size, tile_step_size=0.5, use_gaussian=True, accum_dtype=torch.float32,
+                                  mirror_axes=None):
     """`predict(window (1, C, ph, pw)) -> logits (1, K, ph, pw)`; data (C, D, H, W).  One window per call, like the reference."""
+    if mirror_axes is not None:
+        inner = predict
+        predict = lambda w: mirror_and_predict(inner, w, mirror_axes)
     data, (ys, xs) = pad_nd_image_2d(data, patch_size)                   # predict_from_raw_data.py:703-705
     D, H, W = data.shape[1:]
     steps = compute_steps((H, W), patch_size, tile_step_size)           # :512

@@ -851,6 +851,14 @@ def test_sliding_window_inference_matches_oracle(shape, patch, bs):
     captured = INF.predict_sliding_window_logits(net, data, patch, tile_step_size=0.5, use_gaussian=True, batch_size=bs, graph=True)
     assert rel(captured, want) < 2e-5                    # hipGraph-replayed window forward, zero-padded ragged batch
     assert net.training is False
+    # test-time mirroring (predict_from_raw_data.py:537-552) over both in-plane axes: 4 forwards per window batch, eager and replayed
+    with torch.no_grad():
+        want_m = SW.predict_sliding_window_logits(lambda w: net(w.to(d)).float().cpu(), data, patch, 0.5, True, mirror_axes=(0, 1))
+    assert rel(want_m, want) > 1e-4                      # the mirrored average is a different prediction
+    for g in (False, True):
+        got_m = INF.predict_sliding_window_logits(net, data, patch, tile_step_size=0.5, use_gaussian=True, batch_size=bs, graph=g,
+                                                  mirror_axes=(0, 1))
+        assert rel(got_m, want_m) < 2e-5, g
 
 
 # ------------------------------------------------------------------------------------------------ GPU augmentation (8(f) rank 4)
