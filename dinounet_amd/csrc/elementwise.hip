@@ -282,8 +282,53 @@ __global__ __launch_bounds__(256) void bilinear_add_kernel(const TS* __restrict_
 #pragma unroll
     for (int j = 0; j < V; j++) {
       float v = hy * (hx * to_f32(s00[j]) + lx * to_f32(s01[j])) + ly * (hx * to_f32(s10[j]) + lx * to_f32(s11[j]));
-      out[po * ldo + c0 + j] = from_f32<T>(to_f32(base[po * ldb + c0 + j]) + v);
+      out[po * ldo + c0 + j] = from_f32<T>((base ? to_f32(base[po * ldb + c0 + j]) : 0.f) + v);
     }
+  }
+}
+
+// adjoint of the bilinear resize above (the data gradient of F.interpolate(bilinear, align_corners=False), the tail of
+// LearnableUpsampleBlock, dinounet_training.py:262-263), in GATHER form: an input pixel collects, from every output row / column whose
+// two source taps include it, the same weights the forward used -- deterministic, no atomics.  For target sizes between 1x and 2x the
+// source size (the only case the tail can see) that is at most 4 candidate rows x 4 candidate columns.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_resize_bwd_kernel(const T* __restrict__ dy, long lddy, T* __restrict__ dx, long lddx, int B,
+                                                                  int Hs, int Ws, int Ho, int Wo, int C, long total) {
+  constexpr int V = 4;
+  const int cvn = C / V;
+  const float sh = (float)Hs / (float)Ho, sw = (float)Ws / (float)Wo;
+  const float ih = (float)Ho / (float)Hs, iw = (float)Wo / (float)Ws;
+  GRID_STRIDE(i, total) {
+    const int c0 = (int)(i % cvn) * V;
+    long t = i / cvn;
+    const int xi = (int)(t % Ws); t /= Ws;
+    const int yi = (int)(t % Hs);
+    const int b = (int)(t / Hs);
+    // outputs whose source coordinate lies in (yi - 1, yi + 1): yo in ((yi - 0.5) * ih - 0.5, (yi + 1.5) * ih - 0.5), widened by one
+    const int ya = max(0, (int)floorf((yi - 0.5f) * ih - 0.5f) - 1), yb = min(Ho - 1, (int)ceilf((yi + 1.5f) * ih - 0.5f) + 1);
+    const int xa = max(0, (int)floorf((xi - 0.5f) * iw - 0.5f) - 1), xb = min(Wo - 1, (int)ceilf((xi + 1.5f) * iw - 0.5f) + 1);
+    float acc[V] = {0.f, 0.f, 0.f, 0.f};
+    for (int yo = ya; yo <= yb; yo++) {
+      const float fy = fmaxf(0.f, sh * (yo + 0.5f) - 0.5f);
+      const int y0 = (int)fy, y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
+      const float ly = fy - y0;
+      const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int xo = xa; xo <= xb; xo++) {
+        const float fx = fmaxf(0.f, sw * (xo + 0.5f) - 0.5f);
+        const int x0 = (int)fx, x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+        const float lx = fx - x0;
+        const float wx = (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
+        if (wx == 0.f) continue;
+        const T* g = dy + (((long)b * Ho + yo) * Wo + xo) * lddy + c0;
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[j] += wgt * to_f32(g[j]);
+      }
+    }
+    T* d = dx + (((long)b * Hs + yi) * Ws + xi) * lddx + c0;
+#pragma unroll
+    for (int j = 0; j < V; j++) d[j] = from_f32<T>(acc[j]);
   }
 }
 
@@ -625,7 +670,7 @@ extern "C" int du_maxpool3x3s2_bwd(int dtype, const uint8_t* idx, const void* dy
 extern "C" int du_bilinear_add_fwd(int src_dtype, int dtype, const void* src, int64_t lds_, const void* base, int64_t ldb, void* out,
                                    int64_t ldo, int B, int Hs, int Ws, int Ho, int Wo, int C, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (!src || !base || !out || B <= 0 || C % 4) return DU_ERR_BAD_ARG;
+  if (!src || !out || B <= 0 || C % 4) return DU_ERR_BAD_ARG;          // base == NULL: plain resize
   long total = (long)B * Ho * Wo * (C / 4);
   dim3 g(grid_1d(total)), b(256);
   if (src_dtype == DU_F32 && dtype == DU_F32)
@@ -634,6 +679,20 @@ extern "C" int du_bilinear_add_fwd(int src_dtype, int dtype, const void* src, in
     hipLaunchKernelGGL((bilinear_add_kernel<float, bf16_t>), g, b, 0, st, (const float*)src, lds_, (const bf16_t*)base, ldb, (bf16_t*)out, ldo, B, Hs, Ws, Ho, Wo, C, total);
   else if (src_dtype == DU_BF16 && dtype == DU_BF16)
     hipLaunchKernelGGL((bilinear_add_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)src, lds_, (const bf16_t*)base, ldb, (bf16_t*)out, ldo, B, Hs, Ws, Ho, Wo, C, total);
+  else return DU_ERR_BAD_ARG;
+  return du_check_launch();
+}
+
+extern "C" int du_bilinear_resize_bwd(int dtype, const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int Hs, int Ws, int Ho,
+                                      int Wo, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!dy || !dx || B <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0 || C % 4) return DU_ERR_BAD_ARG;
+  long total = (long)B * Hs * Ws * (C / 4);
+  dim3 g(grid_1d(total)), b(256);
+  if (dtype == DU_F32)
+    hipLaunchKernelGGL(bilinear_resize_bwd_kernel<float>, g, b, 0, st, (const float*)dy, lddy, (float*)dx, lddx, B, Hs, Ws, Ho, Wo, C, total);
+  else if (dtype == DU_BF16)
+    hipLaunchKernelGGL(bilinear_resize_bwd_kernel<bf16_t>, g, b, 0, st, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, B, Hs, Ws, Ho, Wo, C, total);
   else return DU_ERR_BAD_ARG;
   return du_check_launch();
 }

@@ -111,12 +111,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const T* __restri
 // ------------------------------------------------------------------------------------------------------
 // Channel statistics over NHWC: thread = (pixel lane, channel vector); block = one strip of one group.
 // ------------------------------------------------------------------------------------------------------
-// pixels per block: sized so a launch has ~2048 workgroups (256 CUs x 8) but every pixel lane still runs >= 4 iterations
+// pixels per block: sized so a launch has ~512 workgroups (256 CUs x 2: fewer, longer-lived workgroups measured faster in the step than
+// 2048 short ones, and the partial buffer the finalize kernel reads is 4x smaller) but every pixel lane still runs >= 4 iterations
 static inline int pick_strip(int G, long P, int C, int vec) {
   const int cvb = (C / vec) < 256 ? (C / vec) : 256;
   const int np = 256 / (cvb > 0 ? cvb : 1);
+  static const long tmax = getenv("DU_STRIP_TARGET") ? atol(getenv("DU_STRIP_TARGET")) : 512;    // tuning aid (2048: +10 % time in the step)
   long target = 65536L * 8 / C;              // wide rows: fewer, longer strips keep the partial buffer (strips x C x 2) small
-  if (target > 2048) target = 2048;
+  if (target > tmax) target = tmax;
   if (target < 256) target = 256;
   long per_group = target / (G > 0 ? G : 1);
   if (per_group < 1) per_group = 1;
@@ -276,7 +278,23 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__
       sc[j] = rstd[(long)g * C + c0 + j] * w[c0 + j];
       sh[j] = b[c0 + j] - mean[(long)g * C + c0 + j] * sc[j];
     }
-    for (long p = (long)blockIdx.x * np + tp; p < P; p += (long)gridDim.x * np) {
+    // four independent 16-byte loads in flight per thread (one load per trip left the 134 MB decoder tensors at ~2.8 TB/s)
+    const long step = (long)gridDim.x * np;
+    long p = (long)blockIdx.x * np + tp;
+    for (; p + 3 * step < P; p += 4 * step) {
+      uint4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) r[u] = *(const uint4*)(x + ((long)g * P + p + u * step) * ldx + c0);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        Vec16<T> t = as_vec<T>(r[u]);
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(apply_act(to_f32(t.v[j]) * sc[j] + sh[j], act));
+        *(uint4*)(y + ((long)g * P + p + u * step) * ldy + c0) = as_u4(o);
+      }
+    }
+    for (; p < P; p += step) {
       const long pix = (long)g * P + p;
       Vec16<T> t = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
       Vec16<T> o;
@@ -362,10 +380,8 @@ __global__ __launch_bounds__(256) void norm_act_bwd_dx_kernel(const T* __restric
       k1[j] = use_batch_stats ? bsums[((long)g * C + c0 + j) * 2 + 0] * inv_count : 0.f;
       k2[j] = use_batch_stats ? bsums[((long)g * C + c0 + j) * 2 + 1] * inv_count : 0.f;
     }
-    for (long p = (long)blockIdx.x * np + tp; p < P; p += (long)gridDim.x * np) {
-      const long pix = (long)g * P + p;
-      Vec16<T> tx = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
-      Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + pix * lddy + c0));
+    auto one = [&](const uint4& rx, const uint4& rg, long pix) {
+      Vec16<T> tx = as_vec<T>(rx), tg = as_vec<T>(rg);
       Vec16<T> o;
 #pragma unroll
       for (int j = 0; j < V; j++) {
@@ -374,16 +390,35 @@ __global__ __launch_bounds__(256) void norm_act_bwd_dx_kernel(const T* __restric
         o.v[j] = from_f32<T>(wc[j] * rs[j] * (dz - k1[j] - xh * k2[j]));
       }
       *(uint4*)(dx + pix * lddx + c0) = as_u4(o);
+    };
+    // 2 x 2 independent 16-byte loads in flight per thread
+    const long step = (long)gridDim.x * np;
+    long p = (long)blockIdx.x * np + tp;
+    for (; p + step < P; p += 2 * step) {
+      const long pa = (long)g * P + p, pb = pa + step;
+      const uint4 xa = *(const uint4*)(x + pa * ldx + c0), xb = *(const uint4*)(x + pb * ldx + c0);
+      const uint4 ga = *(const uint4*)(dy + pa * lddy + c0), gb = *(const uint4*)(dy + pb * lddy + c0);
+      one(xa, ga, pa);
+      one(xb, gb, pb);
+    }
+    for (; p < P; p += step) {
+      const long pix = (long)g * P + p;
+      one(*(const uint4*)(x + pix * ldx + c0), *(const uint4*)(dy + pix * lddy + c0), pix);
     }
   }
 }
 
 // pixel-lane slots per group for the two elementwise kernels: ~4096 workgroups in total, >= 4 pixels per lane
-static inline int norm_slots(int G, long P, int C, int vec) {
+static inline int norm_slots(int G, long P, int C, int vec, bool bwd = false) {
+  // measured in the step (rocprofv3, tools/_normsweep.sh): the forward kernel (1 load + 1 store per pixel) is best with many short
+  // workgroups, the backward-dx kernel (2 loads + 1 store, 6 channel constants per thread) with few long ones: 42 -> 31 us average
+  static const long total_f = getenv("DU_NORM_SLOTS") ? atol(getenv("DU_NORM_SLOTS")) : 4096;     // tuning aids
+  static const long total_b = getenv("DU_NORM_SLOTS_BWD") ? atol(getenv("DU_NORM_SLOTS_BWD")) : 512;
+  const long total = bwd ? total_b : total_f;
   const int cvb = (C / vec) < 256 ? (C / vec) : 256;
   const int np = 256 / (cvb > 0 ? cvb : 1);
   long s = (P + (long)np * 4 - 1) / ((long)np * 4);
-  long cap = 4096 / (G > 0 ? G : 1);
+  long cap = total / (G > 0 ? G : 1);
   if (cap < 1) cap = 1;
   if (s > cap) s = cap;
   if (s < 1) s = 1;
@@ -646,7 +681,7 @@ extern "C" int du_norm_act_bwd_dx(int dtype, const void* x, int64_t ldx, const v
   hipStream_t st = (hipStream_t)stream;
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (G <= 0 || P <= 0 || C % v || ldx % v || lddy % v || lddx % v) return DU_ERR_BAD_ARG;
-  dim3 grid(norm_slots(G, P, C, v), G), block(256);
+  dim3 grid(norm_slots(G, P, C, v, true), G), block(256);
   const float inv = count > 0 ? 1.0f / count : 0.f;
   if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_bwd_dx_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, mean, rstd, w, b, bsums, (long)P, C, act, inv, use_batch_stats);
   else if (dtype == DU_F32) hipLaunchKernelGGL(norm_act_bwd_dx_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, (float*)dx, lddx, mean, rstd, w, b, bsums, (long)P, C, act, inv, use_batch_stats);

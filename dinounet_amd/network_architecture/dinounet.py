@@ -121,7 +121,7 @@ class DepthwiseSeparableConv(nn.Module):
 
 
 class LearnableUpsampleBlock(nn.Module):
-    """DT:249-264: the same ConvTranspose2d(k2,s2) applied until the target size is reached."""
+    """DT:249-264: the same ConvTranspose2d(k2,s2) applied while a doubling still fits, then a bilinear resize to the exact target."""
 
     def __init__(self, channels: int):
         super().__init__()
@@ -133,8 +133,8 @@ class LearnableUpsampleBlock(nn.Module):
         while h * 2 <= target_size[0] and w * 2 <= target_size[1]:
             out = ops.conv_transpose2x2(out, self.up2.weight, self.up2.bias)
             h, w = out.shape[1], out.shape[2]
-        if (h, w) != tuple(target_size):
-            raise NotImplementedError("target size not reachable by x2 steps (never happens for inputs divisible by 32)")
+        if (h, w) != tuple(target_size):                     # DT:262-263: final bilinear resize to the exact size
+            out = ops.bilinear_resize(out, target_size)
         return out
 
 

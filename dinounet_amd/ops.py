@@ -19,7 +19,7 @@ from ._lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SWIGLU, DU_BF16,
                    PLAIN_ROW, STORE_PIXEL_SHUFFLE2, ConvGeom, GemmArgs)
 
 __all__ = ["mm", "linear", "conv2d", "conv_transpose2x2", "norm_act", "layer_norm", "msda", "dwconv3x3",
-           "maxpool3x3s2", "bilinear_add", "squeeze_excite", "dice_ce_loss"]
+           "maxpool3x3s2", "bilinear_add", "bilinear_resize", "squeeze_excite", "dice_ce_loss"]
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -1414,6 +1414,34 @@ class _BilinearAdd(torch.autograd.Function):
 
 def bilinear_add(src, base):
     return _BilinearAdd.apply(src, base)
+
+
+class _BilinearResize(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) on NHWC with its data gradient (the tail of
+    LearnableUpsampleBlock, dinounet_training.py:262-263: only reached when the target is not a power-of-two multiple of the input)."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        B, Hs, Ws, Cc, lds = _nhwc(x)
+        out = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib().du_bilinear_add_fwd(_code(x.dtype), _code(x.dtype), _p(x), lds, None, 0, _p(out), Cc, B, Hs, Ws, Ho, Wo,
+                                                  Cc, _st()), "du_bilinear_add_fwd")
+        ctx.geo = (B, Hs, Ws, Ho, Wo, Cc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Hs, Ws, Ho, Wo, Cc = ctx.geo
+        dy = dy.contiguous()
+        dx = torch.empty((B, Hs, Ws, Cc), dtype=dy.dtype, device=dy.device)
+        _lib.check(_lib.lib().du_bilinear_resize_bwd(_code(dy.dtype), _p(dy), Cc, _p(dx), Cc, B, Hs, Ws, Ho, Wo, Cc, _st()),
+                   "du_bilinear_resize_bwd")
+        return dx, None, None
+
+
+def bilinear_resize(x, size):
+    """NHWC x -> (B, size[0], size[1], C), bilinear, align_corners=False."""
+    return _BilinearResize.apply(x, int(size[0]), int(size[1]))
 
 
 class _SqueezeExcite(torch.autograd.Function):

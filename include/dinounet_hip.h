@@ -233,9 +233,14 @@ int du_dwconv3x3_bwd_weight(int dtype, const void* x, int64_t ldx, int64_t xbs, 
 /* MaxPool2d(3, 2, 1) on contiguous NHWC; idx (nullable, same shape as y, uint8) records the winning tap */
 int du_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
 int du_maxpool3x3s2_bwd(int dtype, const uint8_t* idx, const void* dy, void* dx, int B, int H, int W, int C, void* stream);
-/* out = base + bilinear_upsample(src) (align_corners=False); src (B,Hs,Ws,C) of src_dtype, base/out (B,Ho,Wo,C) */
+/* out = base + bilinear_upsample(src) (align_corners=False); src (B,Hs,Ws,C) of src_dtype, base/out (B,Ho,Wo,C).  base == NULL: the
+   plain resize F.interpolate(src, size=(Ho,Wo), mode='bilinear', align_corners=False) (tail of LearnableUpsampleBlock,
+   dinounet_training.py:262-263) */
 int du_bilinear_add_fwd(int src_dtype, int dtype, const void* src, int64_t lds_, const void* base, int64_t ldb, void* out,
                         int64_t ldo, int B, int Hs, int Ws, int Ho, int Wo, int C, void* stream);
+/* data gradient of that resize: dx (B,Hs,Ws,C) from dy (B,Ho,Wo,C); gather form (deterministic, no atomics) */
+int du_bilinear_resize_bwd(int dtype, const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int Hs, int Ws, int Ho, int Wo,
+                           int C, void* stream);
 /* dz = dy * act'(z) */
 int du_act_bwd(int dtype, const void* z, const void* dy, void* dz, int64_t n, int act, void* stream);
 

@@ -148,6 +148,10 @@ def bilinear_add(src, base):
     return base + _nhwc(up).to(base.dtype)
 
 
+def bilinear_resize(x, size):
+    return _nhwc(F.interpolate(_nchw(x), size=(int(size[0]), int(size[1])), mode="bilinear", align_corners=False))
+
+
 def squeeze_excite(x, w1, b1, w2, b2, shortcut=None):
     s = x.float().mean((1, 2))
     s = F.relu(F.linear(s, w1.flatten(1), b1))
@@ -189,7 +193,7 @@ def attention(qkv, sin, cos, B, N, H, Dh, prefix, workspace):
 
 
 _NAMES = ["mm", "linear", "linear_cat", "conv1x1_cat", "fapm_project", "conv1x1", "conv2d", "conv2d_stats", "conv_transpose2x2", "norm_act", "layer_norm", "layer_norm_res", "layernorm_raw", "msda_prep", "msda",
-          "dwconv3x3", "dwconv_tokens", "maxpool3x3s2", "bilinear_add", "squeeze_excite", "nchw_to_nhwc", "nhwc_to_nchw_f32", "patchify16", "cast",
+          "dwconv3x3", "dwconv_tokens", "maxpool3x3s2", "bilinear_add", "bilinear_resize", "squeeze_excite", "nchw_to_nhwc", "nhwc_to_nchw_f32", "patchify16", "cast",
           "attention"]
 
 

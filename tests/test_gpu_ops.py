@@ -579,6 +579,42 @@ def test_maxpool_and_bilinear(dt):
         out = ops.bilinear_add(nhwc(src).to(d, dt), nhwc(base).to(d, dt))
         ref = base + F.interpolate(src, size=(ho, wo), mode="bilinear", align_corners=False)
         assert rel(out.permute(0, 3, 1, 2), ref) < TOL[dt]
+    # plain resize with its data gradient (tail of LearnableUpsampleBlock, dinounet_training.py:262-263): between 1x and 2x, exact 2x,
+    # non-square, a mild downscale
+    for (hs, ws, ho, wo) in ((16, 16, 25, 25), (16, 24, 31, 40), (8, 8, 16, 16), (12, 10, 12, 17), (16, 16, 13, 11)):
+        src = q(gen(2, 32, hs, ws, seed=5), dt)
+        sr = src.clone().requires_grad_(True)
+        yr = F.interpolate(sr, size=(ho, wo), mode="bilinear", align_corners=False)
+        go = q(gen(*yr.shape, seed=6), dt)
+        gr = torch.autograd.grad(yr, sr, go)[0]
+        sg = nhwc(src).to(d, dt).requires_grad_(True)
+        y = ops.bilinear_resize(sg, (ho, wo))
+        gg = torch.autograd.grad(y, sg, nhwc(go).to(d, dt))[0]
+        assert rel(y.permute(0, 3, 1, 2), yr) < TOL[dt], (hs, ws, ho, wo)
+        assert rel(gg.permute(0, 3, 1, 2), gr) < TOL[dt], (hs, ws, ho, wo)
+
+
+def test_learnable_upsample_block_bilinear_tail():
+    """LearnableUpsampleBlock (dinounet_training.py:249-264) with a target that is not a power-of-two multiple of the input: transpose
+    convolutions while a doubling still fits, then the bilinear resize -- forward and gradients vs the torch composition."""
+    from dinounet_amd.network_architecture.dinounet import LearnableUpsampleBlock
+    d = dev()
+    blk = LearnableUpsampleBlock(32).to(d)
+    with torch.no_grad():
+        blk.up2.weight.copy_(gen(32, 32, 2, 2, seed=1, scale=0.2)); blk.up2.bias.copy_(gen(32, seed=2))
+    x = gen(2, 32, 6, 5, seed=3)
+    xr = x.clone().requires_grad_(True)
+    w, b = blk.up2.weight.detach().cpu().clone().requires_grad_(True), blk.up2.bias.detach().cpu().clone().requires_grad_(True)
+    t = F.conv_transpose2d(F.conv_transpose2d(xr, w, b, stride=2), w, b, stride=2)          # 24 x 20: one more doubling would exceed 29 x 33
+    yr = F.interpolate(t, size=(29, 33), mode="bilinear", align_corners=False)
+    go = gen(*yr.shape, seed=4)
+    gr = torch.autograd.grad(yr, (xr, w, b), go)
+    xg = nhwc(x).to(d).requires_grad_(True)
+    y = blk(xg, (29, 33))
+    gg = torch.autograd.grad(y, (xg, blk.up2.weight, blk.up2.bias), nhwc(go).to(d))
+    assert rel(y.permute(0, 3, 1, 2), yr) < 2e-4
+    assert rel(gg[0].permute(0, 3, 1, 2), gr[0]) < 2e-4
+    assert rel(gg[1], gr[1]) < 2e-4 and rel(gg[2], gr[2]) < 2e-4
 
 
 def test_layout_helpers():
