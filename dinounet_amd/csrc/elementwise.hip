@@ -17,7 +17,22 @@ __host__ int grid_1d(long total) {
 // Thread = (pixel lane, 8/4-channel vector); a thread keeps the 9 x VEC filter taps of its channels in registers and walks
 // pixels (grid-stride over pixel lanes), so the inner loop is 9 vector loads + 9*VEC FMAs + 1-2 vector stores per pixel.
 // FLIP = true evaluates the data gradient: correlation of dy with the spatially flipped filter.
-template <typename T, bool FLIP>
+// PYR = true: the token pyramid of ConvFFN's DWConv (dinov3_adapter.py:99-109) in ONE launch: every image is N = 21 n tokens
+// (n = H*W/4) holding a (2H x 2W), an (H x W) and an (H/2 x W/2) grid back to back; a pixel index decodes to (image, grid, y, x).
+struct PyrPix { int b, s0, Hs, Ws, yo, xo; };
+__device__ __forceinline__ PyrPix pyr_decode(long p, int H, int W) {
+  const int n = (H * W) >> 2, N = 21 * n;
+  PyrPix q;
+  q.b = (int)(p / N);
+  int t = (int)(p - (long)q.b * N);
+  if (t < 16 * n) { q.s0 = 0; q.Hs = 2 * H; q.Ws = 2 * W; }
+  else if (t < 20 * n) { q.s0 = 16 * n; q.Hs = H; q.Ws = W; t -= 16 * n; }
+  else { q.s0 = 20 * n; q.Hs = H >> 1; q.Ws = W >> 1; t -= 20 * n; }
+  q.yo = t / q.Ws; q.xo = t - q.yo * q.Ws;
+  return q;
+}
+
+template <typename T, bool FLIP, bool PYR>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, long ldx, long xbs, const float* __restrict__ w,
                                                      const float* __restrict__ bias, T* __restrict__ y, long ldy, long ybs,
                                                      T* __restrict__ z, int B, int H, int W, int C, int act, int lanes_per_block) {
@@ -27,7 +42,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, lo
   const int np = 256 / cvb;
   const int tp = threadIdx.x / cvb, tcv = threadIdx.x % cvb;
   if (tp >= np) return;
-  const long npix = (long)B * H * W;
+  const long npix = PYR ? (long)B * 21 * ((H * W) >> 2) : (long)B * H * W;
   for (int cv = tcv; cv < cvn; cv += cvb) {
     const int c0 = cv * V;
     float wt[9][V], bs[V];
@@ -38,25 +53,31 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, lo
       for (int t = 0; t < 9; t++) wt[t][j] = w[(c0 + j) * 9 + (FLIP ? 8 - t : t)];
     }
     for (long p = (long)blockIdx.x * np + tp; p < npix; p += (long)gridDim.x * np) {
-      const int xo = (int)(p % W); long t2 = p / W;
-      const int yo = (int)(t2 % H); const int b = (int)(t2 / H);
+      int xo, yo, b, Hs = H, Ws = W, s0 = 0;
+      if constexpr (PYR) {
+        const PyrPix q = pyr_decode(p, H, W);
+        xo = q.xo; yo = q.yo; b = q.b; Hs = q.Hs; Ws = q.Ws; s0 = q.s0;
+      } else {
+        xo = (int)(p % W); long t2 = p / W;
+        yo = (int)(t2 % H); b = (int)(t2 / H);
+      }
       float acc[V];
 #pragma unroll
       for (int j = 0; j < V; j++) acc[j] = bs[j];
 #pragma unroll
       for (int dy = 0; dy < 3; dy++) {
         const int yi = yo + dy - 1;
-        if (yi < 0 || yi >= H) continue;
+        if (yi < 0 || yi >= Hs) continue;
 #pragma unroll
         for (int dx = 0; dx < 3; dx++) {
           const int xi = xo + dx - 1;
-          if (xi < 0 || xi >= W) continue;
-          Vec16<T> v = as_vec<T>(*(const uint4*)(x + (long)b * xbs + ((long)yi * W + xi) * ldx + c0));
+          if (xi < 0 || xi >= Ws) continue;
+          Vec16<T> v = as_vec<T>(*(const uint4*)(x + (long)b * xbs + (s0 + (long)yi * Ws + xi) * ldx + c0));
 #pragma unroll
           for (int j = 0; j < V; j++) acc[j] += to_f32(v.v[j]) * wt[dy * 3 + dx][j];
         }
       }
-      const long off = (long)b * ybs + ((long)yo * W + xo) * ldy + c0;
+      const long off = (long)b * ybs + (s0 + (long)yo * Ws + xo) * ldy + c0;
       Vec16<T> o;
       if (z) {
 #pragma unroll
@@ -73,7 +94,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, lo
 // dw[c][tap] += sum_pix x[pix+tap][c] * dy[pix][c]; db[c] += sum dy.  Block = strip of pixels, thread = (pixel lane, cvec);
 // per-thread register partials are reduced across the block's pixel lanes through LDS in two passes of five taps (every thread
 // takes part in the column sums), so each block issues one store / atomic per (channel, tap).
-template <typename T>
+template <typename T, bool PYR>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, long ldx, long xbs,
                                                                 const T* __restrict__ dy, long lddy, long dybs,
                                                                 float* __restrict__ dw, float* __restrict__ db, int B, int H,
@@ -84,7 +105,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
   const int cvb = min(cvn, 256);
   const int np = 256 / cvb;
   const int tp = threadIdx.x / cvb, tcv = threadIdx.x % cvb;
-  const int npix = B * H * W;
+  const int npix = PYR ? B * 21 * ((H * W) >> 2) : B * H * W;
   const int p0 = blockIdx.x * strip, p1 = min(npix, p0 + strip);
   for (int cv0 = 0; cv0 < cvn; cv0 += cvb) {
     const int cv = cv0 + tcv;
@@ -97,10 +118,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
       for (int j = 0; j < V; j++) aw[k][j] = 0.f;
     if (active) {
       int p = p0 + tp;
-      int xo = p % W, t = p / W;
-      int yo = t % H, b = t / H;
+      int xo = 0, yo = 0, b = 0, Hs = H, Ws = W, s0 = 0;
+      if constexpr (!PYR) { xo = p % W; const int t = p / W; yo = t % H; b = t / H; }
       for (; p < p1; p += np) {
-        Vec16<T> g = as_vec<T>(*(const uint4*)(dy + (long)b * dybs + ((long)yo * W + xo) * lddy + c0));
+        if constexpr (PYR) {
+          const PyrPix q = pyr_decode(p, H, W);
+          xo = q.xo; yo = q.yo; b = q.b; Hs = q.Hs; Ws = q.Ws; s0 = q.s0;
+        }
+        Vec16<T> g = as_vec<T>(*(const uint4*)(dy + (long)b * dybs + (s0 + (long)yo * Ws + xo) * lddy + c0));
         float gf[V];
 #pragma unroll
         for (int j = 0; j < V; j++) { gf[j] = to_f32(g.v[j]); aw[9][j] += gf[j]; }
@@ -108,18 +133,20 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
 #pragma unroll
         for (int ky = 0; ky < 3; ky++) {
           const int yi = yo + ky - 1;
-          if (yi < 0 || yi >= H) continue;
+          if (yi < 0 || yi >= Hs) continue;
 #pragma unroll
           for (int kx = 0; kx < 3; kx++) {
             const int xi = xo + kx - 1;
-            if (xi < 0 || xi >= W) continue;
-            Vec16<T> v = as_vec<T>(*(const uint4*)(xb + ((long)yi * W + xi) * ldx));
+            if (xi < 0 || xi >= Ws) continue;
+            Vec16<T> v = as_vec<T>(*(const uint4*)(xb + (s0 + (long)yi * Ws + xi) * ldx));
 #pragma unroll
             for (int j = 0; j < V; j++) aw[ky * 3 + kx][j] += to_f32(v.v[j]) * gf[j];
           }
         }
-        xo += np;                                   // advance the pixel coordinate without divisions
-        while (xo >= W) { xo -= W; if (++yo == H) { yo = 0; b++; } }
+        if constexpr (!PYR) {
+          xo += np;                                 // advance the pixel coordinate without divisions
+          while (xo >= W) { xo -= W; if (++yo == H) { yo = 0; b++; } }
+        }
       }
     }
     const int ncol = cvb * V;                        // channel columns this pass covers
@@ -591,8 +618,8 @@ extern "C" int du_dwconv3x3_fwd(int dtype, const void* x, int64_t ldx, int64_t x
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C % v || ldx % v || ldy % v || xbs % v || ybs % v) return DU_ERR_BAD_ARG;
   const int grid = dwconv_grid((long)B * H * W, C, v);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL((dwconv_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ldx, xbs, w, bias, (bf16_t*)y, ldy, ybs, (bf16_t*)z, B, H, W, C, act, 0),
-             hipLaunchKernelGGL((dwconv_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)x, ldx, xbs, w, bias, (float*)y, ldy, ybs, (float*)z, B, H, W, C, act, 0));
+             hipLaunchKernelGGL((dwconv_kernel<bf16_t, false, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, ldx, xbs, w, bias, (bf16_t*)y, ldy, ybs, (bf16_t*)z, B, H, W, C, act, 0),
+             hipLaunchKernelGGL((dwconv_kernel<float, false, false>), dim3(grid), dim3(256), 0, st, (const float*)x, ldx, xbs, w, bias, (float*)y, ldy, ybs, (float*)z, B, H, W, C, act, 0));
   return du_check_launch();
 }
 
@@ -603,8 +630,8 @@ extern "C" int du_dwconv3x3_bwd_data(int dtype, const void* dy, int64_t lddy, in
   if (!dy || !w || !dx || B <= 0 || C % v || lddy % v || lddx % v || dybs % v || dxbs % v) return DU_ERR_BAD_ARG;
   const int grid = dwconv_grid((long)B * H * W, C, v);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL((dwconv_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, lddy, dybs, w, (const float*)nullptr, (bf16_t*)dx, lddx, dxbs, (bf16_t*)nullptr, B, H, W, C, DU_ACT_NONE, 0),
-             hipLaunchKernelGGL((dwconv_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)dy, lddy, dybs, w, (const float*)nullptr, (float*)dx, lddx, dxbs, (float*)nullptr, B, H, W, C, DU_ACT_NONE, 0));
+             hipLaunchKernelGGL((dwconv_kernel<bf16_t, true, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, lddy, dybs, w, (const float*)nullptr, (bf16_t*)dx, lddx, dxbs, (bf16_t*)nullptr, B, H, W, C, DU_ACT_NONE, 0),
+             hipLaunchKernelGGL((dwconv_kernel<float, true, false>), dim3(grid), dim3(256), 0, st, (const float*)dy, lddy, dybs, w, (const float*)nullptr, (float*)dx, lddx, dxbs, (float*)nullptr, B, H, W, C, DU_ACT_NONE, 0));
   return du_check_launch();
 }
 
@@ -636,10 +663,55 @@ extern "C" int du_dwconv3x3_bwd_weight(int dtype, const void* x, int64_t ldx, in
   long blocks = (npix + strip - 1) / strip;
   float* part = (ws && ws_elems >= blocks * C * 10) ? ws : nullptr;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, xbs, (const bf16_t*)dy, lddy, dybs, dw, db, B, H, W, C, strip, part),
-             hipLaunchKernelGGL(dwconv_bwd_weight_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, ldx, xbs, (const float*)dy, lddy, dybs, dw, db, B, H, W, C, strip, part));
+             hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, xbs, (const bf16_t*)dy, lddy, dybs, dw, db, B, H, W, C, strip, part),
+             hipLaunchKernelGGL((dwconv_bwd_weight_kernel<float, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, ldx, xbs, (const float*)dy, lddy, dybs, dw, db, B, H, W, C, strip, part));
   if (part)
     hipLaunchKernelGGL(dwconv_wgrad_finalize_kernel, dim3((C * 10 + 31) / 32), dim3(256), 0, st, (const float*)part, dw, db, (int)blocks, C, accumulate);
+  return du_check_launch();
+}
+
+// ---- the same three kernels over the (B, 21 n, C) token pyramid of ConvFFN (dinov3_adapter.py:99-109), one launch each ----
+extern "C" int du_dwconv3x3_tokens_fwd(int dtype, const void* x, const float* w, const float* bias, void* y, void* z, int B, int H,
+                                       int W, int C, int act, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C % v) return DU_ERR_BAD_ARG;
+  const long N = 21L * ((H * W) >> 2);
+  const int grid = dwconv_grid((long)B * N, C, v);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((dwconv_kernel<bf16_t, false, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (long)C, N * C, w, bias, (bf16_t*)y, (long)C, N * C, (bf16_t*)z, B, H, W, C, act, 0),
+             hipLaunchKernelGGL((dwconv_kernel<float, false, true>), dim3(grid), dim3(256), 0, st, (const float*)x, (long)C, N * C, w, bias, (float*)y, (long)C, N * C, (float*)z, B, H, W, C, act, 0));
+  return du_check_launch();
+}
+
+extern "C" int du_dwconv3x3_tokens_bwd_data(int dtype, const void* dy, const float* w, void* dx, int B, int H, int W, int C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C % v) return DU_ERR_BAD_ARG;
+  const long N = 21L * ((H * W) >> 2);
+  const int grid = dwconv_grid((long)B * N, C, v);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((dwconv_kernel<bf16_t, true, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (long)C, N * C, w, (const float*)nullptr, (bf16_t*)dx, (long)C, N * C, (bf16_t*)nullptr, B, H, W, C, DU_ACT_NONE, 0),
+             hipLaunchKernelGGL((dwconv_kernel<float, true, true>), dim3(grid), dim3(256), 0, st, (const float*)dy, (long)C, N * C, w, (const float*)nullptr, (float*)dx, (long)C, N * C, (float*)nullptr, B, H, W, C, DU_ACT_NONE, 0));
+  return du_check_launch();
+}
+
+// scratch: du_dwconv_wgrad_ws_elems(dtype, B, 21 * H * W / 4, 1, C) floats
+extern "C" int du_dwconv3x3_tokens_bwd_weight(int dtype, const void* x, const void* dy, float* dw, float* db, int B, int H, int W, int C,
+                                              float* ws, int64_t ws_elems, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (!x || !dy || !dw || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C % v) return DU_ERR_BAD_ARG;
+  const long N = 21L * ((H * W) >> 2);
+  const long npix = (long)B * N;
+  const int strip = dwconv_wgrad_strip(npix, C, v);
+  long blocks = (npix + strip - 1) / strip;
+  float* part = (ws && ws_elems >= blocks * C * 10) ? ws : nullptr;
+  if (!part) return DU_ERR_BAD_ARG;          // the partial + finalize form overwrites dw / db: no zero-fill contract on this entry point
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (long)C, N * C, (const bf16_t*)dy, (long)C, N * C, dw, db, B, H, W, C, strip, part),
+             hipLaunchKernelGGL((dwconv_bwd_weight_kernel<float, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (long)C, N * C, (const float*)dy, (long)C, N * C, dw, db, B, H, W, C, strip, part));
+  hipLaunchKernelGGL(dwconv_wgrad_finalize_kernel, dim3((C * 10 + 31) / 32), dim3(256), 0, st, (const float*)part, dw, db, (int)blocks, C, 0);
   return du_check_launch();
 }
 

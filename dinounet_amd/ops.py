@@ -1360,12 +1360,52 @@ def dwconv3x3(x, w, bias=None, act=ACT_NONE):
     return _DWConvSegs.apply(x, w, bias, ((0, B, H, W, Cc, H * W * Cc),), act)
 
 
+class _DWConvTokens(torch.autograd.Function):
+    """ConvFFN's DWConv (dinov3_adapter.py:99-109) + GELU (:87) over the (B, 21 n, C) token pyramid: the three grids of every image in
+    ONE launch per pass (forward, data gradient, weight gradient) instead of one per grid."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, H, W, act):
+        x = x.contiguous()
+        B, N, Cc = x.shape
+        wf = _f32(w).view(Cc, 9)
+        y = torch.empty_like(x)
+        z = torch.empty_like(x) if act != ACT_NONE else None
+        _lib.check(_lib.lib().du_dwconv3x3_tokens_fwd(_code(x.dtype), _p(x), _p(wf), _p(_f32(bias)), _p(y), _p(z), B, H, W, Cc, act, _st()),
+                   "du_dwconv3x3_tokens_fwd")
+        ctx.save_for_backward(x, wf, z)
+        ctx.conf = (H, W, act, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wf, z = ctx.saved_tensors
+        H, W, act, has_bias = ctx.conf
+        B, N, Cc = x.shape
+        L = _lib.lib()
+        code = _code(x.dtype)
+        dy = dy.contiguous()
+        if act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            _lib.check(L.du_act_bwd(code, _p(z), _p(dy), _p(dz), dy.numel(), act, _st()), "du_act_bwd")
+        else:
+            dz = dy
+        dx = torch.empty_like(x)
+        _lib.check(L.du_dwconv3x3_tokens_bwd_data(code, _p(dz), _p(wf), _p(dx), B, H, W, Cc, _st()), "du_dwconv3x3_tokens_bwd_data")
+        dw = torch.empty((Cc, 9), dtype=torch.float32, device=x.device)
+        db = torch.empty(Cc, dtype=torch.float32, device=x.device) if has_bias else None
+        n = int(L.du_dwconv_wgrad_ws_elems(code, B, N, 1, Cc))
+        ws = torch.empty(max(n, 1), dtype=torch.float32, device=x.device)
+        _lib.check(L.du_dwconv3x3_tokens_bwd_weight(code, _p(x), _p(dz), _p(dw), _p(db), B, H, W, Cc, _p(ws), n, _st()),
+                   "du_dwconv3x3_tokens_bwd_weight")
+        return dx, dw.view(Cc, 1, 3, 3), db, None, None, None
+
+
 def dwconv_tokens(x, w, bias, H, W, act=ACT_GELU):
     """x (B, N, C) with N = 21 * (H*W/4) tokens (ConvFFN)."""
     B, N, Cc = x.shape
-    n = N // 21
-    segs = ((0, B, 2 * H, 2 * W, Cc, N * Cc), (16 * n * Cc, B, H, W, Cc, N * Cc), (20 * n * Cc, B, H // 2, W // 2, Cc, N * Cc))
-    return _DWConvSegs.apply(x, w, bias, segs, act)
+    assert N == 21 * ((H * W) // 4) and H % 2 == 0 and W % 2 == 0, (N, H, W)
+    return _DWConvTokens.apply(x, w, bias, H, W, act)
 
 
 class _MaxPool(torch.autograd.Function):

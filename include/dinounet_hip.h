@@ -230,6 +230,15 @@ int64_t du_dwconv_wgrad_ws_elems(int dtype, int B, int H, int W, int C);
 int du_dwconv3x3_bwd_weight(int dtype, const void* x, int64_t ldx, int64_t xbs, const void* dy, int64_t lddy, int64_t dybs,
                             float* dw, float* db, int B, int H, int W, int C, float* ws, int64_t ws_elems, int accumulate,
                             void* stream);
+/* The same depthwise kernel over ConvFFN's token pyramid (DWConv.forward, dinov3_adapter.py:99-109): x, y, z, dy, dx are contiguous
+   (B, 21 n, C) token tensors, n = H*W/4, each image holding a (2H x 2W), an (H x W) and an (H/2 x W/2) grid back to back; one launch
+   instead of one per grid.  z (nullable): pre-activation copy for the backward of `act`.  bwd_weight OVERWRITES dw (C,9) / db (C) and
+   needs du_dwconv_wgrad_ws_elems(dtype, B, 21 n, 1, C) floats of scratch. */
+int du_dwconv3x3_tokens_fwd(int dtype, const void* x, const float* w, const float* bias, void* y, void* z, int B, int H, int W, int C,
+                            int act, void* stream);
+int du_dwconv3x3_tokens_bwd_data(int dtype, const void* dy, const float* w, void* dx, int B, int H, int W, int C, void* stream);
+int du_dwconv3x3_tokens_bwd_weight(int dtype, const void* x, const void* dy, float* dw, float* db, int B, int H, int W, int C, float* ws,
+                                   int64_t ws_elems, void* stream);
 /* MaxPool2d(3, 2, 1) on contiguous NHWC; idx (nullable, same shape as y, uint8) records the winning tap */
 int du_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
 int du_maxpool3x3s2_bwd(int dtype, const uint8_t* idx, const void* dy, void* dx, int B, int H, int W, int C, void* stream);
