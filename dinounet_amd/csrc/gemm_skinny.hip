@@ -146,8 +146,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fused_kernel(const bf16_t
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  // workgroup j starts its walk over the K chunks at a different chunk (and wraps): with long rows (K = 4096: 8 KB pitch) every load of
+  // the launch otherwise hits the same few memory channels at the same time (32 rows at ONE column offset per load, all workgroups in step)
+  const int nchunk = K / SK_CHUNK;
+  const int rot = (int)((blockIdx.x * 5u) % (unsigned)nchunk);
 #pragma unroll 2
-  for (int k = wave * SK_CHUNK; k < K; k += NW * SK_CHUNK) {
+  for (int ci = wave; ci < nchunk; ci += NW) {
+    int cc = ci + rot; if (cc >= nchunk) cc -= nchunk;
+    const int k = cc * SK_CHUNK;
     bf16x8 fb[4], fa0[4], fa1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) fb[j] = *(const bf16x8*)(bp + k + j * 8);
@@ -305,7 +311,8 @@ int du_gemm_skinny(const du_gemm_args& a, hipStream_t st) {
   // K > 2048 (fc2 of the ViT, K = 4096): a fragment load touches 32 rows at the SAME column offset, 8 KB apart -- every request of the
   // launch lands on the same few memory channels and the fused form (all workgroups walk K in step) takes 21 us against 14 us for the
   // split-K pair below, whose slices sit at different column offsets (tools/gemm_ragged.py)
-  if (!no_fuse && a.K <= 2048) {
+  static const int fuse_kmax = getenv("DU_SKINNY_FUSE_KMAX") ? atoi(getenv("DU_SKINNY_FUSE_KMAX")) : 2048;      // A-B aid
+  if (!no_fuse && a.K <= fuse_kmax) {
     // one launch: every workgroup runs the whole contraction of its 32 columns (4 waves x K/4) and applies the epilogue itself.  The
     // split-K pair below costs two launches + a partial round trip (12 us for 40 rows, 96 times per dinounet_l step)
     // waves per workgroup: enough that a wave walks at most ~4 chunks (K = 1024: 16 waves x 1 chunk, 4096: 16 x 4)

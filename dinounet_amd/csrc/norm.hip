@@ -455,6 +455,85 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
   }
 }
 
+// finalize + what the next tiny kernel would do, in one launch (every launch of this size costs ~5 us inside the replayed graph):
+//  STATS: out[g][c] = (sum, sum of squares) as above, then mean / rstd (biased variance) and the optional BatchNorm running-statistics
+//         update -- what norm_stats_finalize_kernel does.  A workgroup owns COLS consecutive columns = COLS / 2 channels of one group.
+template <int COLS>
+__global__ __launch_bounds__(256) void finalize_stats_kernel(const float* __restrict__ part, float* __restrict__ out, int G, int strips, int C2,
+                                                             float inv_count, float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                                             float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
+                                                             float unbias) {
+  constexpr int LANES = 256 / COLS;
+  __shared__ float red[LANES][COLS + 1];
+  __shared__ float tot[COLS];
+  const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+  const int chunks = (C2 + COLS - 1) / COLS;
+  const int g = blockIdx.x / chunks, c = (blockIdx.x % chunks) * COLS + col;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < C2) {
+    const float* p = part + (long)g * strips * C2 + c;
+    int s = sl;
+    for (; s + 3 * LANES < strips; s += 4 * LANES) {
+      a0 += p[(long)s * C2]; a1 += p[(long)(s + LANES) * C2]; a2 += p[(long)(s + 2 * LANES) * C2]; a3 += p[(long)(s + 3 * LANES) * C2];
+    }
+    for (; s < strips; s += LANES) a0 += p[(long)s * C2];
+  }
+  red[sl][col] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0) {
+    float t = 0.f;
+    for (int q = 0; q < LANES; q++) t += red[q][col];
+    tot[col] = t;
+    if (c < C2 && out) out[(long)g * C2 + c] = t;
+  }
+  __syncthreads();
+  if (sl == 0 && (col & 1) == 0 && c + 1 < C2) {
+    const long i = ((long)g * C2 + c) >> 1;                 // (group, channel)
+    const float m = tot[col] * inv_count;
+    float var = tot[col + 1] * inv_count - m * m;
+    var = var > 0.f ? var : 0.f;
+    mean[i] = m;
+    rstd[i] = rsqrtf(var + eps);
+    if (run_mean) {                                         // G == 1 (BatchNorm)
+      run_mean[i] = (1.f - momentum) * run_mean[i] + momentum * m;
+      run_var[i] = (1.f - momentum) * run_var[i] + momentum * var * unbias;
+    }
+  }
+}
+
+//  GRADS: bs[g][c] = (sum dz, sum dz * xhat) as above for EVERY group, then dw[ch] = sum_g bs[g][ch][1], db[ch] = sum_g bs[g][ch][0] --
+//         what norm_param_grads_kernel does.  A workgroup owns COLS consecutive columns of ALL groups.
+template <int COLS>
+__global__ __launch_bounds__(256) void finalize_grads_kernel(const float* __restrict__ part, float* __restrict__ bs, int G, int strips, int C2,
+                                                             float* __restrict__ dw, float* __restrict__ db) {
+  constexpr int LANES = 256 / COLS;
+  __shared__ float red[LANES][COLS + 1];
+  const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+  const int c = blockIdx.x * COLS + col;
+  float over_g = 0.f;
+  for (int g = 0; g < G; g++) {
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C2) {
+      const float* p = part + (long)g * strips * C2 + c;
+      int s = sl;
+      for (; s + LANES < strips; s += 2 * LANES) { a0 += p[(long)s * C2]; a1 += p[(long)(s + LANES) * C2]; }
+      for (; s < strips; s += LANES) a0 += p[(long)s * C2];
+    }
+    red[sl][col] = a0 + a1;
+    __syncthreads();
+    if (sl == 0 && c < C2) {
+      float t = 0.f;
+      for (int q = 0; q < LANES; q++) t += red[q][col];
+      bs[(long)g * C2 + c] = t;
+      over_g += t;
+    }
+    __syncthreads();
+  }
+  if (sl == 0 && c < C2) {
+    if (c & 1) dw[c >> 1] = over_g; else db[c >> 1] = over_g;
+  }
+}
+
 // launches the strip kernel through `launch(part)` and, in two-stage mode, the finalize kernel
 template <typename L>
 int strip_launch(float* out, float* ws, long ws_elems, int G, long strips, int C, hipStream_t st, L launch, int first_only = 0) {
@@ -673,6 +752,70 @@ extern "C" int du_norm_act_bwd_stats(int dtype, const void* x, int64_t ldx, cons
     if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_bwd_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, part);
     else hipLaunchKernelGGL(norm_act_bwd_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, part);
   });
+}
+
+namespace {
+int launch_finalize_stats(const float* part, float* sums, int G, long strips, int C, float count, float eps, float* mean, float* rstd,
+                          float* run_mean, float* run_var, float momentum, hipStream_t st) {
+  const float unbias = count > 1.f ? count / (count - 1.f) : 1.f;
+  if ((long)G * C * 2 >= 4096) {
+    const int chunks = (C * 2 + 31) / 32;
+    hipLaunchKernelGGL(finalize_stats_kernel<32>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, part, sums, G, (int)strips, C * 2, 1.f / count, eps,
+                       mean, rstd, run_mean, run_var, momentum, unbias);
+  } else {
+    const int chunks = (C * 2 + 3) / 4;
+    hipLaunchKernelGGL(finalize_stats_kernel<4>, dim3((unsigned)(G * chunks)), dim3(256), 0, st, part, sums, G, (int)strips, C * 2, 1.f / count, eps,
+                       mean, rstd, run_mean, run_var, momentum, unbias);
+  }
+  return du_check_launch();
+}
+}  // namespace
+
+// du_strip_finalize + du_norm_stats_finalize in one launch (statistics partials from a convolution epilogue); sums (nullable) also gets
+// the (G, C, 2) totals
+extern "C" int du_strip_finalize_norm(const float* part, float* sums, int G, int strips, int C, float count, float eps, float* mean,
+                                      float* rstd, float* run_mean, float* run_var, float momentum, void* stream) {
+  if (!part || !mean || !rstd || G <= 0 || strips <= 0 || C <= 0 || count <= 0.f) return DU_ERR_BAD_ARG;
+  if (run_mean && (G != 1 || !run_var)) return DU_ERR_BAD_ARG;
+  return launch_finalize_stats(part, sums, G, strips, C, count, eps, mean, rstd, run_mean, run_var, momentum, (hipStream_t)stream);
+}
+
+// du_chan_stats + du_norm_stats_finalize: strip partials, then ONE kernel for totals, mean / rstd and the running statistics.  Needs the
+// scratch (du_reduce_ws_elems); count = pixels per group the statistics are taken over
+extern "C" int du_chan_stats_norm(int dtype, const void* x, int64_t ldx, float* sums, int G, int64_t P, int C, float* ws, int64_t ws_elems,
+                                  float count, float eps, float* mean, float* rstd, float* run_mean, float* run_var, float momentum,
+                                  void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (G <= 0 || P <= 0 || C <= 0 || C % v || ldx % v || !x || !mean || !rstd || count <= 0.f) return DU_ERR_BAD_ARG;
+  if (dtype != DU_BF16 && dtype != DU_F32) return DU_ERR_BAD_ARG;
+  if (run_mean && (G != 1 || !run_var)) return DU_ERR_BAD_ARG;
+  const int STRIP = pick_strip(G, P, C, v);
+  const long strips = (P + STRIP - 1) / STRIP;
+  if (!ws || ws_elems < (long)G * strips * C * 2) return DU_ERR_BAD_ARG;
+  dim3 grid((unsigned)(G * strips)), block(256);
+  if (dtype == DU_BF16) hipLaunchKernelGGL(chan_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, sums, G, P, C, STRIP, ws);
+  else hipLaunchKernelGGL(chan_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, sums, G, P, C, STRIP, ws);
+  return launch_finalize_stats(ws, sums, G, strips, C, count, eps, mean, rstd, run_mean, run_var, momentum, st);
+}
+
+// du_norm_act_bwd_stats + du_norm_param_grads: strip partials, then ONE kernel for bsums (G, C, 2), dw (C) and db (C).  Needs the scratch
+extern "C" int du_norm_act_bwd_stats_grads(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* mean,
+                                           const float* rstd, const float* w, const float* b, float* bsums, float* dw, float* db, int G,
+                                           int64_t P, int C, int act, float* ws, int64_t ws_elems, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int v = dtype == DU_BF16 ? 8 : 4;
+  if (G <= 0 || P <= 0 || C <= 0 || C % v || ldx % v || lddy % v || !bsums || !dw || !db) return DU_ERR_BAD_ARG;
+  if (dtype != DU_BF16 && dtype != DU_F32) return DU_ERR_BAD_ARG;
+  const int STRIP = pick_strip(G, P, C, v);
+  const long strips = (P + STRIP - 1) / STRIP;
+  if (!ws || ws_elems < (long)G * strips * C * 2) return DU_ERR_BAD_ARG;
+  dim3 grid((unsigned)(G * strips)), block(256);
+  if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_bwd_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, ws);
+  else hipLaunchKernelGGL(norm_act_bwd_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, ws);
+  if ((long)C * 2 >= 512) hipLaunchKernelGGL(finalize_grads_kernel<32>, dim3((unsigned)((C * 2 + 31) / 32)), dim3(256), 0, st, (const float*)ws, bsums, G, (int)strips, C * 2, dw, db);
+  else hipLaunchKernelGGL(finalize_grads_kernel<4>, dim3((unsigned)((C * 2 + 3) / 4)), dim3(256), 0, st, (const float*)ws, bsums, G, (int)strips, C * 2, dw, db);
+  return du_check_launch();
 }
 
 extern "C" int du_norm_act_bwd_dx(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx,

@@ -1021,25 +1021,35 @@ class _NormAct(torch.autograd.Function):
         count = None
         if use_batch:
             G = B if kind == "in" else 1
-            if stats_part is not None:
-                # per-tile partials from the producing convolution's epilogue (tiles of one image are contiguous)
-                P = (B // G) * H * W
-                sums = torch.empty((G, Cc, 2), dtype=torch.float32, device=x.device)
-                _lib.check(_lib.lib().du_strip_finalize(_p(stats_part), _p(sums), G, stats_part.shape[0] // G, Cc, _st()),
-                           "du_strip_finalize")
-            else:
-                sums, P = chan_stats(x, G)
+            P = (B // G) * H * W
             count = float(P)
-            if kind == "bn" and group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
-                sums = sums.clone()
-                torch.distributed.all_reduce(sums, group=group)   # equal per-rank batch (TRN:322-327 splits evenly)
-                count = count * torch.distributed.get_world_size(group)
             mean = torch.empty((G, Cc), dtype=torch.float32, device=x.device)
             rstd = torch.empty((G, Cc), dtype=torch.float32, device=x.device)
             upd = kind == "bn" and running_mean is not None
-            _lib.check(_lib.lib().du_norm_stats_finalize(_p(sums), count, eps, _p(mean), _p(rstd), G, Cc,
-                                                         _p(running_mean) if upd else None, _p(running_var) if upd else None,
-                                                         float(momentum), _st()), "du_norm_stats_finalize")
+            rm, rv = (_p(running_mean), _p(running_var)) if upd else (None, None)
+            synced = kind == "bn" and group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1
+            L = _lib.lib()
+            if not synced:
+                # totals, mean / rstd and the running statistics in ONE launch behind the partials (du_*_norm)
+                if stats_part is not None:
+                    # per-tile partials from the producing convolution's epilogue (tiles of one image are contiguous)
+                    _lib.check(L.du_strip_finalize_norm(_p(stats_part), None, G, stats_part.shape[0] // G, Cc, count, eps, _p(mean), _p(rstd),
+                                                        rm, rv, float(momentum), _st()), "du_strip_finalize_norm")
+                else:
+                    ws, n = _reduce_ws(x.dtype, G, P, Cc, x.device)
+                    _lib.check(L.du_chan_stats_norm(_code(x.dtype), _p(x), ld, None, G, P, Cc, _p(ws), n, count, eps, _p(mean), _p(rstd),
+                                                    rm, rv, float(momentum), _st()), "du_chan_stats_norm")
+            else:
+                if stats_part is not None:
+                    sums = torch.empty((G, Cc, 2), dtype=torch.float32, device=x.device)
+                    _lib.check(L.du_strip_finalize(_p(stats_part), _p(sums), G, stats_part.shape[0] // G, Cc, _st()), "du_strip_finalize")
+                else:
+                    sums, P = chan_stats(x, G)
+                sums = sums.clone()
+                torch.distributed.all_reduce(sums, group=group)   # equal per-rank batch (TRN:322-327 splits evenly)
+                count = count * torch.distributed.get_world_size(group)
+                _lib.check(L.du_norm_stats_finalize(_p(sums), count, eps, _p(mean), _p(rstd), G, Cc, rm, rv, float(momentum), _st()),
+                           "du_norm_stats_finalize")
         else:
             G, P = 1, B * H * W
             mean = running_mean.float().view(1, Cc)
@@ -1059,11 +1069,10 @@ class _NormAct(torch.autograd.Function):
         L = _lib.lib()
         bs = torch.empty((G, Cc, 2), dtype=torch.float32, device=x.device)
         ws, n = _reduce_ws(x.dtype, G, P, Cc, x.device)
-        _lib.check(L.du_norm_act_bwd_stats(_code(x.dtype), _p(x), ld, _p(dy), Cc, _p(mean), _p(rstd), _p(wf), _p(bf), _p(bs), G, P,
-                                           Cc, act, _p(ws), n, _st()), "du_norm_act_bwd_stats")
         dw = torch.empty(Cc, dtype=torch.float32, device=x.device)
         db = torch.empty(Cc, dtype=torch.float32, device=x.device)
-        _lib.check(L.du_norm_param_grads(_p(bs), _p(dw), _p(db), G, Cc, _st()), "du_norm_param_grads")
+        _lib.check(L.du_norm_act_bwd_stats_grads(_code(x.dtype), _p(x), ld, _p(dy), Cc, _p(mean), _p(rstd), _p(wf), _p(bf), _p(bs), _p(dw),
+                                                 _p(db), G, P, Cc, act, _p(ws), n, _st()), "du_norm_act_bwd_stats_grads")
         bsr = bs
         if kind == "bn" and use_batch and group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
             bsr = bs.clone()

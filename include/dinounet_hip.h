@@ -177,6 +177,18 @@ int du_norm_stats_finalize(const float* sums, float count, float eps, float* mea
                            float* run_var, float momentum, void* stream);
 /* affine-parameter gradients from the backward sums: dw[c] = sum_g bsums[g][c][1], db[c] = sum_g bsums[g][c][0] */
 int du_norm_param_grads(const float* bsums, float* dw, float* db, int G, int C, void* stream);
+/* Fused forms (one launch less each: a launch of this size costs ~5 us inside the replayed graph).  All three need the scratch of
+   du_reduce_ws_elems (no atomics fallback):
+   du_chan_stats_norm       = du_chan_stats + du_norm_stats_finalize (sums nullable);
+   du_strip_finalize_norm   = du_strip_finalize + du_norm_stats_finalize, for statistics partials from a convolution epilogue;
+   du_norm_act_bwd_stats_grads = du_norm_act_bwd_stats + du_norm_param_grads (bsums, dw, db all written). */
+int du_chan_stats_norm(int dtype, const void* x, int64_t ldx, float* sums, int G, int64_t pix_per_group, int C, float* ws, int64_t ws_elems,
+                       float count, float eps, float* mean, float* rstd, float* run_mean, float* run_var, float momentum, void* stream);
+int du_strip_finalize_norm(const float* part, float* sums, int G, int strips, int C, float count, float eps, float* mean, float* rstd,
+                           float* run_mean, float* run_var, float momentum, void* stream);
+int du_norm_act_bwd_stats_grads(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* mean, const float* rstd,
+                                const float* w, const float* b, float* bsums, float* dw, float* db, int G, int64_t pix_per_group, int C,
+                                int act, float* ws, int64_t ws_elems, void* stream);
 /* y = act((x - mean[g,c]) * rstd[g,c] * w[c] + b[c]); mean/rstd: (G, C) fp32. */
 int du_norm_act_fwd(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* mean, const float* rstd,
                     const float* w, const float* b, int G, int64_t pix_per_group, int C, int act, void* stream);
