@@ -34,7 +34,7 @@ class GemmArgs(C.Structure):
                 ("row_scale", C.c_void_p), ("rs_rows", C.c_int32),
                 ("residual", C.c_void_p), ("ldr", C.c_int64),
                 ("store_mode", C.c_int32), ("ps_H", C.c_int32), ("ps_W", C.c_int32), ("ps_C", C.c_int32),
-                ("geom", ConvGeom), ("ws", C.c_void_p), ("ws_elems", C.c_int64)]
+                ("geom", ConvGeom), ("ws", C.c_void_p), ("ws_elems", C.c_int64), ("a_colsum", C.c_void_p)]
 
 
 _CTYPE = {"int": C.c_int, "int64_t": C.c_int64, "float": C.c_float, "int32_t": C.c_int32}

@@ -202,6 +202,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+  // bias-gradient side sum (du_gemm_args.a_colsum, weight-gradient products): sum_k A(m, k) for this tile's rows, taken by ONE tile column
+  // per (tile row, split) -- tn == split % tiles_n spreads that extra VALU work over the workgroups -- from the A fragments the MFMAs
+  // consume anyway (lane l holds row (l & 31), 8 consecutive k per k-step: every k of the tile exactly once across the two half-waves)
+  const bool colsum_on = (AMODE == DU_PLAIN_COL) && P.a_colsum && wn == 0 && tn == split % P.tiles_n;
+  float csum[TM];
+#pragma unroll
+  for (int i = 0; i < TM; i++) csum[i] = 0.f;
+
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk > 0) {
     la.load(opa, tid, m0, P.M, kbeg, kend);
@@ -227,6 +235,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
       for (int i = 0; i < TM; i++) fa[i] = Loader<AMODE, BM>::frag(Ac, (wm * TM + i) * 32, kk, lane);
 #pragma unroll
       for (int j = 0; j < TN; j++) fb[j] = Loader<BMODE, BN>::frag(Bc, (wn * TN + j) * 32, kk, lane);
+      if constexpr (AMODE == DU_PLAIN_COL) {
+        if (colsum_on) {
+#pragma unroll
+          for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) csum[i] += (float)fa[i][e];
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -239,6 +255,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
     __syncthreads();
   }
 
+  if constexpr (AMODE == DU_PLAIN_COL) {
+    if (colsum_on) {
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const int m = m0 + (wm * TM + i) * 32 + (lane & 31);
+        if (m < P.M) atomic_add_f32(P.a_colsum + m, csum[i]);
+      }
+    }
+  }
   TC* Cb = (TC*)P.C + (long)batch * P.cbs;
   // ---- split-K: fp32 atomics straight from the accumulators (lanes 0..31 = 32 consecutive columns) ----
   if (P.split_k > 1) {

@@ -298,6 +298,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
   int tm, tn;
   int nk = P.K / PBK;
   long kbeg = 0;                      // TN: first contraction row of this workgroup's split
+  int my_split = 0;
   if constexpr (TN) {
     // workgroup -> (split, tile): the XCD-contiguous linear index walks the tiles of one split before the next split, so the
     // workgroups that share a K range (and with it the A / B panels) sit on one XCD's L2
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
     const int first = split * base + min(split, extra);
     kbeg = (long)first * (2 * PBK);
     nk = 2 * (base + (split < extra ? 1 : 0));
+    my_split = split;
   } else {
     tile_coords(P, tm, tn);
   }
@@ -501,6 +503,23 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
         else acc[i][j][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[bset][kk], Af[i][b][kk], acc[i][j][b], 0, 0, 0);
       }
   };
+  // bias-gradient side sum of the weight-gradient form (du_gemm_args.a_colsum): sum_k A(m, k) from the A fragments, once per fragment
+  // set (phases q0 / q3 = the j == 0 products), by the two waves with wn == 0 of ONE tile column per (tile row, split)
+  const bool colsum_on = TN && P.a_colsum != nullptr && wn == 0 && tn == my_split % P.tiles_n;
+  float csum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};      // [A half i][row block b]
+  auto colsum_acc = [&](auto i_c) {
+    constexpr int i = decltype(i_c)::value;
+    if constexpr (TN) {
+      if (colsum_on) {
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) csum[i][b] += (float)Af[i][b][kk][e];
+      }
+    }
+  };
   // pin the issue order of a phase.  The compiler orders every ds_read of the phase before its LDS-DMA issues (it must assume they
   // alias), so the reads ride behind the first four MFMAs and the two DMA issues behind the next two.
   auto pin = [&](auto nrd_c) {
@@ -538,6 +557,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
     if (!TAIL || t + 2 < nk) stage(IC<2>{}, IC<p>{}, t + 2);
     mma(IC<0>{}, IC<0>{}, IC<b0set>{});
     pin(IC<4>{});
+    colsum_acc(IC<0>{});
     finish(0);
     // q1
     readA(IC<1>{}, IC<p>{});
@@ -556,6 +576,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
     if (!TAIL || t + 3 < nk) stage(IC<0>{}, IC<1 - p>{}, t + 3);
     mma(IC<1>{}, IC<0>{}, IC<b0set>{});
     pin(IC<4>{});
+    colsum_acc(IC<1>{});
     finish(3);
   };
 
@@ -587,6 +608,15 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
   if (Rb) Rb += (long)batch * P.cbs;
   if (P.dbg & 2) return;            // measurement aid (du_set_option key 3): no epilogue at all
   if constexpr (TN) {
+    if (colsum_on) {
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          const int m = m0 + i * 128 + wm * 64 + b * 32 + (lane & 31);
+          if (m < P.M) atomic_add_f32(P.a_colsum + m, csum[i][b]);
+        }
+    }
     // split-K partial: fp32 atomics into the (zeroed) result.  Register r of a 32 x 32 block = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5),
     // lanes 0..31 = 32 consecutive columns (one 128-byte segment per row)
     const int hi = lane >> 5;

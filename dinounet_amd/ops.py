@@ -118,6 +118,11 @@ _MODE_NAMES = {(0, 0): "linear", (0, 1): "linear_dgrad", (1, 1): "linear_wgrad",
 _ROUTE_NAMES = {0: "gemm_kernel", 1: "gemm_bf16_kernel", 2: "gemm_nt_glds_kernel", 3: "gemm_nt_p8_kernel", 4: "gemm_nt_p8n_kernel", 5: "gemm_tn_p8_kernel"}
 
 
+def gemm_route(**kw):
+    """kernel family du_gemm would run for these gemm_raw arguments (du_gemm_route)"""
+    return gemm_raw(route_only=True, **kw)
+
+
 TRACK_ROUTE = False          # tests: record the kernel family of the last product (du_gemm_route) in LAST_GEMM_ROUTE
 LAST_GEMM_ROUTE = -1
 ROUTES = []                  # (a_mode, b_mode, route) of every product since TRACK_ROUTE was switched on
@@ -125,7 +130,7 @@ ROUTES = []                  # (a_mode, b_mode, route) of every product since TR
 
 def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat, ldc, batch=1, abs_=0, bbs=0, cbs=0,
              split_k=1, alpha=1.0, bias=None, act=ACT_NONE, gamma=None, row_scale=None, rs_rows=0, residual=None, ldr=0,
-             store_mode=0, ps=(0, 0, 0), geom=None):
+             store_mode=0, ps=(0, 0, 0), geom=None, a_colsum=None, route_only=False):
     a = GemmArgs()
     a.dtype, a.out_dtype, a.a_mode, a.b_mode = dtype, out_dtype, a_mode, b_mode
     a.M, a.N, a.K = M, N, K
@@ -142,6 +147,9 @@ def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat,
     a.ps_H, a.ps_W, a.ps_C = ps
     if geom is not None:
         a.geom = geom
+    a.a_colsum = a_colsum
+    if route_only:
+        return int(_lib.lib().du_gemm_route(C.byref(a)))
     ws = None
     if dtype == DU_BF16 and a_mode == PLAIN_ROW and b_mode == PLAIN_ROW and M >= 1024 and 0 < M % 128 <= 64:
         # tall product with a short ragged last tile row: lend the library the scratch of its K-parallel tail kernels (gemm_skinny.hip)
@@ -474,18 +482,31 @@ def _split_for(tiles, kdim, target=512):
     return max(1, s)
 
 
-def mm_wgrad(dy, x):
-    """dw[n][k] = sum_m dy[m][n] * x[m][k]  -> fp32 (N,K); split-K over the rows with fp32 atomics."""
+_WGRAD_COLSUM = os.environ.get("DINOUNET_WGRAD_COLSUM", "1") == "1"
+
+
+def mm_wgrad(dy, x, with_colsum=False):
+    """dw[n][k] = sum_m dy[m][n] * x[m][k]  -> fp32 (N,K); split-K over the rows with fp32 atomics.
+    with_colsum: also return the bias gradient db[n] = sum_m dy[m][n] -- taken inside the weight-gradient kernel from the dY fragments
+    it streams anyway (du_gemm_args.a_colsum) where the kernel family can, by du_colsum (two more launches, one more pass over dY)
+    otherwise."""
     _req(dy, x)
     Mr, N, lda = _rows2d(dy)
     Mr2, K, ldb = _rows2d(x)
     assert Mr == Mr2 and dy.dtype == x.dtype
     out = ZEROS.zeros((N, K), dy.device)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    gemm_raw(dtype=_code(dy.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=PLAIN_COL, M=N, N=K, K=Mr,
-             A=dy.data_ptr(), lda=lda, B=x.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=K,
-             split_k=_split_for(tiles, Mr))
-    return out
+    kw = dict(dtype=_code(dy.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=PLAIN_COL, M=N, N=K, K=Mr,
+              A=dy.data_ptr(), lda=lda, B=x.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=K, split_k=_split_for(tiles, Mr))
+    if not with_colsum:
+        gemm_raw(**kw)
+        return out
+    if _WGRAD_COLSUM and dy.dtype == torch.bfloat16 and gemm_route(**kw) in (1, 5):
+        db = ZEROS.zeros((N,), dy.device)
+        gemm_raw(a_colsum=db.data_ptr(), **kw)
+        return out, db
+    gemm_raw(**kw)
+    return out, colsum(dy)
 
 
 def _reduce_ws(dt, G, P, Cc, device):
@@ -765,8 +786,15 @@ class _Linear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = mm(dyc, ctx.wT) if ctx.wT is not None else mm_dgrad(dyc, wq)
-        dw = mm_wgrad(dyc, x) if ctx.needs_input_grad[1] else None
-        db = colsum(dyc) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            if want_db:
+                dw, db = mm_wgrad(dyc, x, with_colsum=True)
+            else:
+                dw = mm_wgrad(dyc, x)
+        elif want_db:
+            db = colsum(dyc)
         return dx, dw, db, dres, None, None, None
 
 
@@ -814,11 +842,12 @@ class _LinearCat(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = mm(dyc, ctx.wT) if ctx.wT is not None else mm_dgrad(dyc, wq)
-        dw = mm_wgrad(dyc, x)
         db1 = db2 = None
         if has_bias:
-            db = colsum(dyc)
+            dw, db = mm_wgrad(dyc, x, with_colsum=True)
             db1, db2 = db[:n1], db[n1:]
+        else:
+            dw = mm_wgrad(dyc, x)
         return dx, dw[:n1].view(s1), dw[n1:].view(s2), db1, db2, None
 
 
@@ -898,16 +927,19 @@ class _FAPMProject(torch.autograd.Function):
             mm(dgb, ctx.wfT, out=dz2[:, :R])
         else:
             mm_dgrad(dgb, wfq, out=dz2[:, :R])
-        dwf = mm_wgrad(dgb, z2[:, :R])
-        dbf = colsum(dgb) if has_bf else None
+        if has_bf:
+            dwf, dbf = mm_wgrad(dgb, z2[:, :R], with_colsum=True)
+        else:
+            dwf, dbf = mm_wgrad(dgb, z2[:, :R]), None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = (mm(dz2, ctx.wqT) if ctx.wqT is not None else mm_dgrad(dz2, wq)).view(B, H, W, Cc)
-        dw = mm_wgrad(dz2, xm)
         dbs = dbp = None
         if has_b:
-            db = colsum(dz2)
+            dw, db = mm_wgrad(dz2, xm, with_colsum=True)
             dbs, dbp = db[:R], db[R:]
+        else:
+            dw = mm_wgrad(dz2, xm)
         return dx, dw[:R].view(s_ws), dw[R:].view(s_wp), dbs, dbp, dwf.view(s_wf), dbf
 
 

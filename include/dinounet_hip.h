@@ -106,6 +106,10 @@ typedef struct {
   du_conv_geom geom;  /* used by the IM2COL operand (at most one operand is IM2COL) */
   float* ws; int64_t ws_elems; /* optional scratch, du_gemm_ws_elems(args) floats (0 = none wanted for this product); without it the
                                   product still runs, on the plain tile kernels */
+  float* a_colsum;    /* optional, weight-gradient products only (a_mode PLAIN_COL, bf16): a_colsum[m] += sum_k A(m, k), fp32 atomics
+                         into a buffer the caller zero-initialised -- the bias gradient sum_rows dY for free while dY^T X streams dY
+                         anyway (nn.Linear backward).  du_gemm returns DU_ERR_UNSUPPORTED if the kernel family serving the product
+                         cannot do it (du_gemm_route != 1 and != 5): call du_colsum then */
 } du_gemm_args;
 
 int du_gemm(const du_gemm_args* args, void* stream);

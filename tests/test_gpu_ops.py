@@ -169,8 +169,11 @@ def test_gemm_multiphase_wgrad(rows, N, K):
         outs = {}
         for flag in (2, 0):
             L.du_set_option(5, flag)
-            outs[flag] = ops.mm_wgrad(dy.to(d, dt), x.to(d, dt)).float().cpu()
+            # with_colsum: the bias gradient sum_rows dy taken inside the weight-gradient kernel (du_gemm_args.a_colsum), both families
+            dw, db = ops.mm_wgrad(dy.to(d, dt), x.to(d, dt), with_colsum=True)
+            outs[flag] = dw.float().cpu()
             assert (ops.LAST_GEMM_ROUTE == 5) == (flag == 2), ops.LAST_GEMM_ROUTE
+            assert rel(db, dy.double().sum(0).float()) < 2e-5, flag
     finally:
         L.du_set_option(5, 1)
         ops.TRACK_ROUTE = False

@@ -1,0 +1,7 @@
+import sqlite3,sys,re
+c=sqlite3.connect(sys.argv[1]); steps=int(sys.argv[2])
+rows=c.execute("select name, count(*), sum(end-start) from kernels group by name order by count(*) desc").fetchall()
+tot=sum(r[1] for r in rows)
+print(f"# {tot} dispatches = {tot/steps:.0f} per step; kernels sorted by launch count")
+for n,k,ns in rows[:45]:
+    print(f"{k/steps:7.1f}/step {ns/k/1e3:8.2f} us avg {ns/steps/1e6:7.3f} ms/step  {n[:110]}")
