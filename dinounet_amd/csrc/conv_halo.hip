@@ -273,8 +273,9 @@ struct WgradParams {
   const bf16_t* x; long ldx; const bf16_t* x2; long ldx2; int C1, Cin, Cout;
   const bf16_t* dy; long lddy;
   int B, H, W;
-  float* part;              // [gridDim.x][Cout][9 * Cin] fp32
+  float* part;              // [gridDim.x][Cout * 9 * Cin (+ Cout with with_db)] fp32
   int tilesX, tilesY, ntiles;
+  int with_db;              // also emit the bias gradient: per-workgroup column sums of dY behind the slab's weight part
 };
 
 template <int CK, int MT>
@@ -331,7 +332,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_halo_kernel(WgradParams P) 
       yreg[i] = r;
     }
   };
-  auto stores = [&]() {
+  // bias gradient (with_db): 256 % DV == 0, so a thread's dY vectors always cover the same 8 channels (tid % DV): it keeps their sums over
+  // all its tiles of chunk 0 in registers; reduced over the threads through LDS after the tile loop
+  float dbs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto stores = [&](bool sum_dy) {
 #pragma unroll
     for (int i = 0; i < HV; i++) {
       const int v = tid + i * 256;
@@ -340,7 +344,14 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_halo_kernel(WgradParams P) 
 #pragma unroll
     for (int i = 0; i < YV; i++) {
       const int v = tid + i * 256;
-      if (v < 128 * DV) *(uint4*)(Ys + (v / DV) * PD + (v % DV) * 8) = yreg[i];
+      if (v < 128 * DV) {
+        *(uint4*)(Ys + (v / DV) * PD + (v % DV) * 8) = yreg[i];
+        if (sum_dy) {
+          const bf16x8 t = __builtin_bit_cast(bf16x8, yreg[i]);
+#pragma unroll
+          for (int e = 0; e < 8; e++) dbs[e] += (float)t[e];
+        }
+      }
     }
   };
   auto trfrag = [&](const bf16_t* q, int pitch) -> bf16x8 {      // q: this lane's address of the first 4-pixel read
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_halo_kernel(WgradParams P) 
     int tile = blockIdx.x;
     loads(tile, ch);
     while (tile < P.ntiles) {
-      stores();
+      stores(P.with_db && ch == 0);
       __syncthreads();
       const int ntile = tile + gridDim.x;
       if (ntile < P.ntiles) loads(ntile, ch);
@@ -388,8 +399,21 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_halo_kernel(WgradParams P) 
       __syncthreads();
       tile = ntile;
     }
+    const long slab = (long)COUT * 9 * P.Cin + (P.with_db ? COUT : 0);
+    if (P.with_db && ch == 0) {        // every LDS read of the tile loop is behind its last barrier: Xs is free as scratch
+      float* red = (float*)smem_raw;   // [256][8]
+#pragma unroll
+      for (int e = 0; e < 8; e++) red[tid * 8 + e] = dbs[e];
+      __syncthreads();
+      if (tid < COUT) {                // channel tid = group (tid >> 3) element (tid & 7); contributors: threads with t % DV == tid >> 3
+        float sacc = 0.f;
+        for (int t = tid >> 3; t < 256; t += DV) sacc += red[t * 8 + (tid & 7)];
+        P.part[(long)blockIdx.x * slab + (long)COUT * 9 * P.Cin + tid] = sacc;
+      }
+      __syncthreads();
+    }
     // flush this chunk's tiles: part[block][co][tap * Cin + ch * CK + ci]
-    float* dst = P.part + (long)blockIdx.x * COUT * 9 * P.Cin;
+    float* dst = P.part + (long)blockIdx.x * slab;
 #pragma unroll
     for (int i = 0; i < TPW; i++) {
       const int t = wave + 4 * i;
@@ -431,7 +455,7 @@ extern "C" int du_conv3x3_wgrad_halo_blocks(int C1, int Cin, int Cout, int B, in
 // x / x2 as in du_conv3x3_halo, dy (B,H,W,Cout) bf16; part: du_conv3x3_wgrad_halo_blocks(...) x Cout x 9*Cin fp32 scratch;
 // dw (Cout, 9*Cin) fp32 in (tap, ci) column order is OVERWRITTEN (sum of the partial slabs, via du_strip_finalize).
 extern "C" int du_conv3x3_wgrad_halo(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int C1, int Cin, int Cout, int B, int H,
-                                     int W, const void* dy, int64_t lddy, float* part, float* dw, void* stream) {
+                                     int W, const void* dy, int64_t lddy, float* part, float* dw, int with_db, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!x || !dy || !part || !dw) return DU_ERR_BAD_ARG;
   if (!x2) C1 = Cin;
@@ -442,10 +466,12 @@ extern "C" int du_conv3x3_wgrad_halo(const void* x, int64_t ldx, const void* x2,
   P.x = (const bf16_t*)x; P.ldx = ldx; P.x2 = (const bf16_t*)x2; P.ldx2 = ldx2; P.C1 = C1; P.Cin = Cin; P.Cout = Cout;
   P.dy = (const bf16_t*)dy; P.lddy = lddy; P.B = B; P.H = H; P.W = W; P.part = part;
   P.tilesX = W / TW; P.tilesY = H / TH; P.ntiles = B * P.tilesX * P.tilesY;
+  P.with_db = with_db ? 1 : 0;
   const bool c64 = Cin % 64 == 0 && C1 % 64 == 0;
   int rc = DU_ERR_UNSUPPORTED;
   if (Cout == 32) rc = c64 ? launch_wgrad<64, 1>(P, blocks, st) : launch_wgrad<32, 1>(P, blocks, st);
   else if (Cout == 64) rc = launch_wgrad<32, 2>(P, blocks, st);        // 32-channel chunks: 5 accumulator tiles per wave, no spills
   if (rc != DU_OK) return rc;
-  return du_strip_finalize(part, dw, 1, blocks, Cout * 9 * Cin / 2, stream);   // finalize works on (C, 2) pairs: C = elements / 2
+  // finalize works on (C, 2) pairs: C = elements / 2; with_db the Cout bias-gradient sums ride behind the weight gradient
+  return du_strip_finalize(part, dw, 1, blocks, (Cout * 9 * Cin + (with_db ? Cout : 0)) / 2, stream);
 }

@@ -118,6 +118,9 @@ _MODE_NAMES = {(0, 0): "linear", (0, 1): "linear_dgrad", (1, 1): "linear_wgrad",
 _ROUTE_NAMES = {0: "gemm_kernel", 1: "gemm_bf16_kernel", 2: "gemm_nt_glds_kernel", 3: "gemm_nt_p8_kernel", 4: "gemm_nt_p8n_kernel", 5: "gemm_tn_p8_kernel"}
 
 
+_WGRAD_COLSUM = os.environ.get("DINOUNET_WGRAD_COLSUM", "1") == "1"     # bias gradients inside the weight-gradient kernels (A-B aid)
+
+
 def gemm_route(**kw):
     """kernel family du_gemm would run for these gemm_raw arguments (du_gemm_route)"""
     return gemm_raw(route_only=True, **kw)
@@ -482,9 +485,6 @@ def _split_for(tiles, kdim, target=512):
     return max(1, s)
 
 
-_WGRAD_COLSUM = os.environ.get("DINOUNET_WGRAD_COLSUM", "1") == "1"
-
-
 def mm_wgrad(dy, x, with_colsum=False):
     """dw[n][k] = sum_m dy[m][n] * x[m][k]  -> fp32 (N,K); split-K over the rows with fp32 atomics.
     with_colsum: also return the bias gradient db[n] = sum_m dy[m][n] -- taken inside the weight-gradient kernel from the dY fragments
@@ -623,8 +623,9 @@ def conv_dgrad(dy, wd, KH, KW, stride, pad, Hin, Win, out=None):
     return out
 
 
-def conv3x3_wgrad_halo(x, dy, x2=None):
-    """LDS-tiled 3x3 / stride 1 / pad 1 weight gradient (du_conv3x3_wgrad_halo) -> fp32 (Cout, 9*Cin), or None if not served."""
+def conv3x3_wgrad_halo(x, dy, x2=None, with_db=False):
+    """LDS-tiled 3x3 / stride 1 / pad 1 weight gradient (du_conv3x3_wgrad_halo) -> fp32 (Cout, 9*Cin), or None if not served.
+    with_db: -> (dw, db): the bias gradient (column sums of dy) rides behind the weight gradient in the same partial slabs."""
     if x.dtype != torch.bfloat16:
         return None
     B, H, W, C1, ld = _nhwc(x)
@@ -637,25 +638,30 @@ def conv3x3_wgrad_halo(x, dy, x2=None):
     blocks = int(L.du_conv3x3_wgrad_halo_blocks(C1, Cin, Cout, B, H, W))
     if blocks <= 0 or (Ho, Wo) != (H, W):
         return None
-    part = torch.empty((blocks, Cout, 9 * Cin), dtype=torch.float32, device=x.device)
-    dw = torch.empty((Cout, 9 * Cin), dtype=torch.float32, device=x.device)
+    nel = Cout * 9 * Cin + (Cout if with_db else 0)
+    part = torch.empty((blocks, nel), dtype=torch.float32, device=x.device)
+    out = torch.empty(nel, dtype=torch.float32, device=x.device)
+    dw = out[:Cout * 9 * Cin].view(Cout, 9 * Cin)
     e0 = PROFILE.start() if PROFILE is not None else None
-    rc = L.du_conv3x3_wgrad_halo(_p(x), ld, p2, ld2, C1, Cin, Cout, B, H, W, _p(dy), lddy, _p(part), _p(dw), _st())
+    rc = L.du_conv3x3_wgrad_halo(_p(x), ld, p2, ld2, C1, Cin, Cout, B, H, W, _p(dy), lddy, _p(part), _p(out), 1 if with_db else 0, _st())
     if rc == -2:
         return None
     _lib.check(rc, "du_conv3x3_wgrad_halo")
     if PROFILE is not None:
         PROFILE.stop("conv3x3_wgrad_halo_kernel<bf16>" + (f" {H}x{W} {Cin}->{Cout}" if PROFILE.detail else ""), e0,
                      2.0 * B * H * W * Cin * Cout * 9, 2.0 * B * H * W * (Cin + Cout))
-    return dw
+    return (dw, out[Cout * 9 * Cin:]) if with_db else dw
 
 
-def conv_wgrad(x, dy, KH, KW, stride, pad, x2=None):
-    """-> fp32 (Cout, KH*KW*C) in (tap, ci) column order."""
+def conv_wgrad(x, dy, KH, KW, stride, pad, x2=None, with_db=False):
+    """-> fp32 (Cout, KH*KW*C) in (tap, ci) column order; with_db: -> (dw, db), the bias gradient sum_pixels dy taken inside the
+    weight-gradient kernel where it can be (halo kernel: extra slab columns; implicit GEMM: du_gemm_args.a_colsum), else by du_colsum."""
     _req(x, dy)
     if KH == 3 and KW == 3 and stride == 1 and pad == 1:
-        r = conv3x3_wgrad_halo(x, dy, x2)
+        r = conv3x3_wgrad_halo(x, dy, x2, with_db and _WGRAD_COLSUM)
         if r is not None:
+            if with_db and not _WGRAD_COLSUM:
+                return r, colsum(dy.view(-1, dy.shape[-1]))
             return r
     Bo, Ho, Wo, Cout, lddy = _nhwc(dy)
     g, B, ld, Ct = _geom(x, KH, KW, stride, pad, Ho, Wo, 0, x2)
@@ -663,10 +669,18 @@ def conv_wgrad(x, dy, KH, KW, stride, pad, x2=None):
     out = ZEROS.zeros((Cout, Ncol), x.device)
     npix = B * Ho * Wo
     tiles = ((Cout + 127) // 128) * ((Ncol + 127) // 128)
-    gemm_raw(dtype=_code(x.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=IM2COL_COL, M=Cout, N=Ncol, K=npix,
-             A=dy.data_ptr(), lda=lddy, B=x.data_ptr(), ldb=ld, Cmat=out.data_ptr(), ldc=Ncol,
-             split_k=_split_for(tiles, npix, 1024), geom=g)
-    return out
+    kw = dict(dtype=_code(x.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=IM2COL_COL, M=Cout, N=Ncol, K=npix,
+              A=dy.data_ptr(), lda=lddy, B=x.data_ptr(), ldb=ld, Cmat=out.data_ptr(), ldc=Ncol,
+              split_k=_split_for(tiles, npix, 1024), geom=g)
+    if not with_db:
+        gemm_raw(**kw)
+        return out
+    if _WGRAD_COLSUM and x.dtype == torch.bfloat16 and gemm_route(**kw) == 1:
+        db = ZEROS.zeros((Cout,), x.device)
+        gemm_raw(a_colsum=db.data_ptr(), **kw)
+        return out, db
+    gemm_raw(**kw)
+    return out, colsum(dy.view(-1, dy.shape[-1]))
 
 
 class _Conv2d(torch.autograd.Function):
@@ -730,10 +744,13 @@ class _Conv2d(torch.autograd.Function):
                     dx = dfull
                 else:
                     dx, dx2 = dfull[..., :C1], dfull[..., C1:]
+        want_db = has_bias and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[2]:
-            g = conv_wgrad(x, dy, KH, KW, stride, pad, x2)
+            g = conv_wgrad(x, dy, KH, KW, stride, pad, x2, with_db=want_db)
+            if want_db:
+                g, db = g
             dw = g.view(w.shape[0], KH, KW, w.shape[1]).permute(0, 3, 1, 2).contiguous()
-        if has_bias and ctx.needs_input_grad[3]:
+        elif want_db:
             db = colsum(dy.view(-1, dy.shape[-1]))
         return dx, dx2, dw, db, None, None, None
 

@@ -131,10 +131,12 @@ int du_gemm_route(const du_gemm_args* args);
 int du_conv3x3_halo(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int C1, int Cin, int Cout, int B, int H, int W,
                     const void* w, const float* bias, void* y, int64_t ldy, float* stats_part, void* stream);
 /* Weight gradient of the same convolution, dw (Cout, 9*Cin) fp32 in (tap, ci) column order (OVERWRITTEN).  part: scratch of
-   du_conv3x3_wgrad_halo_blocks(...) * Cout * 9*Cin floats (0 blocks = shape not served -> use du_gemm's IM2COL_COL path). */
+   du_conv3x3_wgrad_halo_blocks(...) * Cout * 9*Cin floats (0 blocks = shape not served -> use du_gemm's IM2COL_COL path).
+   with_db != 0: the bias gradient db[co] = sum_pixels dy rides along -- dw then has Cout * 9*Cin + Cout elements (db behind the weight
+   gradient) and part blocks * (Cout * 9*Cin + Cout). */
 int du_conv3x3_wgrad_halo_blocks(int C1, int Cin, int Cout, int B, int H, int W);
 int du_conv3x3_wgrad_halo(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int C1, int Cin, int Cout, int B, int H, int W,
-                          const void* dy, int64_t lddy, float* part, float* dw, void* stream);
+                          const void* dy, int64_t lddy, float* part, float* dw, int with_db, void* stream);
 /* out[g][c][j] = sum_s part[g*strips + s][c][j]: second stage of the column reductions, exposed for producers that emit partials */
 int du_strip_finalize(const float* part, float* out, int G, int strips, int C, void* stream);
 
