@@ -339,7 +339,14 @@ extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
     if (a_i2c && a.K != g.KH * g.KW * g.C) return DU_ERR_BAD_ARG;
     if (b_i2c && a.N != g.KH * g.KW * g.C) return DU_ERR_BAD_ARG;
   }
-  if (a.split_k > 1 && (a.out_dtype != DU_F32 || a.bias || a.act || a.gamma || a.row_scale || a.residual || a.store_mode)) return DU_ERR_BAD_ARG;
+  // weight-gradient form (A contraction-major): row_scale scales the CONTRACTION rows (per-sample DropPath scale on dY); only the bf16
+  // tile engine implements it, and only for K tiles that lie inside one sample
+  const bool k_scale = a.row_scale && a.a_mode == DU_PLAIN_COL;
+  if (k_scale) {
+    const int route = a.dtype == DU_BF16 && !getenv("DU_GEMM_GENERIC") ? du_gemm_route_bf16(a) : 0;
+    if (route != 1 || a.rs_rows <= 0 || a.rs_rows % 64 || a.bias || a.act || a.gamma || a.residual || a.store_mode) return DU_ERR_UNSUPPORTED;
+  }
+  if (a.split_k > 1 && (a.out_dtype != DU_F32 || a.bias || a.act || a.gamma || (a.row_scale && !k_scale) || a.residual || a.store_mode)) return DU_ERR_BAD_ARG;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && a.residual && a.ldc % 1) return DU_ERR_BAD_ARG;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && (a.ps_C <= 0 || a.N != 4 * a.ps_C || a.M % (a.ps_H * a.ps_W))) return DU_ERR_BAD_ARG;
   if (a.a_colsum) {                      // bias-gradient side sum: only the bf16 weight-gradient kernels accumulate it

@@ -228,11 +228,26 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
     }
     const bf16_t* Ac = smem + cur * BUF_EL;
     const bf16_t* Bc = Ac + A_EL;
+    // weight-gradient form with a per-sample scale on the contraction rows (DropPath in backward: dW = (s . dY)^T X): the scale is uniform
+    // over a K tile (rs_rows % BK == 0, checked by the host); a zero scale (dropped sample) skips the tile's MFMAs altogether
+    float s_kt = 1.f;
+    if constexpr (AMODE == DU_PLAIN_COL) {
+      if (P.k_scale) s_kt = P.row_scale[(kbeg + kt * BK) / P.rs_rows];
+    }
+    if (s_kt != 0.f) {
 #pragma unroll
     for (int kk = 0; kk < BK / 16; kk++) {
       bf16x8 fa[TM], fb[TN];
 #pragma unroll
       for (int i = 0; i < TM; i++) fa[i] = Loader<AMODE, BM>::frag(Ac, (wm * TM + i) * 32, kk, lane);
+      if constexpr (AMODE == DU_PLAIN_COL) {
+        if (s_kt != 1.f) {
+#pragma unroll
+          for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) fa[i][e] = (bf16_t)((float)fa[i][e] * s_kt);      // rounds like the materialised s . dY did
+        }
+      }
 #pragma unroll
       for (int j = 0; j < TN; j++) fb[j] = Loader<BMODE, BN>::frag(Bc, (wn * TN + j) * 32, kk, lane);
       if constexpr (AMODE == DU_PLAIN_COL) {
@@ -247,6 +262,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
       for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
     }
     if (more) {
       la.store(smem + (cur ^ 1) * BUF_EL, tid);
@@ -315,7 +331,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
         float4 gg = *(const float4*)(P.gamma + n);
         o[0] *= gg.x; o[1] *= gg.y; o[2] *= gg.z; o[3] *= gg.w;
       }
-      if (P.row_scale) {
+      if (P.row_scale && !P.k_scale) {
         const float rs = P.row_scale[m / P.rs_rows];
 #pragma unroll
         for (int e = 0; e < 4; e++) o[e] *= rs;

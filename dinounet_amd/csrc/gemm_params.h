@@ -25,6 +25,7 @@ struct GemmParams {
   int tiles_m, group_m;   // grouped tile order (gemm_glds.hip): bands of group_m tile rows are walked column by column; 0 = row-major
   int dbg;                // measurement aids of gemm_p8.hip (du_set_option key 3); 0 in production
   float* a_colsum;        // weight-gradient kernels: a_colsum[m] += sum_k A(m, k) (bias gradient), fp32 atomics; NULL = off
+  int k_scale;            // weight-gradient form (A contraction-major): row_scale[k / rs_rows] scales the CONTRACTION rows of A, not output rows
 };
 
 // element offset of C / residual element (m, n) for row stride ld: plain rows, or the pixel-shuffle store of ConvTranspose2d k2 s2
@@ -105,6 +106,7 @@ inline GemmParams make_params(const du_gemm_args& a, int amode, int bmode, int B
   P.rs_rows = a.rs_rows > 0 ? a.rs_rows : 1; P.residual = a.residual; P.ldr = a.ldr;
   P.store_mode = a.store_mode; P.ps_H = a.ps_H; P.ps_W = a.ps_W; P.ps_C = a.ps_C;
   P.a_colsum = a.a_colsum;
+  P.k_scale = (amode == DU_PLAIN_COL && a.row_scale) ? 1 : 0;
   P.tiles_n = (a.N + BN - 1) / BN;
   (void)BM;
   return P;

@@ -117,6 +117,7 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = drop_prob
         self.pinned_mask = None             # test hook: a fixed per-sample mask instead of the device RNG draw
+        self.predrawn = None                # this forward's mask, drawn for all DropPath modules at once by DINOv3_Adapter.forward
 
     def mask(self, B, device):
         """ADP:18-26: per-sample Bernoulli(keep)/keep, or None when inactive."""
@@ -124,6 +125,9 @@ class DropPath(nn.Module):
             return None
         if self.pinned_mask is not None:            # parity tests feed the mask the reference was given (already / keep_prob)
             return self.pinned_mask.to(device=device, dtype=torch.float32)
+        if self.predrawn is not None and self.predrawn.shape[0] == B:
+            m, self.predrawn = self.predrawn, None
+            return m
         keep = 1 - self.drop_prob
         m = torch.empty(B, device=device, dtype=torch.float32).bernoulli_(keep)
         if keep > 0.0:
@@ -323,6 +327,17 @@ class DINOv3_Adapter(nn.Module):
         shapes = [(H_t, W_t)]
 
         del _BN_TICKS[:]                                        # nothing left over from an interrupted forward
+        if self.training:
+            # all DropPath masks of this forward in one draw (ADP:18-26 draws per call: same distribution, 2 launches instead of 12)
+            dps = [m for m in self.modules() if isinstance(m, DropPath) and m.drop_prob > 0.0 and m.pinned_mask is None]
+            keeps = {1 - m.drop_prob for m in dps}
+            if len(dps) > 1 and len(keeps) == 1:
+                keep = keeps.pop()
+                tbl = torch.empty((len(dps), x.shape[0]), device=x.device, dtype=torch.float32).bernoulli_(keep)
+                if keep > 0.0:
+                    tbl.div_(keep)
+                for i, m in enumerate(dps):
+                    m.predrawn = tbl[i]
         x8 = ops.nchw_to_nhwc(x, dt, 8)
         c1, c2, c3, c4 = self.spm(x8, self.level_embed, group)                              # ADP:412-413
         n2, n3 = c2.shape[1], c3.shape[1]

@@ -119,6 +119,7 @@ _ROUTE_NAMES = {0: "gemm_kernel", 1: "gemm_bf16_kernel", 2: "gemm_nt_glds_kernel
 
 
 _WGRAD_COLSUM = os.environ.get("DINOUNET_WGRAD_COLSUM", "1") == "1"     # bias gradients inside the weight-gradient kernels (A-B aid)
+_KSCALE = os.environ.get("DINOUNET_WGRAD_KSCALE", "1") == "1"           # DropPath scale inside the backward GEMMs (A-B aid)
 
 
 def gemm_route(**kw):
@@ -485,7 +486,7 @@ def _split_for(tiles, kdim, target=512):
     return max(1, s)
 
 
-def mm_wgrad(dy, x, with_colsum=False):
+def mm_wgrad(dy, x, with_colsum=False, k_scale=None):
     """dw[n][k] = sum_m dy[m][n] * x[m][k]  -> fp32 (N,K); split-K over the rows with fp32 atomics.
     with_colsum: also return the bias gradient db[n] = sum_m dy[m][n] -- taken inside the weight-gradient kernel from the dY fragments
     it streams anyway (du_gemm_args.a_colsum) where the kernel family can, by du_colsum (two more launches, one more pass over dY)
@@ -498,6 +499,15 @@ def mm_wgrad(dy, x, with_colsum=False):
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     kw = dict(dtype=_code(dy.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=PLAIN_COL, M=N, N=K, K=Mr,
               A=dy.data_ptr(), lda=lda, B=x.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=K, split_k=_split_for(tiles, Mr))
+    if k_scale is not None:
+        # k_scale = (per-sample scale (B,) fp32, rows per sample): scales the contraction rows of dy inside the kernel (du_gemm: row_scale
+        # with a contraction-major A).  Only the bf16 tile engine does it; otherwise the scaled copy is built here
+        kws = dict(kw, row_scale=k_scale[0].data_ptr(), rs_rows=k_scale[1])
+        if gemm_route(**kws) == 1:
+            kw = kws
+        else:
+            dy = (dy.view(k_scale[0].numel(), k_scale[1], -1) * k_scale[0].view(-1, 1, 1).to(dy.dtype)).view(dy.shape)
+            kw = dict(kw, A=dy.data_ptr(), lda=dy.stride(0))
     if not with_colsum:
         gemm_raw(**kw)
         return out
@@ -798,20 +808,31 @@ class _Linear(torch.autograd.Function):
         dyc = dy if dy.stride(1) == 1 else dy.contiguous()
         if dyc.dtype != x.dtype:
             dyc = cast(dyc, x.dtype)
+        ks = None
         if row_scale is not None:
-            dyc = (dyc.view(row_scale.numel(), ctx.rs_rows, -1) * row_scale.view(-1, 1, 1).to(dyc.dtype)).view(dyc.shape)
+            # d(s . y) = s . dy per sample (DropPath).  Where the kernels can, s is applied inside them -- on the OUTPUT rows of the data
+            # gradient (epilogue) and on the CONTRACTION rows of the weight gradient (fragment scale, zero-scale tiles skipped) -- instead of
+            # materialising s . dy (a read + write of dy and two launches per DropPath layer)
+            if _KSCALE and dyc.dtype == torch.bfloat16 and ctx.rs_rows % 64 == 0 and ctx.wT is not None:
+                ks = (row_scale, ctx.rs_rows)
+            else:
+                dyc = (dyc.view(row_scale.numel(), ctx.rs_rows, -1) * row_scale.view(-1, 1, 1).to(dyc.dtype)).view(dyc.shape)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = mm(dyc, ctx.wT) if ctx.wT is not None else mm_dgrad(dyc, wq)
+            if ctx.wT is not None:
+                dx = mm(dyc, ctx.wT, row_scale=ks[0], rs_rows=ks[1]) if ks is not None else mm(dyc, ctx.wT)
+            else:
+                dx = mm_dgrad(dyc, wq)
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if want_db:
-                dw, db = mm_wgrad(dyc, x, with_colsum=True)
+                dw, db = mm_wgrad(dyc, x, with_colsum=True, k_scale=ks)
             else:
-                dw = mm_wgrad(dyc, x)
+                dw = mm_wgrad(dyc, x, k_scale=ks)
         elif want_db:
-            db = colsum(dyc)
+            dys = dyc if ks is None else (dyc.view(row_scale.numel(), ctx.rs_rows, -1) * row_scale.view(-1, 1, 1).to(dyc.dtype)).view(dyc.shape)
+            db = colsum(dys)
         return dx, dw, db, dres, None, None, None
 
 
@@ -985,7 +1006,11 @@ class _ConvT2x2(torch.autograd.Function):
             wp = w.permute(2, 3, 1, 0).reshape(4 * Cout, Cin).to(x.dtype).contiguous()
         out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=x.dtype, device=x.device)
         _, _, _, _, ldc = _nhwc(out)
-        b4 = _f32(bias).repeat(4) if bias is not None else None
+        b4 = None
+        if bias is not None:                               # bias per (tap, co) column: [b; b; b; b] from the weight pack (no repeat launch)
+            b4 = PACK.get((bias, bias, bias, bias), PK_CAST, torch.float32)
+            if b4 is None:
+                b4 = _f32(bias).repeat(4)
         ldr = 0
         if residual is not None:                       # tensor of the output shape added in the epilogue (dinov3_adapter.py:467)
             Br, Hr, Wr, Cr, ldr = _nhwc(residual)

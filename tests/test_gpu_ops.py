@@ -200,6 +200,46 @@ def test_linear_autograd_with_residual_and_droppath(dt):
         assert rel(a, r_) < TOL[dt]
 
 
+def test_linear_droppath_scale_inside_backward_gemms():
+    """DropPath in the backward of a linear layer (ConvFFN fc2, dinov3_adapter.py:148): from the second step on (W^T packed) the per-sample
+    scale is applied inside the GEMMs -- output rows of the data gradient, contraction rows of the weight gradient with dropped samples'
+    K tiles skipped, bias gradient from the scaled fragments -- instead of materialising s . dy.  Same gradients as the reference and as
+    the first step, which still builds the scaled copy."""
+    from dinounet_amd import ops
+    d = dev()
+    bf = torch.bfloat16
+    B, T, K, N = 4, 1280, 256, 192
+    x, res = q(gen(B, T, K, seed=1), bf), q(gen(B, T, N, seed=4), bf)
+    w = torch.nn.Parameter(gen(N, K, seed=2, scale=K ** -0.5).to(d))
+    b = torch.nn.Parameter(gen(N, seed=3).to(d))
+    mask = torch.tensor([0.0, 1 / 0.7, 1 / 0.7, 0.0])
+    go = q(gen(B, T, N, seed=5), bf)
+    xr, wr, br, rr = x.clone().requires_grad_(True), q(w.detach().cpu(), bf).requires_grad_(True), b.detach().cpu().clone().requires_grad_(True), res.clone().requires_grad_(True)
+    yr = F.linear(xr, wr, br) * mask.view(-1, 1, 1) + rr
+    gr = torch.autograd.grad(yr, (xr, wr, br, rr), go)
+
+    def step():
+        xg, rg = x.to(d, bf).requires_grad_(True), res.to(d, bf).requires_grad_(True)
+        ops.TRACK_ROUTE, ops.ROUTES[:] = True, []
+        try:
+            y = ops.linear(xg, w, b, residual=rg, row_scale=mask.to(d), rs_rows=T)
+            g = torch.autograd.grad(y, (xg, w, b, rg), go.to(d, bf))
+        finally:
+            ops.TRACK_ROUTE = False
+        return y.float().cpu(), [t.float().cpu() for t in g]
+
+    ops.PACK.refresh()
+    y0, g0 = step()              # registers W^T: data gradient on the PLAIN_COL kernel, s . dy materialised
+    ops.PACK.refresh()
+    y1, g1 = step()
+    assert (ops.PLAIN_ROW, ops.PLAIN_COL) not in [(am, bm) for am, bm, _ in ops.ROUTES]
+    assert rel(y1, yr) < TOL[bf]
+    for a, b0, r_ in zip(g1, g0, gr):
+        assert rel(a, r_) < TOL[bf]
+        assert rel(a, b0) < 1e-2
+    assert float(g1[0][0].abs().max()) == 0.0 and float(g1[0][3].abs().max()) == 0.0       # dropped samples: exactly zero input gradient
+
+
 # ------------------------------------------------------------------------------------------------ conv
 def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--top", type=int, default=60)
+    ap.add_argument("--trainstep", action="store_true", help="trace the step bench.py runs (training.TrainStep eager step with FusedClipSGD) and EVERY aten op that is not a pure view, backward included (autograd multithreading off so the dispatch mode sees it)")
     ap.add_argument("--profiler", action="store_true", help="torch.profiler view instead: every watched op with input shapes, split by thread (the autograd engine's own copies / zero fills are invisible to the dispatch-mode tracer)")
     a = ap.parse_args()
     from dinounet_amd.plans import PLANS_2D
@@ -45,6 +46,14 @@ def main():
         torch.nn.utils.clip_grad_norm_(params, 12.0)
         opt.step()
 
+    if a.trainstep:
+        from dinounet_amd.training import TrainStep
+        from dinounet_amd.optim import FusedClipSGD
+        opt2 = FusedClipSGD(params, lr=1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5, max_norm=12.0)
+        ts = TrainStep(net, opt2, params, x.shape, tgt.shape, dev, graph=False)
+        ts(x, tgt)
+        step = lambda: ts()
+        torch.autograd.set_multithreading_enabled(False)
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -72,7 +81,12 @@ def main():
     class Tracer(TorchDispatchMode):
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
             name = "aten::" + func.__name__.split(".")[0]
-            if name in WATCH or name in ("aten::empty_strided", "aten::bernoulli_", "aten::_foreach_add_", "aten::_foreach_mul_"):
+            views = ("view", "reshape", "_unsafe_view", "as_strided", "t", "transpose", "permute", "expand", "slice", "select", "unsqueeze", "squeeze",
+                     "detach", "alias", "empty", "empty_like", "empty_strided", "split", "split_with_sizes", "unbind", "narrow", "flatten", "unflatten",
+                     "_local_scalar_dense", "is_same_size", "sym_size", "stride", "size", "numel", "lift_fresh", "view_as", "chunk", "_reshape_alias",
+                     "new_empty", "new_empty_strided", "resize_", "set_", "is_pinned", "record_stream", "contiguous")
+            watched = (func.__name__.split(".")[0] not in views) if a.trainstep else (name in WATCH or name in ("aten::empty_strided", "aten::bernoulli_", "aten::_foreach_add_", "aten::_foreach_mul_"))
+            if watched:
                 frames = [f for f in traceback.extract_stack() if ("dinounet_amd" in f.filename or "tools/" in f.filename) and "glue_trace" not in f.filename]
                 where = " < ".join(f"{os.path.relpath(f.filename, ROOT)}:{f.lineno}" for f in frames[-3:][::-1]) or "(autograd engine / optimizer)"
                 shp = ""
