@@ -283,13 +283,27 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restr
 }
 
 // ---------------- bilinear (align_corners=False) upsample + add (dinov3_adapter.py:472-476) ----------------
-template <typename TS, typename T>
+// Thread = V consecutive channels of one output pixel; V = 8 (16-byte bf16 vectors) when C % 8 == 0, else 4.  (The first version read and
+// wrote element by element: 1.3 TB/s on the 268 MB c1 level.)
+template <typename TS, typename T, int V>
 __global__ __launch_bounds__(256) void bilinear_add_kernel(const TS* __restrict__ src, long lds_, const T* __restrict__ base,
                                                            long ldb, T* __restrict__ out, long ldo, int B, int Hs, int Ws, int Ho,
                                                            int Wo, int C, long total) {
-  constexpr int V = 4;
   const int cvn = C / V;
   const float sh = (float)Hs / (float)Ho, sw = (float)Ws / (float)Wo;
+  auto load = [&](const TS* p, float* v) {
+    if constexpr (sizeof(TS) == 2 && V == 8) {
+      const bf16x8 t = __builtin_bit_cast(bf16x8, *(const uint4*)p);
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = (float)t[j];
+    } else if constexpr (sizeof(TS) == 4 && V % 4 == 0) {
+#pragma unroll
+      for (int j = 0; j < V; j += 4) { const float4 t = *(const float4*)(p + j); v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; j++) v[j] = to_f32(p[j]);
+    }
+  };
   GRID_STRIDE(i, total) {
     const int c0 = (int)(i % cvn) * V;
     long t = i / cvn;
@@ -301,15 +315,36 @@ __global__ __launch_bounds__(256) void bilinear_add_kernel(const TS* __restrict_
     const int y0 = (int)fy, x0 = (int)fx;
     const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
     const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
-    const TS* s00 = src + (((long)b * Hs + y0) * Ws + x0) * lds_ + c0;
-    const TS* s01 = src + (((long)b * Hs + y0) * Ws + x1) * lds_ + c0;
-    const TS* s10 = src + (((long)b * Hs + y1) * Ws + x0) * lds_ + c0;
-    const TS* s11 = src + (((long)b * Hs + y1) * Ws + x1) * lds_ + c0;
+    float a00[V], a01[V], a10[V], a11[V], bs[V];
+    load(src + (((long)b * Hs + y0) * Ws + x0) * lds_ + c0, a00);
+    load(src + (((long)b * Hs + y0) * Ws + x1) * lds_ + c0, a01);
+    load(src + (((long)b * Hs + y1) * Ws + x0) * lds_ + c0, a10);
+    load(src + (((long)b * Hs + y1) * Ws + x1) * lds_ + c0, a11);
     const long po = ((long)b * Ho + yo) * Wo + xo;
+    if (base) {
+      if constexpr (sizeof(T) == 2 && V == 8) {
+        const bf16x8 tb = __builtin_bit_cast(bf16x8, *(const uint4*)(base + po * ldb + c0));
 #pragma unroll
-    for (int j = 0; j < V; j++) {
-      float v = hy * (hx * to_f32(s00[j]) + lx * to_f32(s01[j])) + ly * (hx * to_f32(s10[j]) + lx * to_f32(s11[j]));
-      out[po * ldo + c0 + j] = from_f32<T>((base ? to_f32(base[po * ldb + c0 + j]) : 0.f) + v);
+        for (int j = 0; j < 8; j++) bs[j] = (float)tb[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; j++) bs[j] = to_f32(base[po * ldb + c0 + j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; j++) bs[j] = 0.f;
+    }
+    float o[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) o[j] = bs[j] + hy * (hx * a00[j] + lx * a01[j]) + ly * (hx * a10[j] + lx * a11[j]);
+    if constexpr (sizeof(T) == 2 && V == 8) {
+      bf16x8 r;
+#pragma unroll
+      for (int j = 0; j < 8; j++) r[j] = (bf16_t)o[j];
+      *(uint4*)(out + po * ldo + c0) = __builtin_bit_cast(uint4, r);
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; j++) out[po * ldo + c0 + j] = from_f32<T>(o[j]);
     }
   }
 }
@@ -743,15 +778,18 @@ extern "C" int du_bilinear_add_fwd(int src_dtype, int dtype, const void* src, in
                                    int64_t ldo, int B, int Hs, int Ws, int Ho, int Wo, int C, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!src || !out || B <= 0 || C % 4) return DU_ERR_BAD_ARG;          // base == NULL: plain resize
-  long total = (long)B * Ho * Wo * (C / 4);
+  // 16-byte vectors (8 channels per thread) when every row pitch and pointer allows it
+  const bool v8 = dtype == DU_BF16 && C % 8 == 0 && lds_ % 8 == 0 && ldo % 8 == 0 && (!base || ldb % 8 == 0) &&
+                  ((((uintptr_t)src) | ((uintptr_t)out) | ((uintptr_t)base)) & 15) == 0;
+  const int V = v8 ? 8 : 4;
+  long total = (long)B * Ho * Wo * (C / V);
   dim3 g(grid_1d(total)), b(256);
-  if (src_dtype == DU_F32 && dtype == DU_F32)
-    hipLaunchKernelGGL((bilinear_add_kernel<float, float>), g, b, 0, st, (const float*)src, lds_, (const float*)base, ldb, (float*)out, ldo, B, Hs, Ws, Ho, Wo, C, total);
-  else if (src_dtype == DU_F32 && dtype == DU_BF16)
-    hipLaunchKernelGGL((bilinear_add_kernel<float, bf16_t>), g, b, 0, st, (const float*)src, lds_, (const bf16_t*)base, ldb, (bf16_t*)out, ldo, B, Hs, Ws, Ho, Wo, C, total);
-  else if (src_dtype == DU_BF16 && dtype == DU_BF16)
-    hipLaunchKernelGGL((bilinear_add_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)src, lds_, (const bf16_t*)base, ldb, (bf16_t*)out, ldo, B, Hs, Ws, Ho, Wo, C, total);
+#define BL_LAUNCH(TS, T, VV) hipLaunchKernelGGL((bilinear_add_kernel<TS, T, VV>), g, b, 0, st, (const TS*)src, lds_, (const T*)base, ldb, (T*)out, ldo, B, Hs, Ws, Ho, Wo, C, total)
+  if (src_dtype == DU_F32 && dtype == DU_F32) BL_LAUNCH(float, float, 4);
+  else if (src_dtype == DU_F32 && dtype == DU_BF16) { if (v8) BL_LAUNCH(float, bf16_t, 8); else BL_LAUNCH(float, bf16_t, 4); }
+  else if (src_dtype == DU_BF16 && dtype == DU_BF16) { if (v8) BL_LAUNCH(bf16_t, bf16_t, 8); else BL_LAUNCH(bf16_t, bf16_t, 4); }
   else return DU_ERR_BAD_ARG;
+#undef BL_LAUNCH
   return du_check_launch();
 }
 
