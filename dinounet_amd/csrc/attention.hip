@@ -342,7 +342,70 @@ extern "C" int du_qkv_rope_split(int dtype, const void* qkv, void* q, void* k, v
   return du_check_launch();
 }
 
+// rows [m_begin, m_begin + m_count) of the (B * N, 3 * H * Dh) projection only (the skinny tail of a product whose tile part was stored
+// through DU_STORE_QKV_ROPE)
+template <typename T>
+__global__ __launch_bounds__(256) void qkv_rope_split_rows_kernel(const T* __restrict__ rows, T* __restrict__ q, T* __restrict__ k,
+                                                                  T* __restrict__ v, const float* __restrict__ sin_t,
+                                                                  const float* __restrict__ cos_t, int N, int Npad, int H, int Dh,
+                                                                  int prefix, float qscale, long m_begin, long total) {
+  constexpr int V = Elem<T>::VEC;
+  const int dv = Dh / V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int d0 = (int)(i % dv) * V;
+    long t = i / dv;
+    const int h = (int)(t % H); t /= H;
+    const int which = (int)(t % 3); t /= 3;          // t = local row
+    const long m = m_begin + t;
+    const int b = (int)(m / N), n = (int)(m - (long)b * N);
+    const T* src = rows + ((t * 3 + which) * H + h) * Dh;
+    Vec16<T> x = as_vec<T>(*(const uint4*)(src + d0));
+    float o[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) o[j] = to_f32(x.v[j]);
+    if (which < 2 && n >= prefix) {
+      const int half = Dh / 2;
+      const int dp = d0 < half ? d0 + half : d0 - half;
+      const float sgn = d0 < half ? -1.f : 1.f;
+      Vec16<T> y = as_vec<T>(*(const uint4*)(src + dp));
+      const float* sp = sin_t + (long)(n - prefix) * Dh + d0;
+      const float* cp = cos_t + (long)(n - prefix) * Dh + d0;
+#pragma unroll
+      for (int j = 0; j < V; j++) o[j] = o[j] * cp[j] + sgn * to_f32(y.v[j]) * sp[j];
+    }
+    if (which == 0) {
+#pragma unroll
+      for (int j = 0; j < V; j++) o[j] *= qscale;
+    }
+    T* dst = (which == 0 ? q : (which == 1 ? k : v)) + (((long)b * H + h) * Npad + n) * Dh + d0;
+    Vec16<T> r;
+#pragma unroll
+    for (int j = 0; j < V; j++) r.v[j] = from_f32<T>(o[j]);
+    *(uint4*)dst = as_u4(r);
+  }
+}
+
 int g_attn_w = 0;        // unused knob kept for du_set_option key 4 (workgroups are 4 waves: 3-wave workgroups measured slower)
+
+extern "C" int du_qkv_rope_split_rows(int dtype, const void* qkv_rows, void* q, void* k, void* v, const float* sin_t, const float* cos_t,
+                                      int B, int N, int Npad, int H, int Dh, int prefix, float qscale, int64_t m_begin, int m_count,
+                                      void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == DU_BF16 ? 8 : 4;
+  if (!qkv_rows || !q || !k || !v || !sin_t || !cos_t || B <= 0 || N <= 0 || Npad < N || H <= 0 || Dh <= 0 || (Dh / 2) % vec || prefix < 0 ||
+      prefix > N || m_begin < 0 || m_count <= 0 || m_begin + m_count > (int64_t)B * N)
+    return DU_ERR_BAD_ARG;
+  const long total = (long)m_count * 3 * H * (Dh / vec);
+  long g = (total + 255) / 256; if (g > 65535) g = 65535;
+  if (dtype == DU_BF16)
+    hipLaunchKernelGGL(qkv_rope_split_rows_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)qkv_rows, (bf16_t*)q, (bf16_t*)k,
+                       (bf16_t*)v, sin_t, cos_t, N, Npad, H, Dh, prefix, qscale, (long)m_begin, total);
+  else if (dtype == DU_F32)
+    hipLaunchKernelGGL(qkv_rope_split_rows_kernel<float>, dim3((unsigned)g), dim3(256), 0, st, (const float*)qkv_rows, (float*)q, (float*)k,
+                       (float*)v, sin_t, cos_t, N, Npad, H, Dh, prefix, qscale, (long)m_begin, total);
+  else return DU_ERR_BAD_ARG;
+  return du_check_launch();
+}
 
 extern "C" int du_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int N, int Npad, int Dh,
                                 void* stream) {

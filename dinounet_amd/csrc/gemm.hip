@@ -353,6 +353,10 @@ extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
     const int route = a.dtype == DU_BF16 && a.a_mode == DU_PLAIN_COL && !getenv("DU_GEMM_GENERIC") ? du_gemm_route_bf16(a) : 0;
     if (route != 1 && route != 5) return DU_ERR_UNSUPPORTED;
   }
+  if (a.store_mode == DU_STORE_QKV_ROPE) {       // fused RoPE + head split: the 256 x 128 multi-phase kernel or nothing
+    if (a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.split_k > 1) return DU_ERR_UNSUPPORTED;
+    return du_gemm_nt_p8(a, st);
+  }
   if (a.act == DU_ACT_SWIGLU) {          // gated epilogue: multi-phase bf16 NT kernels only (callers fall back to du_swiglu_pairs)
     if (a.dtype != DU_BF16 || a.N % 2) return DU_ERR_UNSUPPORTED;
     return du_gemm_nt_p8(a, st);

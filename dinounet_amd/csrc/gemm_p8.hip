@@ -138,6 +138,39 @@ __device__ __forceinline__ void stage_block_bf16(const f32x16& a, const float4 (
     }
   }
 }
+// DU_STORE_QKV_ROPE staging of one head's two 32-column halves (accumulator blocks lo = dims 0..31, hi = dims 32..63 of the SAME lane
+// and register: rotate-half pairs never leave the lane): bias, RoPE for q / k rows past the prefix tokens
+// (layers/attention.py:66-85: x * cos + rotate_half(x) * sin in fp32), q scale, bf16 pack
+__device__ __forceinline__ void stage_head_rope(const GemmParams& P, const f32x16& lo, const f32x16& hi_, const float4 (&blo)[4],
+                                                const float4 (&bhi)[4], bf16_t* stg, int ldb, int srow, int scol, int hi, int m, int which) {
+  const int b = m / P.ps_H, t = m - b * P.ps_H;
+  const bool rot = which < 2 && t >= P.rope_prefix && m < P.M;
+  const float qs = which == 0 ? P.rope_qscale : 1.0f;
+  const long trow = rot ? (long)(t - P.rope_prefix) * 64 : 0;
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const int d = 8 * g + 4 * hi;
+    float x1[4] = {lo[4 * g] + blo[g].x, lo[4 * g + 1] + blo[g].y, lo[4 * g + 2] + blo[g].z, lo[4 * g + 3] + blo[g].w};
+    float x2[4] = {hi_[4 * g] + bhi[g].x, hi_[4 * g + 1] + bhi[g].y, hi_[4 * g + 2] + bhi[g].z, hi_[4 * g + 3] + bhi[g].w};
+    float o1[4], o2[4];
+    if (rot) {
+      const float4 c1 = *(const float4*)(P.rope_cos + trow + d), s1 = *(const float4*)(P.rope_sin + trow + d);
+      const float4 c2 = *(const float4*)(P.rope_cos + trow + 32 + d), s2 = *(const float4*)(P.rope_sin + trow + 32 + d);
+      const float cc1[4] = {c1.x, c1.y, c1.z, c1.w}, ss1[4] = {s1.x, s1.y, s1.z, s1.w};
+      const float cc2[4] = {c2.x, c2.y, c2.z, c2.w}, ss2[4] = {s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) { o1[e] = x1[e] * cc1[e] - x2[e] * ss1[e]; o2[e] = x2[e] * cc2[e] + x1[e] * ss2[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; e++) { o1[e] = x1[e]; o2[e] = x2[e]; }
+    }
+    bf16x4 t1, t2;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { t1[e] = (bf16_t)(o1[e] * qs); t2[e] = (bf16_t)(o2[e] * qs); }
+    *(uint2*)(stg + srow * ldb + scol + d) = __builtin_bit_cast(uint2, t1);
+    *(uint2*)(stg + srow * ldb + scol + 32 + d) = __builtin_bit_cast(uint2, t2);
+  }
+}
 // this lane's bias values for the block whose first column is ncol0 (zeros without a bias); columns past N are clamped (never stored)
 __device__ __forceinline__ void load_bias4(const GemmParams& P, int ncol0, int hi, float4 (&bv)[4]) {
 #pragma unroll
@@ -154,11 +187,12 @@ __device__ __forceinline__ void stage_block_f32(const f32x16& a, float* stg, int
 }
 // rows [0, nrows) of the bf16 staging tile -> C rows mrow0 + ...: 16 bytes per lane, whole rows per wave.  TBN = staged columns,
 // n0 / ncols = first column / column count of C they map to (half the GEMM's for the SwiGLU gate)
-template <int TBN>
+template <int TBN, bool QKV = false>
 __device__ __forceinline__ void readout_bf16(const GemmParams& P, const bf16_t* stg, int ldb, int nrows, int mrow0, int n0, int ncols,
                                              bf16_t* Cb, int tid) {
   constexpr int C8 = TBN / 8;
-  const bool wide = (P.ldc % 8 == 0) && ((((uintptr_t)Cb) & 15) == 0) && (P.store_mode == DU_STORE_PLAIN || P.ps_C % 8 == 0);
+  // QKV: 8 consecutive d of one head are 16 contiguous bytes whatever the plane stride
+  const bool wide = ((((uintptr_t)Cb) & 15) == 0) && P.ldc % 8 == 0 && (QKV || P.store_mode == DU_STORE_PLAIN || P.ps_C % 8 == 0);
 #pragma unroll 4
   for (int v = tid; v < nrows * C8; v += 512) {
     const int row = v / C8, c8 = v % C8;
@@ -166,7 +200,7 @@ __device__ __forceinline__ void readout_bf16(const GemmParams& P, const bf16_t* 
     if (m >= P.M || n >= ncols) continue;
     const uint4 t = *(const uint4*)(stg + row * ldb + c8 * 8);
     if ((P.dbg & 1) && t.x != 0x12345678u) continue;      // measurement aid (du_set_option key 3): staging without the global stores
-    bf16_t* dst = Cb + out_offset(P, m, n, P.ldc);
+    bf16_t* dst = Cb + (QKV ? qkv_heads_offset(P, m, n, P.ldc) : out_offset(P, m, n, P.ldc));
     if (wide && n + 8 <= ncols) *(uint4*)dst = t;
     else {
       *(uint2*)dst = make_uint2(t.x, t.y);
@@ -863,6 +897,17 @@ __global__ __launch_bounds__(512) void gemm_nt_p8n_kernel(GemmParams P) {
           for (int c = 0; c < 2; c++)
             stage_block_bf16<ACT>(acc[i][c], bv[c], stg, N_STG_LDB, i * 128 + wm * 32 + (lane & 31), wn * 64 + c * 32, hi);
       };
+      if (P.store_mode == DU_STORE_QKV_ROPE) {        // a wave's 64 columns = one (which, head): RoPE in registers, head-major store
+        const int which = (n0 + wn * 64) / (P.ps_C * 64);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          const int srow = i * 128 + wm * 32 + (lane & 31);
+          stage_head_rope(P, acc[i][0], acc[i][1], bv[0], bv[1], stg, N_STG_LDB, srow, wn * 64, hi, m0 + srow, which);
+        }
+        __syncthreads();
+        readout_bf16<NBN, true>(P, stg, N_STG_LDB, 256, m0, n0, P.N, (bf16_t*)Cb, tid);
+        return;
+      }
       if (P.act == DU_ACT_SWIGLU) {
         stage_all(IC<DU_ACT_SWIGLU>{});
         __syncthreads();
@@ -974,6 +1019,11 @@ static bool p8_gather_legal(const du_gemm_args& a) {
 static bool p8_legal(const du_gemm_args& a) {
   if (a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.dtype != DU_BF16) return false;
   if (a.split_k > 1) return false;
+  if (a.store_mode == DU_STORE_QKV_ROPE) {       // 256 x 128 kernel only (du_gemm_p8_choice), bias-only bf16 epilogue, d_head 64
+    if (a.out_dtype != DU_BF16 || a.residual || a.gamma || a.row_scale || a.alpha != 1.0f || a.act != DU_ACT_NONE || a.batch > 1) return false;
+    if (a.ps_H <= 0 || a.ps_W < a.ps_H || a.ps_C <= 0 || a.N != 3 * a.ps_C * 64 || a.ldc % 8 || !a.rope_sin || !a.rope_cos) return false;
+    if ((((uintptr_t)a.rope_sin) | ((uintptr_t)a.rope_cos) | ((uintptr_t)a.C)) & 15) return false;
+  } else
   if (a.store_mode != DU_STORE_PLAIN && (a.store_mode != DU_STORE_PIXEL_SHUFFLE2 || a.ps_C % 4 || a.act == DU_ACT_SWIGLU)) return false;
   if (a.K % 128 || a.K < 256 || a.M < 256 || a.N < 128 || a.N % 4) return false;
   if (a.lda % 8 || a.ldb % 8 || (((uintptr_t)a.A) & 15) || (((uintptr_t)a.B) & 15)) return false;
@@ -989,6 +1039,7 @@ int du_gemm_p8_choice(const du_gemm_args& a) {
   if (g_p8_mode != 0 && g_p8_tn && p8_gather_legal(a))      // ConvT data gradient: 256 x 256 tiles once they fill most of the CUs
     return (g_p8_mode > 0 || (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 192) ? 1 : 0;
   if (g_p8_mode == 0 || !p8_legal(a)) return 0;
+  if (a.store_mode == DU_STORE_QKV_ROPE) return 2;
   if (g_p8_mode > 0) return g_p8_mode == 2 ? 2 : 1;
   // rounds of workgroups on the 256 CUs (one 8-wave workgroup per CU) x cost per workgroup (a 256 x 128 tile costs ~0.56 of a
   // 256 x 256 one: half the MFMAs at a lower operand reuse); measured crossovers: tools/gemm_p8_bench.py

@@ -25,6 +25,7 @@ struct GemmParams {
   int tiles_m, group_m;   // grouped tile order (gemm_glds.hip): bands of group_m tile rows are walked column by column; 0 = row-major
   int dbg;                // measurement aids of gemm_p8.hip (du_set_option key 3); 0 in production
   float* a_colsum;        // weight-gradient kernels: a_colsum[m] += sum_k A(m, k) (bias gradient), fp32 atomics; NULL = off
+  const float* rope_sin; const float* rope_cos; int rope_prefix; float rope_qscale;     // DU_STORE_QKV_ROPE
   int k_scale;            // weight-gradient form (A contraction-major): row_scale[k / rs_rows] scales the CONTRACTION rows of A, not output rows
 };
 
@@ -36,6 +37,15 @@ __device__ __forceinline__ long out_offset(const GemmParams& P, int m, int n, lo
   const int x = m % P.ps_W, t2 = m / P.ps_W, y = t2 % P.ps_H, b = t2 / P.ps_H;
   const long opix = ((long)b * 2 * P.ps_H + 2 * y + (q >> 1)) * (2 * P.ps_W) + 2 * x + (q & 1);
   return opix * ld + co;
+}
+
+// DU_STORE_QKV_ROPE: (b, t) x (which, h, d) -> [which][b][h][t][d]; ld = elements between the q / k / v planes.  Kept out of out_offset():
+// inlined into every epilogue it pushed the 256 x 256 kernel's fp32-staged readout into scratch (+7 ms per step).
+__device__ __forceinline__ long qkv_heads_offset(const GemmParams& P, int m, int n, long ld) {
+  const int b = m / P.ps_H, t = m - b * P.ps_H;
+  const int hd = P.ps_C * 64;
+  const int which = n / hd, rem = n - which * hd;
+  return (long)which * ld + (((long)b * P.ps_C + (rem >> 6)) * P.ps_W + t) * 64 + (rem & 63);
 }
 
 __device__ __forceinline__ int div_small(int x, int d) {
@@ -106,6 +116,7 @@ inline GemmParams make_params(const du_gemm_args& a, int amode, int bmode, int B
   P.rs_rows = a.rs_rows > 0 ? a.rs_rows : 1; P.residual = a.residual; P.ldr = a.ldr;
   P.store_mode = a.store_mode; P.ps_H = a.ps_H; P.ps_W = a.ps_W; P.ps_C = a.ps_C;
   P.a_colsum = a.a_colsum;
+  P.rope_sin = a.rope_sin; P.rope_cos = a.rope_cos; P.rope_prefix = a.rope_prefix; P.rope_qscale = a.rope_qscale;
   P.k_scale = (amode == DU_PLAIN_COL && a.row_scale) ? 1 : 0;
   P.tiles_n = (a.N + BN - 1) / BN;
   (void)BM;

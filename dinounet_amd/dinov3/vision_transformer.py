@@ -7,7 +7,7 @@ return_class_token=True)`, dinov3_adapter.py:424-426).  The torch sub-modules ar
 the arithmetic runs in libdinounet_hip.so:
 
   patch embed  : du_patchify16 + du_gemm                      (layers/patch_embed.py:61-76)
-  per block    : du_layernorm_fwd -> du_gemm(QKV, K-masked bias) -> du_qkv_rope_split -> du_attention_fwd
+  per block    : du_layernorm_fwd -> du_gemm(QKV, K-masked bias; bf16: RoPE + head split in its epilogue, else du_qkv_rope_split) -> du_attention_fwd
                  -> du_gemm(proj, LayerScale + residual epilogue) -> du_layernorm_fwd
                  -> du_gemm(fc1 + erf-GELU epilogue) -> du_gemm(fc2, LayerScale + residual epilogue)
                                                               (layers/block.py:189-194, attention.py:87-118)
@@ -261,8 +261,7 @@ class DinoVisionTransformer(nn.Module):
         def attn_branch(xr, Bs, i, d, scale):
             """xr (Bs*N, D) fp32 += [scale *] ls1(attn(norm1(xr)))   in place (layers/block.py:189-193)"""
             h, _, _ = ops.layernorm_raw(xr, d["n1w"], d["n1b"], 1e-5, dtype)
-            qkv = ops.mm(h, d["qkv_w"], bias=d["qkv_b"])
-            a = ops.attention(qkv, sin_all[i], cos_all[i], Bs, N, nh, dh, npre, self._ws)
+            a = ops.qkv_attention(h, d["qkv_w"], d["qkv_b"], sin_all[i], cos_all[i], Bs, N, nh, dh, npre, self._ws)
             ops.mm(a, d["proj_w"], bias=d["proj_b"], gamma=d["g1"], residual=xr, out=xr, row_scale=scale, rs_rows=xr.shape[0] if scale is not None else 0)
 
         def ffn_branch(xr, d, scale):

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SWIGLU, DU_BF16, DU_F32, IM2COL_COL, IM2COL_ROW, PLAIN_COL,
-                   PLAIN_ROW, STORE_PIXEL_SHUFFLE2, ConvGeom, GemmArgs)
+                   PLAIN_ROW, STORE_PIXEL_SHUFFLE2, STORE_QKV_ROPE, ConvGeom, GemmArgs)
 
 __all__ = ["mm", "linear", "conv2d", "conv_transpose2x2", "norm_act", "layer_norm", "msda", "dwconv3x3",
            "maxpool3x3s2", "bilinear_add", "bilinear_resize", "squeeze_excite", "dice_ce_loss"]
@@ -134,7 +134,7 @@ ROUTES = []                  # (a_mode, b_mode, route) of every product since TR
 
 def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat, ldc, batch=1, abs_=0, bbs=0, cbs=0,
              split_k=1, alpha=1.0, bias=None, act=ACT_NONE, gamma=None, row_scale=None, rs_rows=0, residual=None, ldr=0,
-             store_mode=0, ps=(0, 0, 0), geom=None, a_colsum=None, route_only=False):
+             store_mode=0, ps=(0, 0, 0), geom=None, a_colsum=None, rope=None, route_only=False):
     a = GemmArgs()
     a.dtype, a.out_dtype, a.a_mode, a.b_mode = dtype, out_dtype, a_mode, b_mode
     a.M, a.N, a.K = M, N, K
@@ -152,6 +152,8 @@ def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat,
     if geom is not None:
         a.geom = geom
     a.a_colsum = a_colsum
+    if rope is not None:
+        a.rope_sin, a.rope_cos, a.rope_prefix, a.rope_qscale = rope
     if route_only:
         return int(_lib.lib().du_gemm_route(C.byref(a)))
     ws = None
@@ -1724,6 +1726,50 @@ def cast(x, dt):
 # ----------------------------------------------------------------------------------------------------
 # ViT attention (forward only: the backbone is frozen, dinov3_adapter.py:326,423)
 # ----------------------------------------------------------------------------------------------------
+# RoPE + head split in the qkv GEMM's epilogue (DU_STORE_QKV_ROPE).  Parity-tested, but measured NEUTRAL in the dinounet_l step (33.64 /
+# 33.71 ms fused vs 33.56 ms with the separate du_qkv_rope_split pass: the epilogue's table loads, the per-row division and the 128-byte
+# head-major store segments cost what the 100 MB pass saved), so it stays opt-in.
+_QKV_FUSED = os.environ.get("DINOUNET_QKV_FUSED", "0") == "1"
+
+
+def qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, workspace):
+    """attention(h w^T + bias) of one ViT block (layers/attention.py:88-118): h (B*N, D) normalised tokens -> (B*N, H*Dh).
+    bf16, d_head 64: the qkv product's epilogue applies RoPE and the q scale and stores q / k / v head-major (DU_STORE_QKV_ROPE), so the
+    (B*N, 3*H*Dh) matrix and the pass that re-read it (du_qkv_rope_split) do not exist; the few rows past the last full 256-row tile
+    (M = 8 * 1029 = 32 * 256 + 40) go through a small plain product + du_qkv_rope_split_rows.  Otherwise: mm + attention()."""
+    dt = h.dtype
+    M, D = h.shape
+    if _QKV_FUSED and dt == torch.bfloat16 and Dh == 64 and M == B * N and M >= 256:
+        Npad = (N + 7) // 8 * 8
+        key = ("qkv", dt, B, H, Npad, Dh)
+        if key not in workspace:
+            workspace[key] = torch.zeros((3, B, H, Npad, Dh), dtype=dt, device=h.device)
+        qkv3 = workspace[key]
+        q, k, v = qkv3
+        r = M % 256
+        M0 = M - r
+        qscale = Dh ** -0.5 * math.log2(math.e)
+        _, _, lda = _rows2d(h)
+        Nw, _, ldb = _rows2d(w)
+        kw = dict(dtype=DU_BF16, out_dtype=DU_BF16, a_mode=PLAIN_ROW, b_mode=PLAIN_ROW, M=M0, N=Nw, K=D, A=h.data_ptr(), lda=lda,
+                  B=w.data_ptr(), ldb=ldb, Cmat=qkv3.data_ptr(), ldc=B * H * Npad * Dh, bias=_dp(bias), store_mode=STORE_QKV_ROPE,
+                  ps=(N, Npad, H), rope=(sin.data_ptr(), cos.data_ptr(), prefix, qscale))
+        if Nw == 3 * H * Dh and gemm_route(**kw) == 4:
+            gemm_raw(**kw)
+            L = _lib.lib()
+            if r:
+                tail = mm(h[M0:], w, bias=bias)
+                _lib.check(L.du_qkv_rope_split_rows(DU_BF16, _p(tail), _p(q), _p(k), _p(v), _p(sin), _p(cos), B, N, Npad, H, Dh, prefix,
+                                                    qscale, M0, r, _st()), "du_qkv_rope_split_rows")
+            out = torch.empty((M, H * Dh), dtype=dt, device=h.device)
+            e0 = PROFILE.start() if PROFILE is not None else None
+            _lib.check(L.du_attention_fwd(_p(q), _p(k), _p(v), _p(out), B, H, N, Npad, Dh, _st()), "du_attention_fwd")
+            if PROFILE is not None:
+                PROFILE.stop("attn_fwd_kernel<bf16>", e0, 4.0 * B * H * N * N * Dh, 4.0 * B * H * N * Dh * 2)
+            return out
+    return attention(mm(h, w, bias=bias), sin, cos, B, N, H, Dh, prefix, workspace)
+
+
 def attention(qkv, sin, cos, B, N, H, Dh, prefix, workspace):
     """qkv (B*N, 3*H*Dh) -> (B*N, H*Dh).  bf16: fused flash kernel; fp32 (parity mode): QK^T / softmax / PV as batched
     MFMA GEMMs with materialised scores."""

@@ -68,6 +68,11 @@ extern "C" {
 
 /* du_gemm store modes */
 #define DU_STORE_PLAIN 0
+#define DU_STORE_QKV_ROPE 2 /* the ViT's qkv projection stored head-major with RoPE: row m = (b, token t) of M = B * ps_H tokens, column
+                              n = (which, h, d) of N = 3 * ps_C * 64 -> out[which][b][h][t][d] in three (B, ps_C, ps_W = Npad, 64) planes ldc
+                              elements apart; q and k of tokens >= rope_prefix are rotated (rotate-half, fp32) with rope_sin / rope_cos
+                              ((ps_H - prefix, 64) fp32), q is multiplied by rope_qscale.  bf16, d_head 64, bias-only epilogue; served
+                              by the 256 x 128 multi-phase kernel only (DU_ERR_UNSUPPORTED otherwise: du_qkv_rope_split then) */
 #define DU_STORE_PIXEL_SHUFFLE2 1 /* ConvTranspose2d k2 s2: column n=(dy*2+dx)*Cout+co of input pixel (b,y,x)
                                      goes to output pixel (b,2y+dy,2x+dx), channel co */
 
@@ -106,6 +111,7 @@ typedef struct {
   du_conv_geom geom;  /* used by the IM2COL operand (at most one operand is IM2COL) */
   float* ws; int64_t ws_elems; /* optional scratch, du_gemm_ws_elems(args) floats (0 = none wanted for this product); without it the
                                   product still runs, on the plain tile kernels */
+  const float* rope_sin; const float* rope_cos; int32_t rope_prefix; float rope_qscale;   /* DU_STORE_QKV_ROPE only */
   float* a_colsum;    /* optional, weight-gradient products only (a_mode PLAIN_COL, bf16): a_colsum[m] += sum_k A(m, k), fp32 atomics
                          into a buffer the caller zero-initialised -- the bias gradient sum_rows dY for free while dY^T X streams dY
                          anyway (nn.Linear backward).  du_gemm returns DU_ERR_UNSUPPORTED if the kernel family serving the product
@@ -146,6 +152,10 @@ int du_strip_finalize(const float* part, float* out, int G, int strips, int C, v
    applied to q and k for tokens >= prefix using sin/cos tables (N - prefix, Dh) fp32. */
 int du_qkv_rope_split(int dtype, const void* qkv, void* q, void* k, void* v, const float* sin_t, const float* cos_t,
                       int B, int N, int Npad, int H, int Dh, int prefix, float qscale, void* stream);
+/* The same for the token rows [m_begin, m_begin + m_count) of the (B * N, 3 * H * Dh) matrix only; qkv_rows points at row m_begin (the
+   rows a tile kernel left to the skinny tail when it wrote the rest through DU_STORE_QKV_ROPE). */
+int du_qkv_rope_split_rows(int dtype, const void* qkv_rows, void* q, void* k, void* v, const float* sin_t, const float* cos_t, int B, int N,
+                           int Npad, int H, int Dh, int prefix, float qscale, int64_t m_begin, int m_count, void* stream);
 /* Non-causal softmax2(q k^T) v per (b, head) with base-2 exponentials: q must be pre-scaled by
    Dh^-0.5 * log2(e).  q,k,v: (B, H, Npad, Dh) bf16; out: (B, N, H*Dh) bf16.  Dh in {64, 128}. */
 int du_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int N, int Npad, int Dh,

@@ -192,9 +192,13 @@ def attention(qkv, sin, cos, B, N, H, Dh, prefix, workspace):
     return o.transpose(1, 2).reshape(B * N, H * Dh).to(qkv.dtype)
 
 
+def qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, workspace):
+    return attention(mm(h, w, bias=bias), sin, cos, B, N, H, Dh, prefix, workspace)
+
+
 _NAMES = ["mm", "linear", "linear_cat", "conv1x1_cat", "fapm_project", "conv1x1", "conv2d", "conv2d_stats", "conv_transpose2x2", "norm_act", "layer_norm", "layer_norm_res", "layernorm_raw", "msda_prep", "msda",
           "dwconv3x3", "dwconv_tokens", "maxpool3x3s2", "bilinear_add", "bilinear_resize", "squeeze_excite", "nchw_to_nhwc", "nhwc_to_nchw_f32", "patchify16", "cast",
-          "attention"]
+          "attention", "qkv_attention"]
 
 
 @contextlib.contextmanager

@@ -720,6 +720,50 @@ def test_vit_attention(dt, B, H, N, Dh):
     assert rel(out, ref) < (2e-4 if dt == torch.float32 else 3e-2)
 
 
+@pytest.mark.parametrize("B,H,N,D", [(8, 16, 1029, 1024), (2, 6, 1029, 384), (3, 12, 261, 768)])
+def test_vit_qkv_rope_in_gemm_epilogue(B, H, N, D):
+    """qkv projection with RoPE + q scale + head-major store in the multi-phase GEMM's epilogue (DU_STORE_QKV_ROPE, rows past the last
+    256-row tile through du_qkv_rope_split_rows) vs the separate product + du_qkv_rope_split: identical q / k / v planes (same fp32 values,
+    same single bf16 rounding ... of the rotated value instead of rounding the projection first: compared at bf16 resolution), and the
+    attention output vs torch SDPA on the fp32 projection."""
+    from dinounet_amd import ops
+    d = dev()
+    bf = torch.bfloat16
+    Dh, prefix = 64, 5
+    h = q(gen(B * N, D, seed=1), bf)
+    w = q(gen(3 * H * Dh, D, seed=2, scale=D ** -0.5), bf)
+    bias = gen(3 * H * Dh, seed=3, scale=0.1)
+    ang = gen(N - prefix, Dh, seed=4)
+    sin, cos = torch.sin(ang), torch.cos(ang)
+    hd, wd, bd, sd, cd = h.to(d, bf), w.to(d, bf), bias.to(d), sin.to(d).contiguous(), cos.to(d).contiguous()
+    ws1, ws2 = {}, {}
+    ops.TRACK_ROUTE, ops.ROUTES[:] = True, []
+    fused_default = ops._QKV_FUSED
+    ops._QKV_FUSED = True                  # opt-in path (measured neutral in the step, see ops.py)
+    try:
+        out_f = ops.qkv_attention(hd, wd, bd, sd, cd, B, N, H, Dh, prefix, ws1)
+    finally:
+        ops.TRACK_ROUTE = False
+        ops._QKV_FUSED = fused_default
+    assert 4 in [r for _, _, r in ops.ROUTES], ops.ROUTES                 # the 256 x 128 multi-phase kernel took the fused store
+    out_u = ops.attention(ops.mm(hd, wd, bias=bd), sd, cd, B, N, H, Dh, prefix, ws2)
+    (k1,), (k2,) = ws1.keys(), ws2.keys()
+    for name, a, b in zip("qkv", ws1[k1], ws2[k2]):
+        assert rel(a, b) < 1.2e-2, name          # <= 1 bf16 ulp apart: the unfused path rounds the projection to bf16 before rotating it
+    assert rel(out_f, out_u) < 2e-2          # the 1-ulp q / k / v differences through the softmax
+    qkv = h @ w.t() + bias
+    qq, kk, vv = [t.transpose(1, 2) for t in qkv.view(B, N, 3, H, Dh).unbind(2)]
+
+    def rope(t):
+        a = t[:, :, prefix:]
+        x1, x2 = a.chunk(2, -1)
+        return torch.cat([t[:, :, :prefix], a * cos + torch.cat([-x2, x1], -1) * sin], 2)
+
+    ref = F.scaled_dot_product_attention(rope(qq), rope(kk), vv).transpose(1, 2).reshape(B * N, H * Dh)
+    assert rel(out_f, ref) < 3e-2
+    assert rel(out_u, ref) < 3e-2
+
+
 @pytest.mark.parametrize("B,H,W,C1,C2,Cout", [(2, 16, 32, 64, 0, 32), (1, 24, 16, 32, 32, 32), (2, 8, 16, 64, 64, 64), (1, 16, 16, 128, 128, 128),
                                               (1, 32, 48, 32, 0, 64), (3, 8, 16, 128, 0, 64)])
 def test_conv3x3_halo_kernel_fwd_bwd_stats(B, H, W, C1, C2, Cout):
