@@ -12,6 +12,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 # per-source extras.  attention.hip: MFMA results straight into VGPRs (the softmax reads every S^T accumulator with VALU ops; in the
 # accumulator half of the register file each one costs a v_accvgpr_read and a second register: 194 -> 166 registers, 2 -> 3 waves / SIMD)
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# kernels of these files must not use scratch: a register spill in a GEMM / attention / conv main loop or epilogue is a silent multi-ms
+# regression (seen: an address helper inlined into every epilogue put 576 bytes per lane of the 256 x 256 kernel on the stack, +7 ms per
+# step, all tests green).  The build reads hipcc's resource-usage remarks and fails on ScratchSize > 0 there.
+NO_SCRATCH = ("gemm_bf16.hip", "gemm_glds.hip", "gemm_p8.hip", "gemm_skinny.hip", "conv_halo.hip", "attention.hip")
+REMARK = "-Rpass-analysis=kernel-resource-usage"
 
 
 def _digest():
@@ -38,7 +43,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in SOURCES:
         o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(s, []), *([REMARK] if s in NO_SCRATCH else []), "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print("[dinounet_amd build]", " ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -47,6 +52,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError(f"hipcc failed on {s}")
+        if s in NO_SCRATCH:
+            name, spills = None, []
+            for ln in out.decode().splitlines():
+                if "Function Name:" in ln:
+                    name = ln.split("Function Name:")[1].split("[")[0].strip()
+                elif "ScratchSize [bytes/lane]:" in ln and int(ln.split("ScratchSize [bytes/lane]:")[1].split("[")[0]) > 0:
+                    spills.append(f"{name} ({ln.split('ScratchSize [bytes/lane]:')[1].split('[')[0].strip()} B/lane)")
+            if spills:
+                raise RuntimeError(f"{s}: kernels spill to scratch: " + "; ".join(spills[:6]))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     subprocess.check_call(cmd)
     # a kernel whose host stub the compiler dropped (seen once: a helper-lambda call inside an LDS-DMA builtin's arguments) links as an
