@@ -349,6 +349,10 @@ extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
   if (a.split_k > 1 && (a.out_dtype != DU_F32 || a.bias || a.act || a.gamma || (a.row_scale && !k_scale) || a.residual || a.store_mode)) return DU_ERR_BAD_ARG;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && a.residual && a.ldc % 1) return DU_ERR_BAD_ARG;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && (a.ps_C <= 0 || a.N != 4 * a.ps_C || a.M % (a.ps_H * a.ps_W))) return DU_ERR_BAD_ARG;
+  if (a.b_colsum) {                      // ConvT bias gradient from the gathered dY operand: bf16 weight-gradient kernels only
+    const int route = a.dtype == DU_BF16 && a.a_mode == DU_PLAIN_COL && a.b_mode == DU_IM2COL_COL && !getenv("DU_GEMM_GENERIC") ? du_gemm_route_bf16(a) : 0;
+    if ((route != 1 && route != 5) || a.geom.C <= 0 || a.N % a.geom.C) return DU_ERR_UNSUPPORTED;
+  }
   if (a.a_colsum) {                      // bias-gradient side sum: only the bf16 weight-gradient kernels accumulate it
     const int route = a.dtype == DU_BF16 && a.a_mode == DU_PLAIN_COL && !getenv("DU_GEMM_GENERIC") ? du_gemm_route_bf16(a) : 0;
     if (route != 1 && route != 5) return DU_ERR_UNSUPPORTED;

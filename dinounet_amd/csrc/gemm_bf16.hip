@@ -209,6 +209,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
   float csum[TM];
 #pragma unroll
   for (int i = 0; i < TM; i++) csum[i] = 0.f;
+  // the same for the gathered dY operand of a ConvTranspose weight gradient (du_gemm_args.b_colsum): one tile ROW per (tile column, split)
+  const bool bsum_on = (BMODE == DU_IM2COL_COL) && P.b_colsum && wm == 0 && tm == split % P.tiles_m;
+  float bsum[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++) bsum[j] = 0.f;
 
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk > 0) {
@@ -258,6 +263,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
             for (int e = 0; e < 8; e++) csum[i] += (float)fa[i][e];
         }
       }
+      if constexpr (BMODE == DU_IM2COL_COL) {
+        if (bsum_on) {
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) bsum[j] += (float)fb[j][e];
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -277,6 +290,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
       for (int i = 0; i < TM; i++) {
         const int m = m0 + (wm * TM + i) * 32 + (lane & 31);
         if (m < P.M) atomic_add_f32(P.a_colsum + m, csum[i]);
+      }
+    }
+  }
+  if constexpr (BMODE == DU_IM2COL_COL) {
+    if (bsum_on) {
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+        if (n < P.N) atomic_add_f32(P.b_colsum + n % P.b.C, bsum[j]);
       }
     }
   }

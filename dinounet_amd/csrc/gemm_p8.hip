@@ -554,6 +554,21 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
       }
     }
   };
+  // ConvT weight gradient (GA): bias gradient from the gathered dY operand (du_gemm_args.b_colsum): sum_k B(n, k) from the B fragments,
+  // by the two waves with wm == 0 of ONE tile row per (tile column, split); B-half 0 fragments are complete in phase q3, B-half 1 in q0
+  const bool bsum_on = TN && GA && P.b_colsum != nullptr && wm == 0 && tm == my_split % P.tiles_m;
+  float bsum[2] = {0.f, 0.f};                       // [B half j]
+  auto bsum_acc = [&](auto j_c, auto set_c) {
+    constexpr int j = decltype(j_c)::value, set = decltype(set_c)::value;
+    if constexpr (TN && GA) {
+      if (bsum_on) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) bsum[j] += (float)Bf[set][kk][e];
+      }
+    }
+  };
   // pin the issue order of a phase.  The compiler orders every ds_read of the phase before its LDS-DMA issues (it must assume they
   // alias), so the reads ride behind the first four MFMAs and the two DMA issues behind the next two.
   auto pin = [&](auto nrd_c) {
@@ -592,12 +607,14 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
     mma(IC<0>{}, IC<0>{}, IC<b0set>{});
     pin(IC<4>{});
     colsum_acc(IC<0>{});
+    bsum_acc(IC<0>{}, IC<b0set>{});
     finish(0);
     // q1
     readA(IC<1>{}, IC<p>{});
     if (!TAIL || t + 2 < nk) stage(IC<3>{}, IC<p>{}, t + 2);
     mma(IC<0>{}, IC<1>{}, IC<b1set>{});
     pin(IC<8>{});
+    bsum_acc(IC<1>{}, IC<b1set>{});
     finish(1);
     // q2
     if (!TAIL || t + 1 < nk) readA(IC<0>{}, IC<1 - p>{});
@@ -650,6 +667,15 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
           const int m = m0 + i * 128 + wm * 64 + b * 32 + (lane & 31);
           if (m < P.M) atomic_add_f32(P.a_colsum + m, csum[i][b]);
         }
+    }
+    if constexpr (GA) {
+      if (bsum_on) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int n = n0 + j * 128 + wn * 32 + (lane & 31);
+          if (n < P.N) atomic_add_f32(P.b_colsum + n % P.b.C, bsum[j]);
+        }
+      }
     }
     // split-K partial: fp32 atomics into the (zeroed) result.  Register r of a 32 x 32 block = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5),
     // lanes 0..31 = 32 consecutive columns (one 128-byte segment per row)

@@ -25,6 +25,7 @@ struct GemmParams {
   int tiles_m, group_m;   // grouped tile order (gemm_glds.hip): bands of group_m tile rows are walked column by column; 0 = row-major
   int dbg;                // measurement aids of gemm_p8.hip (du_set_option key 3); 0 in production
   float* a_colsum;        // weight-gradient kernels: a_colsum[m] += sum_k A(m, k) (bias gradient), fp32 atomics; NULL = off
+  float* b_colsum;        // ConvT weight gradient: b_colsum[n % b.C] += sum_k B(n, k) (bias gradient over the four taps); NULL = off
   const float* rope_sin; const float* rope_cos; int rope_prefix; float rope_qscale;     // DU_STORE_QKV_ROPE
   int k_scale;            // weight-gradient form (A contraction-major): row_scale[k / rs_rows] scales the CONTRACTION rows of A, not output rows
 };
@@ -115,7 +116,7 @@ inline GemmParams make_params(const du_gemm_args& a, int amode, int bmode, int B
   P.alpha = a.alpha; P.bias = a.bias; P.act = a.act; P.gamma = a.gamma; P.row_scale = a.row_scale;
   P.rs_rows = a.rs_rows > 0 ? a.rs_rows : 1; P.residual = a.residual; P.ldr = a.ldr;
   P.store_mode = a.store_mode; P.ps_H = a.ps_H; P.ps_W = a.ps_W; P.ps_C = a.ps_C;
-  P.a_colsum = a.a_colsum;
+  P.a_colsum = a.a_colsum; P.b_colsum = a.b_colsum;
   P.rope_sin = a.rope_sin; P.rope_cos = a.rope_cos; P.rope_prefix = a.rope_prefix; P.rope_qscale = a.rope_qscale;
   P.k_scale = (amode == DU_PLAIN_COL && a.row_scale) ? 1 : 0;
   P.tiles_n = (a.N + BN - 1) / BN;

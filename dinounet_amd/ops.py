@@ -134,7 +134,7 @@ ROUTES = []                  # (a_mode, b_mode, route) of every product since TR
 
 def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat, ldc, batch=1, abs_=0, bbs=0, cbs=0,
              split_k=1, alpha=1.0, bias=None, act=ACT_NONE, gamma=None, row_scale=None, rs_rows=0, residual=None, ldr=0,
-             store_mode=0, ps=(0, 0, 0), geom=None, a_colsum=None, rope=None, route_only=False):
+             store_mode=0, ps=(0, 0, 0), geom=None, a_colsum=None, b_colsum=None, rope=None, route_only=False):
     a = GemmArgs()
     a.dtype, a.out_dtype, a.a_mode, a.b_mode = dtype, out_dtype, a_mode, b_mode
     a.M, a.N, a.K = M, N, K
@@ -152,6 +152,7 @@ def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat,
     if geom is not None:
         a.geom = geom
     a.a_colsum = a_colsum
+    a.b_colsum = b_colsum
     if rope is not None:
         a.rope_sin, a.rope_cos, a.rope_prefix, a.rope_qscale = rope
     if route_only:
@@ -1042,15 +1043,23 @@ class _ConvT2x2(torch.autograd.Function):
             gemm_raw(dtype=_code(dy.dtype), out_dtype=_code(dx.dtype), a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * H * W,
                      N=Cin, K=4 * Cout, A=dy.data_ptr(), lda=lddy, B=wd.data_ptr(), ldb=4 * Cout, Cmat=dx.data_ptr(),
                      ldc=Cin, geom=g)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             gw = ZEROS.zeros((Cin, 4 * Cout), dy.device)
             npix = B * H * W
             tiles = ((Cin + 127) // 128) * ((4 * Cout + 127) // 128)
-            gemm_raw(dtype=_code(dy.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=IM2COL_COL, M=Cin, N=4 * Cout,
-                     K=npix, A=x.data_ptr(), lda=ld, B=dy.data_ptr(), ldb=lddy, Cmat=gw.data_ptr(), ldc=4 * Cout,
-                     split_k=_split_for(tiles, npix, 1024), geom=g)
+            kw = dict(dtype=_code(dy.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=IM2COL_COL, M=Cin, N=4 * Cout,
+                      K=npix, A=x.data_ptr(), lda=ld, B=dy.data_ptr(), ldb=lddy, Cmat=gw.data_ptr(), ldc=4 * Cout,
+                      split_k=_split_for(tiles, npix, 1024), geom=g)
+            if want_db and _WGRAD_COLSUM and dy.dtype == torch.bfloat16 and gemm_route(**kw) in (1, 5):
+                # bias gradient = sum over all dY pixels = sum over (input pixel, tap) of the gathered operand: taken inside the kernel
+                db = ZEROS.zeros((Cout,), dy.device)
+                gemm_raw(b_colsum=db.data_ptr(), **kw)
+                want_db = False
+            else:
+                gemm_raw(**kw)
             dw = gw.view(Cin, 2, 2, Cout).permute(0, 3, 1, 2).contiguous()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_db:
             Bo, Ho, Wo, Co, ldo = _nhwc(dy)
             db = colsum(dy.as_strided((Bo * Ho * Wo, Co), (ldo, 1), dy.storage_offset()))
         return dx, dw, db, (dy if ctx.has_res else None)

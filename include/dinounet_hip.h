@@ -116,6 +116,10 @@ typedef struct {
                          into a buffer the caller zero-initialised -- the bias gradient sum_rows dY for free while dY^T X streams dY
                          anyway (nn.Linear backward).  du_gemm returns DU_ERR_UNSUPPORTED if the kernel family serving the product
                          cannot do it (du_gemm_route != 1 and != 5): call du_colsum then */
+  float* b_colsum;    /* optional, ConvTranspose2d k2 s2 weight-gradient products only (a_mode PLAIN_COL, b_mode IM2COL_COL, bf16):
+                         b_colsum[n % geom.C] += sum_k B(n, k) -- every dY pixel appears exactly once among the (input pixel, tap) pairs, so
+                         this is the bias gradient sum_pixels dY[.., co]; same contract as a_colsum (zero-initialised, atomics,
+                         DU_ERR_UNSUPPORTED unless du_gemm_route is 1 or 5) */
 } du_gemm_args;
 
 int du_gemm(const du_gemm_args* args, void* stream);
