@@ -379,3 +379,25 @@ def test_compact_checkpoint_round_trip_and_reference_key_contract(tmp_path):
     with pytest.raises(ValueError):
         CK.expand_state_dict(compact, meta, backbone_state=bb)
     assert CK.expand_state_dict(compact, meta, backbone_state=bb, check=False)["encoder.dinov3_adapter.backbone.cls_token"] is bb["cls_token"]
+
+
+def test_test_time_mirroring_matches_reference_golden():
+    """Test-time mirroring: the oracle restatement AND the product's host logic (inference._mirror_and_predict around any forward) reproduce
+    the outputs of the reference's own nnUNetPredictor._internal_maybe_mirror_and_predict (tests/golden/sliding_window_mirror.npz, written
+    by oracle/make_golden_mirror.py from predict_from_raw_data.py:537-552 driving a small non-symmetric stand-in network)."""
+    from oracle import sliding_window_oracle as SW
+    from oracle.make_golden_mirror import toy_network
+    from dinounet_amd import inference as INF
+    g = np.load(os.path.join(GOLD, "sliding_window_mirror.npz"))
+    x = torch.from_numpy(g["x"])
+    i = 0
+    while f"axes{i}" in g:
+        axes = None if int(g[f"axes{i}"][0]) < 0 else tuple(int(a) for a in g[f"axes{i}"])
+        want = torch.from_numpy(g[f"y{i}"])
+        assert torch.allclose(SW.mirror_and_predict(toy_network, x.clone(), axes), want, rtol=0, atol=1e-6)
+        combos = INF.mirror_axes_combinations(axes, x.ndim)
+        assert len(combos) == (0 if axes is None else 2 ** len(axes) - 1)
+        assert torch.allclose(INF._mirror_and_predict(toy_network, x.clone(), combos), want, rtol=0, atol=1e-6)
+        i += 1
+    assert i == 4
+    assert not torch.allclose(torch.from_numpy(g["y0"]), torch.from_numpy(g["y3"]), atol=1e-3)      # mirroring changes the prediction
