@@ -507,7 +507,8 @@ int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
       if (a.row_scale) tail.row_scale = a.row_scale + m0 / a.rs_rows;
       du_gemm_args head = a;
       head.M = (int)m0;
-      // (forking the tail onto a side stream with event edges measured slower, eager and inside a hipGraph: 191.6 vs 194.0 slices/s)
+      // (forking the tail onto a side stream with event edges measured slower both times it was tried, inside the hipGraph: round 1 beside
+      // the 128 x 128 kernels 191.6 vs 194.0 slices/s; round 2 beside the multi-phase kernels, 8 KB-LDS tail form, 33.9 vs 33.2 ms per step)
       int rc = nt_tiles(head, st);
       if (rc == DU_OK) {
         rc = du_gemm_skinny(tail, st);
