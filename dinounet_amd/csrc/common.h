@@ -44,6 +44,19 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
+// acc + the sum of the 8 bf16 of an MFMA operand fragment, in fp32: four v_dot2c_f32_bf16 against (1, 1) instead of eight converts + eight
+// adds (the bias-gradient side sums of the weight-gradient kernels run in the MFMA loop's VALU shadow: instruction count is what they cost)
+__device__ __forceinline__ float frag_sum8(const bf16x8& f, float acc) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const bf16x2_t pr = {f[2 * e], f[2 * e + 1]};
+    acc = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, acc, false);
+  }
+  return acc;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case DU_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));

@@ -203,8 +203,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   // bias-gradient side sum (du_gemm_args.a_colsum, weight-gradient products): sum_k A(m, k) for this tile's rows, taken by ONE tile column
-  // per (tile row, split) -- tn == split % tiles_n spreads that extra VALU work over the workgroups -- from the A fragments the MFMAs
-  // consume anyway (lane l holds row (l & 31), 8 consecutive k per k-step: every k of the tile exactly once across the two half-waves)
+  // per (tile row, split) -- tn == split % tiles_n rotates that duty over the columns -- from the A fragments the MFMAs consume anyway
+  // (lane l holds row (l & 31), 8 consecutive k per k-step: every k of the tile exactly once across the two half-waves).  The owner
+  // test is loop-invariant on purpose: the compiler unswitches the K loop, so only the owners run the slower variant (+10..25 % on their
+  // launch).  Dealing the K tiles out over ALL columns (a per-iteration test, tried with a modulo and with a counter) slowed every
+  // workgroup's loop and lost the whole gain: 35.2 vs 33.9 ms per step.
   const bool colsum_on = (AMODE == DU_PLAIN_COL) && P.a_colsum && wn == 0 && tn == split % P.tiles_n;
   float csum[TM];
 #pragma unroll
@@ -259,16 +262,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
         if (colsum_on) {
 #pragma unroll
           for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) csum[i] += (float)fa[i][e];
+            csum[i] = frag_sum8(fa[i], csum[i]);
         }
       }
       if constexpr (BMODE == DU_IM2COL_COL) {
         if (bsum_on) {
 #pragma unroll
           for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) bsum[j] += (float)fb[j][e];
+            bsum[j] = frag_sum8(fb[j], bsum[j]);
         }
       }
 #pragma unroll

@@ -549,8 +549,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
         for (int b = 0; b < 2; b++)
 #pragma unroll
           for (int kk = 0; kk < 4; kk++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) csum[i][b] += (float)Af[i][b][kk][e];
+            csum[i][b] = frag_sum8(Af[i][b][kk], csum[i][b]);
       }
     }
   };
@@ -564,8 +563,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
       if (bsum_on) {
 #pragma unroll
         for (int kk = 0; kk < 4; kk++)
-#pragma unroll
-          for (int e = 0; e < 8; e++) bsum[j] += (float)Bf[set][kk][e];
+          bsum[j] = frag_sum8(Bf[set][kk], bsum[j]);
       }
     }
   };
