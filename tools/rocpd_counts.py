@@ -1,3 +1,7 @@
+#!/usr/bin/env python
+"""Kernels of a rocprofv3 rocpd SQLite database (--kernel-trace) sorted by LAUNCH COUNT: launches per step, average duration, ms per step.
+A launch costs ~5 us inside the replayed train-step graph whatever it does, so this is the to-do list for launch merging.
+usage: python tools/rocpd_counts.py <results.db> <steps in the trace>"""
 import sqlite3,sys,re
 c=sqlite3.connect(sys.argv[1]); steps=int(sys.argv[2])
 rows=c.execute("select name, count(*), sum(end-start) from kernels group by name order by count(*) desc").fetchall()
