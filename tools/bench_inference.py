@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--eager", action="store_true", help="no hipGraph capture of the window forward")
+    ap.add_argument("--mirror", action="store_true", help="test-time mirroring over both in-plane axes (4 forwards per window batch)")
     a = ap.parse_args()
     from dinounet_amd.plans import PLANS_2D
     from dinounet_amd.network_architecture import DinoUNet
@@ -31,16 +32,18 @@ def main():
     net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name=a.model, precision="bf16").to(dev).eval()
     data = torch.randn(3, a.slices, a.size, a.size, generator=torch.Generator().manual_seed(1)).to(dev)
     nwin = len(INF.sliding_window_origins((a.slices, a.size, a.size), (512, 512), 0.5))
-    INF.predict_sliding_window_logits(net, data, (512, 512), 0.5, True, a.batch, graph=not a.eager)
+    mirror = (0, 1) if a.mirror else None
+    INF.predict_sliding_window_logits(net, data, (512, 512), 0.5, True, a.batch, graph=not a.eager, mirror_axes=mirror)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.reps):
-        out = INF.predict_sliding_window_logits(net, data, (512, 512), 0.5, True, a.batch, graph=not a.eager)
+        out = INF.predict_sliding_window_logits(net, data, (512, 512), 0.5, True, a.batch, graph=not a.eager, mirror_axes=mirror)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.reps
     print(json.dumps({"metric": "sliding-window inference, 512x512 windows, step 0.5, gaussian", "model": a.model, "volume": [a.slices, a.size, a.size],
                       "windows": nwin, "window_batch": a.batch, "s_per_volume": round(dt, 4), "windows_per_s": round(nwin / dt, 1),
-                      "slices_per_s": round(a.slices / dt, 2), "logits_shape": list(out.shape), "dtype": "bf16", "hipgraph": not a.eager}))
+                      "slices_per_s": round(a.slices / dt, 2), "logits_shape": list(out.shape), "dtype": "bf16", "hipgraph": not a.eager,
+                      "mirror_axes": list(mirror) if mirror else None}))
 
 
 if __name__ == "__main__":
