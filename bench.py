@@ -119,7 +119,9 @@ def main():
     ms = dt / a.steps * 1e3
     value = a.batch * world / (dt / a.steps)
 
-    out = {"metric": "2D slices/sec training, dinounet_l 512x512 bf16", "value": round(value, 3), "unit": "slices/s",
+    # BASELINE.json's metric for the default workload; other --model / --size / --precision runs name what they measured
+    metric = f"2D slices/sec training, {a.model} {a.size}x{a.size} {a.precision}"
+    out = {"metric": metric, "value": round(value, 3), "unit": "slices/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
            "config": {"workload": f"{a.model} train step (fwd+loss+bwd+clip+SGD), {a.size}x{a.size}x3 slices, batch {a.batch}/GPU, "
