@@ -401,3 +401,52 @@ def test_test_time_mirroring_matches_reference_golden():
         i += 1
     assert i == 4
     assert not torch.allclose(torch.from_numpy(g["y0"]), torch.from_numpy(g["y3"]), atol=1e-3)      # mirroring changes the prediction
+
+
+def test_gemm_dispatch_host_logic_without_gpu():
+    """du_gemm's kernel-family choice (du_gemm_route: pure host logic of csrc/gemm*.hip, no launch) for the shapes of a dinounet_l
+    512^2 batch-8 train step -- a regression guard for the dispatch heuristics the measured numbers in DESIGN.md / profiles/ rest on:
+    0 generic, 1 bf16 128 x 128 engine, 2 direct-to-LDS 128 x 128, 3 / 4 multi-phase 256 x 256 / 256 x 128, 5 multi-phase weight-gradient."""
+    import ctypes as C
+    from dinounet_amd import _lib
+    from dinounet_amd._lib import (DU_BF16, DU_F32, IM2COL_COL, IM2COL_ROW, PLAIN_COL, PLAIN_ROW, ConvGeom, GemmArgs)
+    L = _lib.lib()
+
+    def route(M, N, K, am=PLAIN_ROW, bm=PLAIN_ROW, dt=DU_BF16, od=DU_BF16, split=1, geom=None, lda=None, ldb=None, row_scale=False):
+        a = GemmArgs()
+        a.dtype, a.out_dtype, a.a_mode, a.b_mode = dt, od, am, bm
+        a.M, a.N, a.K = M, N, K
+        a.A, a.B, a.C = 0x100000, 0x200000, 0x300000          # aligned fake addresses: nothing is dereferenced
+        a.lda = lda or (K if am == PLAIN_ROW else M)
+        a.ldb = ldb or (K if bm == PLAIN_ROW else N)
+        a.ldc = N
+        a.batch, a.split_k, a.alpha = 1, split, 1.0
+        if row_scale:
+            a.row_scale, a.rs_rows = 0x400000, 5376
+        if geom is not None:
+            a.geom = geom
+        return int(L.du_gemm_route(C.byref(a))), int(L.du_gemm_ws_elems(C.byref(a)))
+
+    # frozen ViT-L, M = 8 * 1029 tokens: 256 x 128 tiles for qkv / proj / fc2, 256 x 256 for fc1; the 40 ragged rows leave the tile grid
+    assert route(8232, 3072, 1024)[0] == 4 and route(8232, 4096, 1024)[0] == 3
+    assert route(8232, 1024, 4096, od=DU_F32)[0] == 4 and route(8232, 1024, 1024, od=DU_F32)[0] == 4
+    assert route(8232, 3072, 1024)[1] > 0 and route(8192, 3072, 1024)[1] == 0
+    # adapter / FAPM linears: K = 192 is not a multiple of 128 -> direct-to-LDS 128 x 128; few tiles -> not the multi-phase kernels
+    assert route(43008, 1024, 192)[0] == 2 and route(2048, 256, 256)[0] == 2
+    assert route(43008, 1024, 512)[0] in (3, 4) and route(131072, 512, 1024)[0] == 3
+    # weight gradients: short splits stay on the 128 x 128 engine (atomics per workgroup), long ones go to the multi-phase TN form;
+    # a DropPath row scale on the contraction rows is implemented by the 128 x 128 engine only
+    assert route(1024, 512, 43008, PLAIN_COL, PLAIN_COL, od=DU_F32, split=16)[0] == 1
+    assert route(512, 1024, 131072, PLAIN_COL, PLAIN_COL, od=DU_F32, split=16)[0] == 5
+    assert route(512, 1024, 131072, PLAIN_COL, PLAIN_COL, od=DU_F32, split=16, row_scale=True)[0] == 1
+    assert route(512, 1024, 131072, PLAIN_COL, PLAIN_COL, od=DU_F32, split=1)[0] == 1           # no split requested: C is not known to be zeroed
+    # ConvTranspose2d k2 s2 1024 -> 1024 on a 64 x 64 grid (the adapter's `up`): both gradients gather dY in place on the multi-phase kernels
+    g = ConvGeom()
+    g.Hi, g.Wi, g.C, g.C1, g.KH, g.KW, g.stride, g.pad, g.Ho, g.Wo, g.transposed = 128, 128, 1024, 1024, 2, 2, 2, 0, 64, 64, 0
+    assert route(32768, 1024, 4096, IM2COL_ROW, PLAIN_ROW, geom=g, lda=1024, ldb=4096)[0] == 3
+    assert route(1024, 4096, 32768, PLAIN_COL, IM2COL_COL, od=DU_F32, split=4, geom=g, lda=1024, ldb=1024)[0] == 5
+    g3 = ConvGeom()
+    g3.Hi, g3.Wi, g3.C, g3.C1, g3.KH, g3.KW, g3.stride, g3.pad, g3.Ho, g3.Wo, g3.transposed = 512, 512, 64, 64, 3, 3, 2, 1, 256, 256, 0
+    assert route(64, 576, 524288, PLAIN_COL, IM2COL_COL, od=DU_F32, split=64, geom=g3, lda=64, ldb=64)[0] == 1        # 3 x 3 im2col: no gather form
+    # fp32 parity mode: the generic exact-fp32 kernel
+    assert route(8232, 3072, 1024, dt=DU_F32, od=DU_F32)[0] == 0
