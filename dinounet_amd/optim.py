@@ -100,8 +100,7 @@ class FusedClipSGD(torch.optim.Optimizer):
             t = self._tab_host[self._flip]
             if self._tab_evt[self._flip] is not None:
                 self._tab_evt[self._flip].synchronize()       # the copy that last read this pinned table (two steps ago) has finished
-        for i, p in enumerate(active):
-            t[i, 1] = p.grad.data_ptr()
+        t.numpy()[:, 1] = [p.grad.data_ptr() for p in active]         # one vectorised write (285 indexed tensor writes cost ~1 ms of host time)
         self._tab_dev.copy_(t, non_blocking=True)
         if not capturing:
             ev = torch.cuda.Event()

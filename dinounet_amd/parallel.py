@@ -119,14 +119,22 @@ class GradAllReducer:
     def _gather(self, bi):
         from . import _lib
         g = self.gather[bi]
-        host = g["host_cap"] if torch.cuda.is_current_stream_capturing() else g["host"]
-        for i, (_, p) in enumerate(self.buckets[bi]):
+        capturing = torch.cuda.is_current_stream_capturing()
+        host = g["host_cap"] if capturing else g["host"]
+        if not capturing and g.get("evt") is not None:
+            g["evt"].synchronize()         # the previous step's asynchronous copy of this pinned table has been read (the host may run ahead)
+        ptrs = []
+        for _, p in self.buckets[bi]:
             gr = p.grad
             if gr.dtype != torch.float32 or not gr.is_contiguous():
                 gr = gr.float().contiguous()
                 self._keep.append(gr)
-            host[i, 0] = gr.data_ptr()
+            ptrs.append(gr.data_ptr())
+        host.numpy()[:, 0] = ptrs
         g["dev"].copy_(host, non_blocking=True)
+        if not capturing:
+            g["evt"] = torch.cuda.Event()
+            g["evt"].record()
         _lib.check(_lib.lib().du_pack_weights(g["dev"].data_ptr(), g["pre"].data_ptr(), g["n"], g["nblocks"],
                                               torch.cuda.current_stream().cuda_stream), "du_pack_weights")
 
