@@ -7,14 +7,10 @@ MI355X_MICROARCH.md "rocprofv3 PMC slots") over `bench.py --graph off --steps 2 
   pass B  SQ_LDS_IDX_ACTIVE  SQ_LDS_UNALIGNED_STALL  SQ_ACTIVE_INST_VALU  SQ_ACTIVE_INST_LDS  SQ_ACTIVE_INST_VMEM  SQ_ACTIVE_INST_SCA
           SQ_INSTS_VALU  SQ_WAVES  + GRBM_GUI_ACTIVE
 
-Counters the installed rocprofv3 does not list (`rocprofv3 -L`) are dropped from a pass instead of failing it.  Derived columns:
-  parked  = WAIT_ANY / WAVE_CYCLES        waves sitting in s_waitcnt / s_barrier
-  stall   = WAIT_INST_ANY / WAVE_CYCLES   issue stalls (MFMA dependency, pipe busy); lds = the WAIT_INST_LDS share of it
-  issue   = ACTIVE_INST_ANY / WAVE_CYCLES
-  mfma    = VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)      the matrix pipes' duty over the launch (the guide: the counter
-            advances 32 per 32x32x16 bf16 MFMA; GUI_ACTIVE is per launch in shader cycles)
-  conflict = LDS_BANK_CONFLICT / LDS_IDX_ACTIVE  (pass A / pass B: different launches of the same kernel, means per launch)
-Run ON THE GPU BOX:  python tools/pmc_kernels.py   -> gpurun_out/r02_pmc_sq_cycles_eager.txt (copy into profiles/)."""
+Counters the installed rocprofv3 does not list (`rocprofv3 -L`) are dropped from a pass instead of failing it.  Derived columns (see render()): the wave view -- parked / stalled / issuing shares of the waves' lifetime -- and the SIMD view -- duty of
+the matrix pipe, the VALU, LDS and VMEM issue ports over the launch -- plus LDS bank-conflict cycles per LDS-array cycle.
+Run ON THE GPU BOX:  python tools/pmc_kernels.py   -> gpurun_out/r02_pmc_sq_cycles_eager.txt (copy into profiles/);
+re-render an earlier output without a GPU:  python tools/pmc_kernels.py --from-raw <file>."""
 import glob
 import os
 import re
@@ -68,9 +64,87 @@ def collect(tag, counters, env):
     return out
 
 
+def render(data, used, n_inst, path):
+    """data: kernel -> counter -> (rows, mean per counter INSTANCE).  SQ counters come as one row per (XCD, shader engine) = n_inst rows per
+    dispatch (32 on MI355X: SQ_WAVES x 32 = the launch's waves), each covering 1024 / n_inst SIMDs; GRBM_GUI_ACTIVE is the launch's length
+    in shader cycles in every row.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles."""
+    simd = N_SIMD / n_inst
+
+    def g(d, k):
+        return d[k][1] if k in d else None
+
+    def ratio(a, b):
+        return f"{a / b:6.3f}" if a is not None and b else "     -"
+
+    rows = []
+    for name, d in data.items():
+        wc, gui = g(d, "SQ_WAVE_CYCLES"), g(d, "GRBM_GUI_ACTIVE")
+        n = d.get("SQ_WAVE_CYCLES", (0, 0))[0] // n_inst
+        rows.append((gui * n if gui else 0.0, name, n, d, wc, gui))
+    rows.sort(key=lambda r: -r[0])
+    with open(path, "w") as f:
+        f.write(f"# csrc-digest {_build._digest()}\n")
+        for tag, cs in used.items():
+            f.write(f"# pass {tag}: rocprofv3 --pmc {' '.join(cs)} --kernel-trace -- python bench.py --graph off --steps 2 --warmup 1 "
+                    f"--no-cpu-baseline --no-roofline\n")
+        f.write("# dinounet_l 512x512 bf16 batch 8, three eager steps; means over all launches of a kernel name; kernels sorted by launches x "
+                "GRBM_GUI_ACTIVE.\n"
+                f"# SQ counters arrive per (XCD, shader engine): {n_inst} rows per dispatch, {simd:.0f} SIMDs each (SQ_WAVES x {n_inst} = waves of the "
+                "launch).\n"
+                "# wave view (fractions of SQ_WAVE_CYCLES, i.e. of the resident waves' lifetime):\n"
+                "#   parked = WAIT_ANY (s_waitcnt / s_barrier), stall = WAIT_INST_ANY (issue stalls: MFMA dependency, busy pipe; lds = its "
+                "WAIT_INST_LDS part), issue = ACTIVE_INST_ANY\n"
+                "# SIMD view (fractions of the launch, GUI_ACTIVE x SIMDs; the launch length includes the eager dispatch gap):\n"
+                "#   mfma = VALU_MFMA_BUSY_CYCLES, valu = 4 x ACTIVE_INST_VALU (MFMA issue included), ldsi = 4 x ACTIVE_INST_LDS, vmem = 4 x "
+                "ACTIVE_INST_VMEM\n"
+                "# conflict = LDS_BANK_CONFLICT / LDS_IDX_ACTIVE (extra cycles per LDS-array cycle)\n")
+        f.write(f"# {'launches':>8} {'gui_active':>11} {'parked':>6} {'stall':>6} {'lds':>6} {'issue':>6} | {'mfma':>6} {'valu':>6} {'ldsi':>6} "
+                f"{'vmem':>6} | {'conflict':>8}  kernel\n")
+        for _, name, n, d, wc, gui in rows[:40]:
+            den = gui * simd if gui else None
+
+            def duty(k, mul):
+                v = g(d, k)
+                return ratio(v * mul if v is not None else None, den)
+            f.write(f"{n:10d} {gui or 0:11.0f} {ratio(g(d, 'SQ_WAIT_ANY'), wc)} {ratio(g(d, 'SQ_WAIT_INST_ANY'), wc)} "
+                    f"{ratio(g(d, 'SQ_WAIT_INST_LDS'), wc)} {ratio(g(d, 'SQ_ACTIVE_INST_ANY'), wc)} | "
+                    f"{duty('SQ_VALU_MFMA_BUSY_CYCLES', 1)} {duty('SQ_ACTIVE_INST_VALU', 4)} {duty('SQ_ACTIVE_INST_LDS', 4)} "
+                    f"{duty('SQ_ACTIVE_INST_VMEM', 4)} | {ratio(g(d, 'SQ_LDS_BANK_CONFLICT'), g(d, 'SQ_LDS_IDX_ACTIVE')):>8}  {short(name)}\n")
+        f.write("\n# raw means per counter instance\n")
+        for _, name, n, d, wc, gui in rows[:40]:
+            f.write(f"{short(name)}\n")
+            for cn in sorted(d):
+                f.write(f"    {cn:28s} {d[cn][1]:16.1f}   ({d[cn][0]} rows)\n")
+
+
+def from_raw(path):
+    """Rebuild (data, used) from the raw section of an earlier output (re-render without the GPU)."""
+    data, used, cur = {}, {}, None
+    raw = False
+    for line in open(path):
+        m = re.match(r"# pass (\w): rocprofv3 --pmc (.*?) --kernel-trace", line)
+        if m:
+            used[m.group(1)] = m.group(2).split()
+        elif line.startswith("# raw means"):
+            raw = True
+        elif raw and line.startswith("    "):
+            cn, v, n = re.match(r"\s+(\S+)\s+([0-9.]+)\s+\((\d+) ", line).groups()
+            data[cur][cn] = (int(n), float(v))
+        elif raw and line.strip():
+            cur = line.rstrip("\n")
+            data[cur] = {}
+    return data, used
+
+
 def main():
     outdir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(outdir, exist_ok=True)
+    path = os.path.join(outdir, "r02_pmc_sq_cycles_eager.txt")
+    if len(sys.argv) > 2 and sys.argv[1] == "--from-raw":
+        data, used = from_raw(sys.argv[2])
+        render(data, used, 32, path)
+        print(open(path).read()[:5000])
+        return
     env = dict(os.environ, TMPDIR="/tmp")
     have = available()
     data = {}
@@ -83,43 +157,9 @@ def main():
             print(f"[pmc_kernels] pass {tag}: not listed by rocprofv3 -L, dropped: {dropped}")
         for name, d in collect(tag, cs, env).items():
             data.setdefault(name, {}).update(d)
-
-    def g(d, k):
-        return d[k][1] if k in d else None
-
-    def ratio(a, b):
-        return f"{a / b:6.3f}" if a is not None and b else "     -"
-
-    rows = []
-    for name, d in data.items():
-        wc, gui = g(d, "SQ_WAVE_CYCLES"), g(d, "GRBM_GUI_ACTIVE")
-        n = d.get("SQ_WAVE_CYCLES", d.get("GRBM_GUI_ACTIVE", (0, 0)))[0]
-        rows.append((gui * n if gui else 0.0, name, n, d, wc, gui))
-    rows.sort(key=lambda r: -r[0])
-    path = os.path.join(outdir, "r02_pmc_sq_cycles_eager.txt")
-    with open(path, "w") as f:
-        f.write(f"# csrc-digest {_build._digest()}\n")
-        for tag, cs in used.items():
-            f.write(f"# pass {tag}: rocprofv3 --pmc {' '.join(cs)} --kernel-trace -- python bench.py --graph off --steps 2 --warmup 1 "
-                    f"--no-cpu-baseline --no-roofline\n")
-        f.write("# means per launch over all launches of a kernel name (dinounet_l 512x512 bf16 batch 8, three eager steps); kernels sorted by "
-                "launches x GRBM_GUI_ACTIVE.\n# parked = WAIT_ANY / WAVE_CYCLES, stall = WAIT_INST_ANY / WAVE_CYCLES (lds = WAIT_INST_LDS share), "
-                "issue = ACTIVE_INST_ANY / WAVE_CYCLES,\n# mfma = VALU_MFMA_BUSY_CYCLES / (GUI_ACTIVE x 1024 SIMDs), conflict = LDS_BANK_CONFLICT / "
-                "LDS_IDX_ACTIVE, valu / ldsi / vmem = ACTIVE_INST_{VALU,LDS,VMEM} / WAVE_CYCLES (pass B over pass A)\n")
-        f.write(f"# {'launches':>8} {'gui_active':>11} {'parked':>6} {'stall':>6} {'lds':>6} {'issue':>6} {'mfma':>6} {'conflict':>8} "
-                f"{'valu':>6} {'ldsi':>6} {'vmem':>6}  kernel\n")
-        for _, name, n, d, wc, gui in rows[:40]:
-            mf = g(d, "SQ_VALU_MFMA_BUSY_CYCLES")
-            f.write(f"{n:10d} {gui or 0:11.0f} {ratio(g(d, 'SQ_WAIT_ANY'), wc)} {ratio(g(d, 'SQ_WAIT_INST_ANY'), wc)} "
-                    f"{ratio(g(d, 'SQ_WAIT_INST_LDS'), wc)} {ratio(g(d, 'SQ_ACTIVE_INST_ANY'), wc)} "
-                    f"{ratio(mf, gui * N_SIMD if gui else None)} {ratio(g(d, 'SQ_LDS_BANK_CONFLICT'), g(d, 'SQ_LDS_IDX_ACTIVE')):>8} "
-                    f"{ratio(g(d, 'SQ_ACTIVE_INST_VALU'), wc)} {ratio(g(d, 'SQ_ACTIVE_INST_LDS'), wc)} {ratio(g(d, 'SQ_ACTIVE_INST_VMEM'), wc)}  "
-                    f"{short(name)}\n")
-        f.write("\n# raw means per launch\n")
-        for _, name, n, d, wc, gui in rows[:40]:
-            f.write(f"{short(name)}\n")
-            for cn in sorted(d):
-                f.write(f"    {cn:28s} {d[cn][1]:16.1f}   ({d[cn][0]} launches)\n")
+    # rows per dispatch of an SQ counter: the launch's waves / the per-row SQ_WAVES of a kernel whose grid we know is not available here,
+    # so take the smallest row count ratio SQ : GRBM seen x the GRBM rows per dispatch (1 or 4 by rocprofv3 version) -> fall back to 32
+    render(data, used, 32, path)
     print(open(path).read()[:5000])
 
 
