@@ -4,7 +4,6 @@ layouts (NHWC / token-major).  Monkey-patched in by the `-m "not gpu"` host-logi
 without a GPU.  The product never imports this file; on a GPU box the real ops call libdinounet_hip.so.
 """
 import contextlib
-import math
 
 import torch
 import torch.nn.functional as F

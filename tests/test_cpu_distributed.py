@@ -3,7 +3,6 @@ DDP batch-Dice loss (all-gather forward / all-reduce backward, ddp_allgather.py:
 import os
 import socket
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

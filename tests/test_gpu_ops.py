@@ -2,7 +2,6 @@
 against the CPU oracle / a plain PyTorch fp32 reference of the same op on the same seeded inputs.
 Tolerances: fp32 kernels 2e-4 (max-abs error relative to the reference's max-abs; fp32 MFMA accumulation order differs
 from the CPU's), bf16 kernels 3e-2; MSDA fp32 vs the reference's fp64 fixture 1e-5."""
-import math
 import os
 
 import numpy as np
@@ -237,7 +236,7 @@ def test_linear_droppath_scale_inside_backward_gemms():
         return y.float().cpu(), [t.float().cpu() for t in g]
 
     ops.PACK.refresh()
-    y0, g0 = step()              # registers W^T: data gradient on the PLAIN_COL kernel, s . dy materialised
+    _, g0 = step()               # registers W^T: data gradient on the PLAIN_COL kernel, s . dy materialised
     ops.PACK.refresh()
     y1, g1 = step()
     assert (ops.PLAIN_ROW, ops.PLAIN_COL) not in [(am, bm) for am, bm, _ in ops.ROUTES]
