@@ -133,6 +133,7 @@ class GPUAugment2D:
         if ((d["zoom"] > 0) & (d["zoom"] < 1)).any():
             _lib.check(L.du_aug_lowres(_p(out), _p(tmp), _p(t_zoom), P, H, W, _st()), "du_aug_lowres")
             out, tmp = tmp, out
+        keep = []                      # operands of the asynchronous launches below stay referenced until apply() returns
         for key, inv in (("gamma_inv", 1.0), ("gamma", 0.0)):
             g = d[key]
             if not (g > 0).any():

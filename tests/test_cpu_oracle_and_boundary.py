@@ -203,6 +203,45 @@ def test_host_glue_train_mode_and_grads():
     assert sorted(k for k, p in named.items() if p.requires_grad and p.grad is None) == meta["unused"]
 
 
+def test_deep_supervision_oracle_and_host_glue_match_reference_golden():
+    """deep_supervision=True (dinounet_training.py:603-629): the oracle restatement AND the product's module wiring (kernels replaced by the
+    torch shim) against the reference's three logits tensors, the weighted loss and the gradient norms of dinounet_s_64_ds_train.npz."""
+    import _cpu_op_shim as shim
+    from dinounet_amd.network_architecture import DinoUNet
+    from dinounet_amd.dinov3.adapter import DropPath
+    g, meta = _load("dinounet_s_64_ds_train")
+    x = weights.make_input(2, 3, 64, 64, seed=1)
+    tgt = weights.make_target(2, 64, 64, 2, seed=1)
+    with torch.no_grad():
+        outs = O.dinounet_forward(x, _sd("dinounet_s"), "dinounet_s", training=True, deep_supervision=True)
+    assert [tuple(o.shape) for o in outs] == [(2, 2, 64, 64), (2, 2, 32, 32), (2, 2, 16, 16)]
+    for i, o in enumerate(outs):
+        assert rel(o, torch.from_numpy(g[f"logits{i}"])) < 2e-5, i
+    plans = dict(PLANS_2D, architecture=dict(PLANS_2D["architecture"], deep_supervision=True))
+    net = DinoUNet.from_config(plans, 3, 2, dinov3_pretrained_path=None, dinov3_model_name="dinounet_s", precision="fp32")
+    net.load_state_dict(_sd("dinounet_s"), strict=True)
+    net.train()
+    for m in net.modules():
+        if isinstance(m, DropPath):
+            m.drop_prob = 0.0
+    net.encoder.dinov3_adapter.backbone.rope_embed.rescale_coords = None
+    with shim.patched_ops():
+        ys = net.decoder(net.encoder(x))
+        assert isinstance(ys, list) and len(ys) == 3
+        loss = sum(w * O.dc_and_ce_loss(y, tgt[..., ::2 ** i, ::2 ** i].contiguous()) for i, (y, w) in enumerate(zip(ys, meta["ds_weights"])))
+        loss.backward()
+    for i, y in enumerate(ys):
+        assert rel(y.detach(), torch.from_numpy(g[f"logits{i}"])) < 2e-5, i
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    norms = meta["grad_norms"]
+    gmax = max(norms.values())
+    named = dict(net.named_parameters())
+    for k, n in norms.items():
+        got = float(named[k].grad.norm())
+        assert abs(got - n) <= 5e-3 * max(n, 1e-3 * gmax), (k, got, n)
+    assert sorted(k for k, p in named.items() if p.requires_grad and p.grad is None) == meta["unused"]
+
+
 def test_host_glue_pinned_train_randomness():
     """train() with the per-block RoPE rescale draws and the DropPath masks pinned to the values the reference was given
     (oracle/make_golden.py: pin_reference_randomness): the product's wiring of both random ops (device-side draws replaced through the

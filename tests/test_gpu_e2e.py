@@ -24,9 +24,10 @@ def _load(name):
     return g, json.loads(str(g["meta"]))
 
 
-def _build(model, num_classes, precision):
+def _build(model, num_classes, precision, deep_supervision=False):
     from dinounet_amd.network_architecture import DinoUNet
-    net = DinoUNet.from_config(PLANS_2D, 3, num_classes, dinov3_pretrained_path=None, dinov3_model_name=model, precision=precision)
+    plans = PLANS_2D if not deep_supervision else dict(PLANS_2D, architecture=dict(PLANS_2D["architecture"], deep_supervision=True))
+    net = DinoUNet.from_config(plans, 3, num_classes, dinov3_pretrained_path=None, dinov3_model_name=model, precision=precision)
     ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
     net.load_state_dict(weights.make_state_dict(ks, seed=0), strict=True)
     return net.cuda()
@@ -153,12 +154,71 @@ def test_train_step_fp32_vs_reference():
             worst = (k, err)
     print(f"worst grad-norm deviation {worst[1]:.2e} at {worst[0]}")
     assert worst[1] < 1e-2, worst
+    errs = []
     for key in g.files:
         if key.startswith("grad:"):
             k = key[5:]
             ref = torch.from_numpy(g[key])
             if ref.norm() > 1e-3 * gmax:
-                assert float((named[k].grad.cpu() - ref).norm() / ref.norm()) < 2e-2, k
+                errs.append((float((named[k].grad.cpu() - ref).norm() / ref.norm()), float(ref.norm() / gmax), k))
+    errs.sort(reverse=True)
+    for e, n, k in errs[:6]:
+        print(f"  full-gradient rel-L2 {e:.2e}  (|g| / max|g| = {n:.1e})  {k}")
+    assert errs[0][0] < 2e-2, errs[0]
+    assert sorted(k for k, p in named.items() if p.requires_grad and p.grad is None) == meta["unused"]
+
+
+def test_deep_supervision_train_step_fp32_vs_reference():
+    """UNetDecoder with deep_supervision=True (dinounet_training.py:603-629): one head per decoder stage, list largest first.  The three
+    logits tensors, a weighted Dice + CE over them and every gradient norm (small gradients in full) against the reference's own modules
+    (tests/golden/dinounet_s_64_ds_train.npz, oracle/make_golden_ds.py); all three seg layers receive gradients."""
+    from dinounet_amd.dinov3.adapter import DropPath
+    g, meta = _load("dinounet_s_64_ds_train")
+    net = _build("dinounet_s", 2, "fp32", deep_supervision=True).train()
+    assert net.decoder.deep_supervision is True
+    for m in net.modules():
+        if isinstance(m, DropPath):
+            m.drop_prob = 0.0
+    net.encoder.dinov3_adapter.backbone.rope_embed.rescale_coords = None
+    x = weights.make_input(2, 3, 64, 64, seed=1).cuda()
+    tgt = weights.make_target(2, 64, 64, 2, seed=1).cuda()
+    outs = net(x)
+    assert isinstance(outs, list) and len(outs) == 3
+    loss = 0.0
+    for i, (y, w) in enumerate(zip(outs, meta["ds_weights"])):
+        assert rel(y, torch.from_numpy(g[f"logits{i}"])) < 1e-3, i
+        loss = loss + w * O.dc_and_ce_loss(y, tgt[..., ::2 ** i, ::2 ** i].contiguous())
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    norms = meta["grad_norms"]
+    gmax = max(norms.values())
+    named = dict(net.named_parameters())
+    worst = ("", 0.0)
+    for k, n in norms.items():
+        assert named[k].grad is not None, k
+        err = abs(float(named[k].grad.norm()) - n) / max(n, 1e-3 * gmax)
+        if err > worst[1]:
+            worst = (k, err)
+    print(f"deep supervision: worst grad-norm deviation {worst[1]:.2e} at {worst[0]}")
+    assert worst[1] < 1e-2, worst
+    errs = []
+    for key in g.files:
+        if key.startswith("grad:"):
+            k = key[5:]
+            ref = torch.from_numpy(g[key])
+            if ref.norm() > 1e-3 * gmax:
+                errs.append((float((named[k].grad.cpu() - ref).norm() / ref.norm()), float(ref.norm() / gmax), k))
+    errs.sort(reverse=True)
+    # this gradient sits on a discontinuity at 64 x 64 (bilinear samples of 4 x 4 maps on cell borders): a 1e-6 relative perturbation of
+    # the input moves the REFERENCE's own gradient of the last extractor's sampling offsets by 2.8 % (meta["self_noise"], measured by
+    # oracle/make_golden_ds.py on the reference's modules).  A tensor may deviate by 2e-2 or by 1.5 x the reference's own sensitivity.
+    noise = meta["self_noise"]
+    for e, n, k in errs[:6]:
+        print(f"  full-gradient rel-L2 {e:.2e}  (|g| / max|g| = {n:.1e}, reference self-noise {noise[k]:.2e})  {k}")
+    for e, n, k in errs:
+        assert e < max(2e-2, 1.5 * noise[k]), (k, e, noise[k])
+    for s_ in range(3):
+        assert float(named[f"decoder.seg_layers.{s_}.weight"].grad.norm()) > 0
     assert sorted(k for k, p in named.items() if p.requires_grad and p.grad is None) == meta["unused"]
 
 

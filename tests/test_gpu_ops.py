@@ -24,10 +24,19 @@ def dev():
 
 
 def rel(a, b):
+    """max |a - b| / max |b|, taken over the whole tensor AND per slice of the last dimension (channel / output column; slices floored at
+    1 % of the global maximum, weighted 1/4): a channel that is wrong as a whole cannot hide behind a larger one.  Over the 519 comparisons
+    of this file the per-slice figure is <= 3.8 x the global one wherever it is not pure fp32 round-off (< 1e-5)."""
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     assert a.shape == b.shape, (a.shape, b.shape)
     assert torch.isfinite(a).all(), "non-finite values in kernel output"
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+    bmax = b.abs().max()
+    g = float((a - b).abs().max() / bmax.clamp_min(1e-20))
+    if a.dim() >= 2 and a.shape[-1] > 1 and float(bmax) > 0:
+        red = tuple(range(a.dim() - 1))
+        col = float(((a - b).abs().amax(red) / b.abs().amax(red).clamp_min(1e-2 * bmax)).max())
+        g = max(g, col / 4)
+    return g
 
 
 def close(a, b, rtol, atol):
