@@ -137,6 +137,7 @@ def main():
                 r["measured_peak"] = meas                      # what a micro-benchmark reaches on this chip (same unit as peak)
                 r["frac_of_measured_peak"] = round(r["achieved"] / meas, 4)
                 pmc_traffic(r)
+                pmc_cycles(r)
             except Exception as e:  # noqa: BLE001
                 out["roofline"] = {"error": repr(e)}
         if not a.no_cpu_baseline and world == 1:
@@ -198,6 +199,40 @@ def pmc_traffic(roof):
     roof["traffic"] = round(tot["fetch"] + tot["write"])
     roof["traffic_unit"] = "bytes/launch"
     roof["traffic_source"] = f"profiles/{{{','.join(src)}}} (separate rocprofv3 --pmc passes of bench.py --graph off on csrc digest {digest[:12]}; FETCH_SIZE x2)"
+
+
+def pmc_cycles(roof):
+    """roofline.pmc_cycles = where the dominant kernel's cycles go, from the SQ-counter passes of this same command (tools/pmc_kernels.py ->
+    profiles/r02_pmc_sq_cycles_eager.txt, digest-checked like the traffic files): share of the launch the matrix pipe is busy (the PMC
+    counterpart of `frac`), and the shares of the resident waves' lifetime spent parked (s_waitcnt / barrier), issue-stalled and issuing."""
+    from dinounet_amd import _build
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_sq_cycles_eager.txt")
+    key = roof.get("kernel", "").split("<")[0]
+    if not key or not os.path.exists(path):
+        return
+    lines = open(path).read().splitlines()
+    if not any(l.startswith("# csrc-digest") and _build._digest() in l for l in lines[:3]):
+        return
+    n, acc = 0, [0.0] * 5
+    for line in lines:
+        if line.startswith("#") or not line.strip():
+            if line.startswith("# raw means"):
+                break
+            continue
+        f = line.replace("|", " ").split()
+        if len(f) >= 12 and f[0].isdigit() and key in line:
+            try:
+                vals = [float(f[i]) for i in (2, 3, 5, 6, 7)]          # parked, stall, issue, mfma, valu
+            except ValueError:
+                continue
+            w = int(f[0])
+            n += w
+            acc = [a_ + w * v for a_, v in zip(acc, vals)]
+    if n:
+        parked, stall, issue, mfma, valu = [round(v / n, 3) for v in acc]
+        roof["pmc_cycles"] = {"matrix_pipe_busy": mfma, "valu_issue": valu, "waves_parked": parked, "waves_issue_stalled": stall,
+                              "waves_issuing": issue, "source": "profiles/r02_pmc_sq_cycles_eager.txt (eager launches, launch-weighted over the "
+                                                                 "kernel's instantiations)"}
 
 
 def cpu_baseline(net, a):
