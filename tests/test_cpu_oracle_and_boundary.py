@@ -489,3 +489,33 @@ def test_gemm_dispatch_host_logic_without_gpu():
     assert route(64, 576, 524288, PLAIN_COL, IM2COL_COL, od=DU_F32, split=64, geom=g3, lda=64, ldb=64)[0] == 1        # 3 x 3 im2col: no gather form
     # fp32 parity mode: the generic exact-fp32 kernel
     assert route(8232, 3072, 1024, dt=DU_F32, od=DU_F32)[0] == 0
+
+
+def test_bench_roofline_reads_pmc_summaries_only_for_matching_kernel_sources(monkeypatch):
+    """roofline.traffic / roofline.pmc_cycles come from committed rocprofv3 PMC summaries (counters cannot be collected inside the timed
+    process); each summary names the digest of the kernel sources it was measured on, and bench.py must ignore a summary taken on other
+    sources (traffic stays absent, with a note) instead of reporting stale bytes."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from dinounet_amd import _build
+    head = open(os.path.join(root, "profiles", "r02_pmc_fetch_size_eager.txt")).read().splitlines()[0]
+    recorded = re.match(r"# csrc-digest ([0-9a-f]{64})", head).group(1)
+    kernel = "gemm_nt_p8n_kernel<bf16,linear>"
+
+    monkeypatch.setattr(_build, "_digest", lambda: recorded)
+    roof = {"kernel": kernel}
+    bench.pmc_traffic(roof)
+    bench.pmc_cycles(roof)
+    assert isinstance(roof["traffic"], int) and 5e7 < roof["traffic"] < 1e9 and recorded[:12] in roof["traffic_source"]
+    pc = roof["pmc_cycles"]
+    assert 0.0 < pc["matrix_pipe_busy"] < 1.0 and abs(pc["waves_parked"] + pc["waves_issue_stalled"] + pc["waves_issuing"] - 1.0) < 0.05
+
+    monkeypatch.setattr(_build, "_digest", lambda: "0" * 64)
+    roof = {"kernel": kernel}
+    bench.pmc_traffic(roof)
+    bench.pmc_cycles(roof)
+    assert "traffic" not in roof and "digest mismatch" in roof["traffic_note"] and "pmc_cycles" not in roof
