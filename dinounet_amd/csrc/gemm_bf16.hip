@@ -150,7 +150,11 @@ template <> struct Out4<bf16_t> {
   }
 };
 
-template <int AMODE, int BMODE, typename TC, int WM, int WN, int TM, int TN>
+// KSCALE (weight-gradient form only): DropPath's per-sample scale on the contraction rows, dropped samples' K tiles skipped.  A template
+// parameter, not a run-time test of P.k_scale: with the `if (s_kt != 0)` skip branch in the loop the register allocator parks the
+// accumulators in AGPRs and copies all of them to VGPRs and back EVERY K step (64 v_accvgpr_read + 64 v_accvgpr_write per 16 MFMAs,
+// tools/isa_budget.py), in scaled and unscaled launches alike: +6 us per launch, DESIGN 6.27.  Unscaled launches now compile without it.
+template <int AMODE, int BMODE, typename TC, int WM, int WN, int TM, int TN, bool KSCALE = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int A_EL = tile_elems(AMODE, BM), B_EL = tile_elems(BMODE, BN);
@@ -239,16 +243,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
     // weight-gradient form with a per-sample scale on the contraction rows (DropPath in backward: dW = (s . dY)^T X): the scale is uniform
     // over a K tile (rs_rows % BK == 0, checked by the host); a zero scale (dropped sample) skips the tile's MFMAs altogether
     float s_kt = 1.f;
-    if constexpr (AMODE == DU_PLAIN_COL) {
-      if (P.k_scale) s_kt = P.row_scale[(kbeg + kt * BK) / P.rs_rows];
-    }
-    if (s_kt != 0.f) {
+    if constexpr (KSCALE) s_kt = P.row_scale[(kbeg + kt * BK) / P.rs_rows];
+    if (!KSCALE || s_kt != 0.f) {
 #pragma unroll
     for (int kk = 0; kk < BK / 16; kk++) {
       bf16x8 fa[TM], fb[TN];
 #pragma unroll
       for (int i = 0; i < TM; i++) fa[i] = Loader<AMODE, BM>::frag(Ac, (wm * TM + i) * 32, kk, lane);
-      if constexpr (AMODE == DU_PLAIN_COL) {
+      if constexpr (KSCALE) {
         if (s_kt != 1.f) {
 #pragma unroll
           for (int i = 0; i < TM; i++)
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
         float4 gg = *(const float4*)(P.gamma + n);
         o[0] *= gg.x; o[1] *= gg.y; o[2] *= gg.z; o[3] *= gg.w;
       }
-      if (P.row_scale && !P.k_scale) {
+      if (P.row_scale && !P.k_scale) {      // (k_scale: the scale was applied to the contraction rows inside the loop)
         const float rs = P.row_scale[m / P.rs_rows];
 #pragma unroll
         for (int e = 0; e < 4; e++) o[e] *= rs;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
   }
 }
 
-template <int AMODE, int BMODE, typename TC, int WM, int WN, int TM, int TN>
+template <int AMODE, int BMODE, typename TC, int WM, int WN, int TM, int TN, bool KSCALE = false>
 int launch_cfg(const du_gemm_args& a, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int A_EL = tile_elems(AMODE, BM), B_EL = tile_elems(BMODE, BN);
@@ -393,7 +395,10 @@ int launch_cfg(const du_gemm_args& a, hipStream_t st) {
   static const int group_env = getenv("DU_GEMM_GROUP_M") ? atoi(getenv("DU_GEMM_GROUP_M")) : 8;    // 0 / 1: row-major tile order
   P.group_m = group_env;
   dim3 grid(P.tiles_m * P.tiles_n, (a.batch < 1 ? 1 : a.batch) * P.split_k);
-  auto kfn = gemm_bf16_kernel<AMODE, BMODE, TC, WM, WN, TM, TN>;
+  if constexpr (AMODE == DU_PLAIN_COL && !KSCALE) {
+    if (P.k_scale) return launch_cfg<AMODE, BMODE, TC, WM, WN, TM, TN, true>(a, st);
+  }
+  auto kfn = gemm_bf16_kernel<AMODE, BMODE, TC, WM, WN, TM, TN, KSCALE>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return DU_ERR_LAUNCH;

@@ -323,9 +323,17 @@ constexpr int P8_LDS = 256 * P8_STG_LDB * 2;   // 135 168 B >= 2 * BUF_B and >= 
 
 // GA ("gather"): the ConvTranspose2d k2 s2 backward products read their im2col operand in place -- NT: A(m = input pixel, k = (tap, co)) =
 // dy[out pixel (2y + tap/2, 2x + tap%2)][co] (data gradient); TN: B(k = input pixel, n = (tap, co)) likewise (weight gradient).
+// workgroup -> XCD-contiguous linear index: the hardware places workgroup b on XCD b % 8; an XCD then owns a contiguous run of indices
+__device__ __forceinline__ int xcd_linear_index() {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// The tile program of both launch forms: the plain kernel below (one product per launch) and gemm_tn_group_kernel (several weight-gradient
+// products per launch).  TN: `lin` = this workgroup's (split, tile) index inside the product, tiles of one split adjacent.
 template <typename TC, int SCHED, bool TN, bool GA>
-__global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char* smem, const int lin) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -334,11 +342,8 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
   long kbeg = 0;                      // TN: first contraction row of this workgroup's split
   int my_split = 0;
   if constexpr (TN) {
-    // workgroup -> (split, tile): the XCD-contiguous linear index walks the tiles of one split before the next split, so the
-    // workgroups that share a K range (and with it the A / B panels) sit on one XCD's L2
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    // (split, tile): the linear index walks the tiles of one split before the next split, so the workgroups that share a K range (and
+    // with it the A / B panels) sit on one XCD's L2
     const int ntiles = P.tiles_m * P.tiles_n;
     const int split = lin / ntiles, tile = lin - split * ntiles;
     tm = tile / P.tiles_n; tn = tile - tm * P.tiles_n;
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
     tile_coords(P, tm, tn);
   }
   const int m0 = tm * PBM, n0 = tn * PBN;
-  const int batch = blockIdx.y;
+  const int batch = TN ? 0 : blockIdx.y;
 
   // ---- buffer descriptors based at the tile's first row (TN: first contraction row + first tile column); reads past the matrix fail
   // the bounds check and load zeros ----
@@ -676,8 +681,10 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
       }
     }
     // split-K partial: fp32 atomics into the (zeroed) result.  Register r of a 32 x 32 block = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5),
-    // lanes 0..31 = 32 consecutive columns (one 128-byte segment per row)
+    // lanes 0..31 = 32 consecutive columns (one 128-byte segment per row).  A product that is NOT split (grouped launches give short
+    // products one workgroup per tile) owns its tile: plain stores, no read-modify-write at the memory side
     const int hi = lane >> 5;
+    const bool plain = P.split_k == 1;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int n = n0 + j * 128 + wn * 32 + (lane & 31);
@@ -689,7 +696,11 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             const int m = m0 + i * 128 + wm * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (m < P.M) atomic_add_f32((float*)Cb + (long)m * P.ldc + n, acc[i][j][b][r] * P.alpha);
+            if (m < P.M) {
+              float* dst = (float*)Cb + (long)m * P.ldc + n;
+              if (plain) *dst = acc[i][j][b][r] * P.alpha;
+              else atomic_add_f32(dst, acc[i][j][b][r] * P.alpha);
+            }
           }
     }
     return;
@@ -738,6 +749,47 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
       readout_f32_any<TC, PBN>(P, stg, P8_STG_LDF, 128, m0 + i * 128, n0, Cb, Rb, tid);
     }
   }
+}
+
+template <typename TC, int SCHED, bool TN, bool GA>
+__global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  p8_tile_body<TC, SCHED, TN, GA>(P, smem, TN ? xcd_linear_index() : 0);
+}
+
+// ---- grouped weight gradients: several dW = dY^T X products in ONE launch (du_gemm_tn_group) ----------------------------------------
+// Why: a weight gradient has a huge contraction (rows = B x pixels / tokens) and a small result, so one product alone must be cut into
+// ~256 / tiles K splits to fill the chip -- and every split ends with a 256 x 256 fp32 read-modify-write of the result (35-60 us of
+// memory-side atomics per 256-workgroup launch whatever K: more than the MFMA loop of most of these products, tools/gemm_tn_bench.py).
+// Nothing reads a weight gradient before the optimizer, so the host defers them (ops.WgradQueue) and launches many together: the 256
+// workgroups are then dealt out over ALL queued products in proportion to their contraction length -- 2-4 splits per product instead
+// of 16-64, an order of magnitude fewer partial tiles, unsplit products written with plain stores -- with the tile program above
+// unchanged.  The job table travels in the kernel arguments (no device-side table to keep alive across hipGraph replays).
+constexpr int TN_GROUP_MAX = 40;
+struct TnJob {
+  const void* A; const void* B; float* C; float* a_colsum;
+  int lda, ldb, ldc, M, N, K, splits, unit0;      // unit0: first (split, tile) unit of this job in the launch
+};
+struct TnGroupArgs { int njobs, nunits, dbg, pad_; TnJob jobs[TN_GROUP_MAX]; };
+
+template <int SCHED>
+__global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroupArgs G) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lin = xcd_linear_index();
+  if (lin >= G.nunits) return;
+  int j = 0;
+  while (j + 1 < G.njobs && lin >= G.jobs[j + 1].unit0) j++;
+  GemmParams P{};
+  P.a.p = G.jobs[j].A; P.a.ld = G.jobs[j].lda;
+  P.b.p = G.jobs[j].B; P.b.ld = G.jobs[j].ldb;
+  P.C = G.jobs[j].C; P.ldc = G.jobs[j].ldc;
+  P.M = G.jobs[j].M; P.N = G.jobs[j].N; P.K = G.jobs[j].K;
+  P.split_k = G.jobs[j].splits;
+  P.alpha = 1.0f;
+  P.a_colsum = G.jobs[j].a_colsum;
+  P.tiles_m = (P.M + PBM - 1) / PBM; P.tiles_n = (P.N + PBN - 1) / PBN;
+  P.dbg = G.dbg;
+  p8_tile_body<float, SCHED, true, false>(P, smem, lin - G.jobs[j].unit0);
 }
 
 // ================================================================================================================================
@@ -1121,6 +1173,77 @@ int du_gemm_tn_p8_splits(const du_gemm_args& a) {
   const long ldmax = a.b_mode == DU_PLAIN_COL && a.ldb > a.lda ? a.ldb : a.lda;
   if ((long)(npairs / s + 1) * 128 * ldmax * 2 > 0x7fffffffL) return 0;
   return (int)s;
+}
+
+// ---- grouped weight gradients (see gemm_tn_group_kernel) ----
+static bool tn_group_legal(const du_tn_job& j) {
+  if (!j.A || !j.B || !j.C || j.M <= 0 || j.N <= 0) return false;
+  if (j.K % 128 || j.K < 512) return false;                       // whole K-tile pairs, at least two pairs per split
+  if (j.lda % 8 || j.ldb % 8 || j.lda < j.M || j.ldb < j.N || j.ldc < j.N) return false;
+  if ((((uintptr_t)j.A) | ((uintptr_t)j.B)) & 15) return false;
+  if (j.lda > 0x7fffffffL / 4 || j.ldb > 0x7fffffffL / 4 || j.ldc > 0x7fffffffL) return false;
+  // an unsplit product addresses its whole operand through one 32-bit buffer offset
+  const long ldmax = j.lda > j.ldb ? j.lda : j.ldb;
+  return ((long)j.K + 128) * ldmax * 2 <= 0x7fffffffL;
+}
+extern "C" int du_gemm_tn_group_legal(const du_tn_job* job) { return (job && g_p8_mode != 0 && tn_group_legal(*job)) ? 1 : 0; }
+
+extern "C" int du_gemm_tn_group(const du_tn_job* jobs, int njobs, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (njobs < 0 || (njobs > 0 && !jobs)) return DU_ERR_BAD_ARG;
+  for (int i = 0; i < njobs; i++)
+    if (!tn_group_legal(jobs[i])) return DU_ERR_UNSUPPORTED;
+  static const int target_units = getenv("DU_TN_GROUP_UNITS") ? atoi(getenv("DU_TN_GROUP_UNITS")) : 256;   // one 8-wave workgroup per CU
+  static const int min_pairs = getenv("DU_TN_GROUP_MINPAIRS") ? atoi(getenv("DU_TN_GROUP_MINPAIRS")) : 8;  // >= 1024 contraction rows per split
+  void (*kfn)(TnGroupArgs) = g_p8_sched ? gemm_tn_group_kernel<1> : gemm_tn_group_kernel<0>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[g_p8_sched ? 1 : 0]) {
+    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS) != hipSuccess) return DU_ERR_LAUNCH;
+    attr_set[g_p8_sched ? 1 : 0] = true;
+  }
+  int i0 = 0;
+  while (i0 < njobs) {
+    // one launch: consecutive jobs while their tiles fit one round of workgroups
+    int tiles[TN_GROUP_MAX], pairs[TN_GROUP_MAX], splits[TN_GROUP_MAX];
+    int n = 0, units = 0;
+    while (i0 + n < njobs && n < TN_GROUP_MAX) {
+      const du_tn_job& j = jobs[i0 + n];
+      const int t = ((j.M + PBM - 1) / PBM) * ((j.N + PBN - 1) / PBN);
+      if (n > 0 && units + t > target_units) break;
+      tiles[n] = t; pairs[n] = j.K / 128; splits[n] = 1;
+      units += t; n++;
+    }
+    // K splits in proportion to the contraction length: repeatedly split the job with the longest units while the round has room
+    for (;;) {
+      int best = -1; double len = 0.0;
+      for (int k = 0; k < n; k++) {
+        if (units + tiles[k] > target_units || pairs[k] / (splits[k] + 1) < min_pairs) continue;
+        const long ldmax = jobs[i0 + k].lda > jobs[i0 + k].ldb ? jobs[i0 + k].lda : jobs[i0 + k].ldb;
+        (void)ldmax;
+        const double l = (double)pairs[k] / splits[k];
+        if (l > len) { len = l; best = k; }
+      }
+      if (best < 0) break;
+      splits[best]++; units += tiles[best];
+    }
+    TnGroupArgs G{};
+    G.njobs = n; G.dbg = g_p8_debug;
+    int u = 0;
+    for (int k = 0; k < n; k++) {
+      const du_tn_job& j = jobs[i0 + k];
+      TnJob& d = G.jobs[k];
+      d.A = j.A; d.B = j.B; d.C = j.C; d.a_colsum = j.a_colsum;
+      d.lda = (int)j.lda; d.ldb = (int)j.ldb; d.ldc = (int)j.ldc; d.M = j.M; d.N = j.N; d.K = j.K;
+      d.splits = splits[k]; d.unit0 = u;
+      u += tiles[k] * splits[k];
+    }
+    G.nunits = u;
+    hipLaunchKernelGGL(kfn, dim3(u), dim3(512), P8_LDS, st, G);
+    const int rc = du_check_launch();
+    if (rc != DU_OK) return rc;
+    i0 += n;
+  }
+  return DU_OK;
 }
 
 int du_gemm_tn_p8(const du_gemm_args& a, hipStream_t st) {

@@ -405,6 +405,10 @@ class DinoUNet(nn.Module):
             m._act_dtype = dt
         return self
 
+    # nnUNetTrainer.py:210-212 may wrap the network in torch.compile: the forward is a chain of opaque custom autograd Functions over
+    # the C ABI (raw pointers, ctypes), nothing dynamo can trace -- it is excluded from tracing, so the compiled wrapper runs this very
+    # code (same logits, same gradients; tests/test_gpu_boundary.py::test_torch_compile_wrapper_keeps_logits)
+    @torch.compiler.disable
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("DinoUNet (dinounet_amd) runs on the MI355X through libdinounet_hip.so; move the module and "

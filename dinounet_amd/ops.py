@@ -489,15 +489,139 @@ def _split_for(tiles, kdim, target=512):
     return max(1, s)
 
 
-def mm_wgrad(dy, x, with_colsum=False, k_scale=None):
+class WgradQueue:
+    """Deferred weight gradients of the linear layers (du_gemm_tn_group: several dW = dY^T X products in ONE launch).
+
+    Nothing reads a weight gradient before clip_grad_norm_ / the optimizer (nnUNetTrainer.py:919-928), while one product alone has to be
+    cut into 16-64 K splits to fill 256 CUs and pays a full fp32 read-modify-write of its result per split (more than its MFMA loop for
+    most adapter layers, tools/gemm_tn_bench.py).  mm_wgrad(defer=True) therefore only allocates the (zeroed) result, records the job and
+    keeps dY / X alive; flush() launches everything queued -- the workgroups are dealt out over all jobs, 2-4 splits per product.
+
+    flush() runs (a) from an autograd-engine callback at the end of the backward pass that queued the job (`p.grad` is complete when
+    backward() / autograd.grad() returns, whatever the caller does next), (b) from GradAllReducer just before a bucket of gradients is
+    gathered for its all-reduce, (c) at once when a job is queued outside a backward pass (op tests, tools).
+
+    What keeps a product OUT of the queue (it is then computed at once, as before), checked per backward node by can_defer():
+      * the parameter already has a gradient (AccumulateGrad would add the unfinished buffer into it immediately);
+      * the parameter carries tensor hooks, or post-accumulate hooks other than GradAllReducer's (which flushes before it reads);
+      * the forward ran inside a torch DistributedDataParallel wrapper (its reducer copies gradients out of the accumulators as they arrive);
+      * the parameter has ALREADY received a contribution in this backward pass (the engine sums the contributions of a parameter with
+        several uses as soon as the second one is returned): the queue is flushed first, so the earlier buffer is complete.
+    DINOUNET_WGRAD_DEFER=0 disables the queue."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("DINOUNET_WGRAD_DEFER", "1") != "0"
+        self.jobs = []          # du_tn_job records
+        self.keep = []          # dY / X tensors of the queued jobs
+        self.flops = 0.0
+        self.nbytes = 0.0
+        self._armed = False     # an end-of-pass callback is queued with the autograd engine
+        self.seen = set()       # id(parameter) of every weight that received a contribution in the running backward pass
+        self.flush_aware_hooks = 0   # > 0: the post-accumulate hooks on the parameters belong to GradAllReducer
+        self.launches = 0       # statistics (tests)
+        self.queued = 0
+
+    @staticmethod
+    def _param(w):
+        b = w._base if w._base is not None else w
+        return b if (isinstance(b, torch.nn.Parameter) and b.is_leaf) else None
+
+    def note_use(self, *ws):
+        """forward side -> weak references to the leaf Parameters behind the weights for can_defer(), or None when they are not
+        (views of) leaf Parameters or the forward runs inside a torch DDP wrapper."""
+        if not self.enabled or not torch.is_grad_enabled():
+            return None
+        if getattr(torch.nn.parallel.DistributedDataParallel, "_active_ddp_module", None) is not None:
+            return None
+        ps = [self._param(w) for w in ws]
+        if any(p is None for p in ps):
+            return None
+        return [weakref.ref(p) for p in ps]
+
+    def _arm(self):
+        if not self._armed:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
+                self._armed = True
+            except RuntimeError:           # not inside a backward pass: nothing will call back
+                return False
+        return True
+
+    def can_defer(self, refs):
+        """backward side (called once per node, before its weight-gradient products): see the class docstring."""
+        if not self.enabled or refs is None:
+            return False
+        ps = [r() for r in refs]
+        if any(p is None for p in ps) or not self._arm():
+            return False
+        again = any(id(p) in self.seen for p in ps)
+        self.seen.update(id(p) for p in ps)
+        if again:
+            self.flush()
+            return False
+        for p in ps:
+            if p.grad is not None or p._backward_hooks:
+                return False
+            if getattr(p, "_post_accumulate_grad_hooks", None) and not self.flush_aware_hooks:
+                return False
+        return True
+
+    def legal(self, job):
+        return bool(_lib.lib().du_gemm_tn_group_legal(C.byref(job)))
+
+    def add(self, job, keep):
+        self.jobs.append(job)
+        self.keep.extend(keep)
+        self.queued += 1
+        self.flops += 2.0 * job.M * job.N * job.K
+        self.nbytes += 2.0 * job.K * (job.M + job.N) + 4.0 * job.M * job.N
+        if not self._armed and not self._arm():
+            self.flush()
+
+    def _end_of_pass(self):
+        self._armed = False
+        self.seen.clear()
+        self.flush()
+
+    def flush(self):
+        if not self.jobs:
+            return
+        n = len(self.jobs)
+        arr = (_lib.TnJob * n)(*self.jobs)
+        e0 = PROFILE.start() if PROFILE is not None else None
+        rc = _lib.lib().du_gemm_tn_group(arr, n, _st())
+        fl, nb = self.flops, self.nbytes
+        self.jobs, self.keep, self.flops, self.nbytes = [], [], 0.0, 0.0
+        _lib.check(rc, "du_gemm_tn_group")
+        self.launches += 1
+        if PROFILE is not None:
+            PROFILE.stop("gemm_tn_group_kernel<bf16,linear_wgrad>" + (f" jobs{n}" if PROFILE.detail else ""), e0, fl, nb)
+
+
+WGRAD = WgradQueue()
+
+
+def mm_wgrad(dy, x, with_colsum=False, k_scale=None, defer=False):
     """dw[n][k] = sum_m dy[m][n] * x[m][k]  -> fp32 (N,K); split-K over the rows with fp32 atomics.
     with_colsum: also return the bias gradient db[n] = sum_m dy[m][n] -- taken inside the weight-gradient kernel from the dY fragments
     it streams anyway (du_gemm_args.a_colsum) where the kernel family can, by du_colsum (two more launches, one more pass over dY)
-    otherwise."""
+    otherwise.
+    defer: the caller hands the result to autograd as the gradient of a parameter used ONCE in the step; the product may then be queued
+    (WgradQueue) and computed later in the backward pass together with others -- the returned tensors are valid after WGRAD.flush()."""
     _req(dy, x)
     Mr, N, lda = _rows2d(dy)
     Mr2, K, ldb = _rows2d(x)
     assert Mr == Mr2 and dy.dtype == x.dtype
+    if defer and WGRAD.enabled and k_scale is None and dy.dtype == torch.bfloat16 and (_WGRAD_COLSUM or not with_colsum):
+        job = _lib.TnJob(A=dy.data_ptr(), lda=lda, B=x.data_ptr(), ldb=ldb, C=0, ldc=K, a_colsum=None, M=N, N=K, K=Mr, reserved=0)
+        job.C = 1                                      # legality does not depend on the result's address
+        if WGRAD.legal(job):
+            out = ZEROS.zeros((N, K), dy.device)
+            db = ZEROS.zeros((N,), dy.device) if with_colsum else None
+            job.C = out.data_ptr()
+            job.a_colsum = db.data_ptr() if with_colsum else None
+            WGRAD.add(job, (dy, x))
+            return (out, db) if with_colsum else out
     out = ZEROS.zeros((N, K), dy.device)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     kw = dict(dtype=_code(dy.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=PLAIN_COL, M=N, N=K, K=Mr,
@@ -799,6 +923,8 @@ class _Linear(torch.autograd.Function):
         # step (against the 128 x 128 kernel of round 1 it was a wash; DINOUNET_DGRAD_NT=0 restores the transpose-read ROW x COL kernel)
         ctx.wT = PACK.get(w, PK_TRANSPOSE, x.dtype) if (_DGRAD_NT and w.dtype != x.dtype and w.shape[0] % 64 == 0) else None
         ctx.save_for_backward(x, wq, row_scale)
+        # the weight gradient may be computed late in the backward pass (WgradQueue) when this is the only use of w in the step
+        ctx.wrefs = WGRAD.note_use(*([w] if bias is None else [w, bias]))
         ctx.rs_rows = rs_rows
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -830,9 +956,9 @@ class _Linear(torch.autograd.Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if want_db:
-                dw, db = mm_wgrad(dyc, x, with_colsum=True, k_scale=ks)
+                dw, db = mm_wgrad(dyc, x, with_colsum=True, k_scale=ks, defer=WGRAD.can_defer(ctx.wrefs))
             else:
-                dw = mm_wgrad(dyc, x, k_scale=ks)
+                dw = mm_wgrad(dyc, x, k_scale=ks, defer=WGRAD.can_defer(ctx.wrefs))
         elif want_db:
             dys = dyc if ks is None else (dyc.view(row_scale.numel(), ctx.rs_rows, -1) * row_scale.view(-1, 1, 1).to(dyc.dtype)).view(dyc.shape)
             db = colsum(dys)
@@ -871,6 +997,7 @@ class _LinearCat(torch.autograd.Function):
             ctx.wT = PACK.get((w1.reshape(n1, -1), w2.reshape(w2.shape[0], -1)), PK_TRANSPOSE, x.dtype)
         ctx.save_for_backward(x, wq)
         ctx.conf = (n1, tuple(w1.shape), tuple(w2.shape), b1 is not None)
+        ctx.wrefs = WGRAD.note_use(*([w1, w2] if b1 is None else [w1, w2, b1, b2]))
         return y
 
     @staticmethod
@@ -885,10 +1012,10 @@ class _LinearCat(torch.autograd.Function):
             dx = mm(dyc, ctx.wT) if ctx.wT is not None else mm_dgrad(dyc, wq)
         db1 = db2 = None
         if has_bias:
-            dw, db = mm_wgrad(dyc, x, with_colsum=True)
+            dw, db = mm_wgrad(dyc, x, with_colsum=True, defer=WGRAD.can_defer(ctx.wrefs))
             db1, db2 = db[:n1], db[n1:]
         else:
-            dw = mm_wgrad(dyc, x)
+            dw = mm_wgrad(dyc, x, defer=WGRAD.can_defer(ctx.wrefs))
         return dx, dw[:n1].view(s1), dw[n1:].view(s2), db1, db2, None
 
 

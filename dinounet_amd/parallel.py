@@ -98,6 +98,9 @@ class GradAllReducer:
             self.gather.append(self._gather_tables(b, views, dev) if self.is_cuda else None)
             for j, (_, p) in enumerate(b):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi, j)))
+        if self.is_cuda:
+            from . import ops
+            ops.WGRAD.flush_aware_hooks += 1       # these hooks flush the deferred weight gradients before they read a gradient
 
     @staticmethod
     def _gather_tables(bucket, views, dev):
@@ -145,6 +148,8 @@ class GradAllReducer:
             self.pending[bi] -= 1
             if self.pending[bi] == 0:
                 if self.is_cuda:
+                    from . import ops
+                    ops.WGRAD.flush()              # deferred weight-gradient products of this bucket (ops.WgradQueue) must exist now
                     self._gather(bi)
                 self._launch(bi)
         return hook
@@ -160,6 +165,9 @@ class GradAllReducer:
 
     def finish(self):
         """Wait for every bucket, install the averaged gradients (views of the flat buffers) as p.grad, re-arm."""
+        if self.is_cuda:
+            from . import ops
+            ops.WGRAD.flush()
         for bi, b in enumerate(self.buckets):
             if self.pending[bi] != 0:      # a gradient never arrived (e.g. frozen branch): reduce what we have
                 for j, (_, p) in enumerate(b):
@@ -181,3 +189,7 @@ class GradAllReducer:
     def remove(self):
         for h in self._hooks:
             h.remove()
+        if self._hooks and self.is_cuda:
+            from . import ops
+            ops.WGRAD.flush_aware_hooks = max(0, ops.WGRAD.flush_aware_hooks - 1)
+        self._hooks = []

@@ -81,6 +81,9 @@ class TrainStep:
         logits = self.net(self.x)
         loss = dc_and_ce_loss(logits, self.tgt)
         loss.backward()
+        if logits.is_cuda:
+            from . import ops
+            ops.WGRAD.flush()          # deferred weight gradients (already flushed by the engine callback; idempotent)
         if self.reducer is not None:
             self.reducer.finish()
         if isinstance(self.opt, FusedClipSGD):              # clip + SGD in three launches (csrc/optim.hip)

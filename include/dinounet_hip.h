@@ -132,6 +132,25 @@ int64_t du_gemm_ws_elems(const du_gemm_args* args);
    multi-phase NT kernels (gemm_p8.hip). */
 int du_gemm_route(const du_gemm_args* args);
 
+/* ---- grouped weight gradients: several dW = dY^T X products in ONE launch ----------------------------------------------------------
+   The reference computes every weight gradient inside its layer's backward (torch autograd: F.linear / conv backward at
+   dinov3_adapter.py:85-89,140-156, ms_deform_attn.py:158-216); nothing reads one before clip_grad_norm_ / optimizer.step()
+   (nnUNetTrainer.py:919-928), so the host may queue them and launch them together.  Each job: C[m][n] (+)= sum_k A[k][m] * B[k][n] with
+   A = dY (K rows, M columns, row stride lda), B = X (K rows, N columns, row stride ldb), bf16; C fp32 (M, N), row stride ldc, ZEROED by
+   the caller (jobs that get more than one K split add into it atomically); a_colsum (nullable, zeroed, M floats): += sum_k A[k][m], the
+   bias gradient.  The 256 workgroups of a launch are dealt out over the jobs in proportion to their contraction length.
+   du_gemm_tn_group_legal: 1 if a job can be queued (K % 128 == 0, K >= 512, lda / ldb % 8 == 0, 16-byte aligned operands, < 2 GB
+   operands); du_gemm_tn_group returns DU_ERR_UNSUPPORTED if any job is not. */
+typedef struct du_tn_job {
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  float* C; int64_t ldc;
+  float* a_colsum;
+  int32_t M, N, K, reserved;
+} du_tn_job;
+int du_gemm_tn_group_legal(const du_tn_job* job);
+int du_gemm_tn_group(const du_tn_job* jobs, int njobs, void* stream);
+
 /* ---- LDS-tiled direct 3x3 convolution (stride 1, pad 1), bf16 NHWC: decoder / FAPM / SPM-stem convs (dinounet_training.py:581-592,
         dinov3_adapter.py:243-249) and, with flipped + transposed weights, their data gradients --------------------------------------- */
 /* x (B,H,W,C1) [+ x2 (B,H,W,Cin-C1): fused concat, nullable]; w bf16 [Cout][9*Cin] in (tap, ci) column order; y (B,H,W,Cout).

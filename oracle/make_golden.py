@@ -386,6 +386,8 @@ def main():
     if "pinned" in which:   # train mode with the random ops pinned on both sides
         train_case_pinned("dinounet_s_64_train_pinned", "dinounet_s", 2, 64, 64, sample=4096)
         train_case_pinned("dinounet_l_256_train_pinned", "dinounet_l", 2, 256, 256, sample=16384)
+    if "pinned512" in which:   # the same at a BASELINE.json shape (512 x 512: N = 1029 tokens, Lq = 5376, 512^2 decoder), round 3
+        train_case_pinned("dinounet_s_512_train_pinned", "dinounet_s", 2, 512, 512, sample=8192)
 
 
 if __name__ == "__main__":

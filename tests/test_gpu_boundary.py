@@ -116,3 +116,95 @@ def test_no_grad_validation_forward():
     with torch.no_grad(), torch.autocast("cuda", enabled=True):
         y2 = net(x)
     assert y2.dtype == torch.float32 and torch.equal(y0, y2)
+
+
+@pytest.mark.parametrize("autocast_dtype", [None, torch.float16, torch.bfloat16])
+def test_reference_msdeformattn_function_unmodified_on_dropin_module(autocast_dtype):
+    """the reference's OWN `MSDeformAttnFunction` (ms_deform_attn.py:28-68, vendored verbatim in
+    tests/ref_vendor/ms_deform_attn_ref.py: custom_fwd(cast_inputs=fp32) forward through grid_sample, once_differentiable backward through
+    `MSDA.ms_deform_attn_backward(..., im2col_step)`) runs on top of the drop-in `MultiScaleDeformableAttention` module: all three
+    gradients against plain autograd through the reference's `ms_deform_attn_core_pytorch` in fp64 (what ops/test.py:101-111 checks the
+    CUDA kernel against), at the production shape (Lq 5376, 32 x 32 plane, 16 heads x 32), with and without the trainer's autocast."""
+    from tests.ref_vendor.ms_deform_attn_ref import MSDeformAttnFunction, ms_deform_attn_core_pytorch
+    import MultiScaleDeformableAttention as MSDA
+    import tests.ref_vendor.ms_deform_attn_ref as R
+    assert R.MSDA is MSDA and MSDA.__file__.endswith("MultiScaleDeformableAttention.py")
+    d = torch.device("cuda")
+    N, S, M, D, Lq, P = 2, 1024, 16, 32, 5376, 4
+    gen = torch.Generator().manual_seed(21)
+    value = (torch.randn(N, S, M, D, generator=gen) * 0.5).to(d)
+    loc = (torch.rand(N, Lq, M, 1, P, 2, generator=gen) * 1.1 - 0.05).to(d)
+    attn = torch.softmax(torch.randn(N, Lq, M, 1, P, generator=gen), -1).to(d)
+    go = torch.randn(N, Lq, M * D, generator=gen).to(d)
+    shapes = torch.tensor([[32, 32]], dtype=torch.long, device=d)
+    lsi = torch.zeros(1, dtype=torch.long, device=d)
+    v, l, a = (t.clone().requires_grad_(True) for t in (value, loc, attn))
+    if autocast_dtype is None:
+        out = MSDeformAttnFunction.apply(v, shapes, lsi, l, a, 64)
+    else:
+        with torch.autocast("cuda", dtype=autocast_dtype):
+            # inputs in the autocast dtype, as they leave the adapter's Linear layers under the trainer's autocast (TRN:914)
+            out = MSDeformAttnFunction.apply(v.to(autocast_dtype), shapes, lsi, l.to(autocast_dtype), a.to(autocast_dtype), 64)
+    assert out.dtype == torch.float32 and out.shape == (N, Lq, M * D)
+    gv, gl, ga = torch.autograd.grad(out, (v, l, a), go)
+    q = (lambda t: t.to(autocast_dtype).double()) if autocast_dtype is not None else (lambda t: t.double())
+    v64, l64, a64 = (q(t).requires_grad_(True) for t in (value, loc, attn))
+    ref = ms_deform_attn_core_pytorch(v64, [(32, 32)], l64, a64)
+    rv, rl, ra = torch.autograd.grad(ref, (v64, l64, a64), go.double())
+
+    def rel(x, y, mask=None):
+        d_ = (x.double() - y).abs()
+        if mask is not None:
+            d_ = d_ * mask
+        return float(d_.max() / y.abs().max())
+    # The location gradient is discontinuous where a sample sits exactly on a pixel centre line (the bilinear corners switch): the
+    # half / bfloat16 grids of the autocast cases put ~1 sample in 64 / 8 there, and fp32 vs fp64 round-off then picks different sides.
+    # Those samples are left out of the grad_loc comparison (they are compared through grad_value / grad_attn, which are continuous).
+    pix = l64.detach() * 32.0 - 0.5
+    off_kink = ((pix - pix.round()).abs() > 1e-4).all(-1, keepdim=True).expand_as(pix).double()
+    errs = dict(out=rel(out, ref), grad_value=rel(gv, rv), grad_loc=rel(gl, rl, off_kink), grad_attn=rel(ga, ra))
+    print(f"[reference MSDeformAttnFunction on the drop-in module, autocast {autocast_dtype}] {errs}; samples off the kinks: "
+          f"{float(off_kink.mean()):.4f}")
+    # under autocast the gradients travel back through the .to(half) casts of the test's inputs: one rounding to the autocast dtype
+    tol = {None: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[autocast_dtype]
+    assert errs["out"] < 1e-5 and errs["grad_value"] < tol and errs["grad_attn"] < tol and errs["grad_loc"] < max(tol, 2e-4), errs
+    # once_differentiable (MSA:48): a second derivative through the backward must raise, as with the compiled extension
+    v2 = value.clone().requires_grad_(True)
+    o2 = MSDeformAttnFunction.apply(v2, shapes, lsi, loc, attn, 64)
+    g2, = torch.autograd.grad(o2, v2, go, create_graph=True)
+    with pytest.raises(RuntimeError):
+        g2.sum().backward()
+    # the extension's own argument check (ms_deform_attn_cuda.cu:57): batch not divisible by min(batch, im2col_step)
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_backward(torch.cat([value, value[:1]]).contiguous(), shapes, lsi, torch.cat([loc, loc[:1]]).contiguous(),
+                                     torch.cat([attn, attn[:1]]).contiguous(), torch.cat([go, go[:1]]).contiguous(), 2)
+
+
+def test_torch_compile_wrapper_keeps_logits():
+    """nnUNetTrainer.py:210-212: `self.network = torch.compile(self.network)` when nnUNet_compile is set.  The module is a graph of opaque
+    custom autograd Functions over the C ABI: dynamo must break the graph around them (or fall back to eager) and return the same logits
+    and gradients as the bare module -- it does not have to speed anything up."""
+    import torch._dynamo
+    from dinounet_amd.training import dc_and_ce_loss
+    x, t = _batch()
+    ref = _net()
+    y_ref = ref(x)
+    dc_and_ce_loss(y_ref, t).backward()
+    g_ref = _grads(ref)
+    torch._dynamo.reset()
+    net = _net()
+    cnet = torch.compile(net)
+    y = cnet(x)
+    assert y.dtype == torch.float32 and y.shape == y_ref.shape
+    assert float((y - y_ref).abs().max()) <= 1e-5 * float(y_ref.abs().max())
+    dc_and_ce_loss(y, t).backward()
+    g = _grads(net)
+    assert set(g) == set(g_ref)
+    gmax = max(float(v.norm()) for v in g_ref.values())
+    for k in g:
+        assert float((g[k] - g_ref[k]).norm()) <= 2e-3 * max(float(g_ref[k].norm()), 1e-3 * gmax), k
+    net.eval()
+    with torch.no_grad():
+        y_eval = torch.compile(net)(x)
+    assert torch.isfinite(y_eval).all()
+    torch._dynamo.reset()

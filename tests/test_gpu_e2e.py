@@ -276,7 +276,7 @@ def _pin_randomness(net, B):
         m.pinned_mask = mk
 
 
-@pytest.mark.parametrize("name", ["dinounet_s_64_train_pinned", "dinounet_l_256_train_pinned"])
+@pytest.mark.parametrize("name", ["dinounet_s_64_train_pinned", "dinounet_l_256_train_pinned", "dinounet_s_512_train_pinned"])
 def test_train_step_pinned_randomness_vs_reference(name):
     """train() with the per-block RoPE rescale draws (LAY/rope_position_encoding.py:93-97) and the DropPath masks (ADP:18-26) pinned to
     the values the reference was given (oracle/make_golden.py: pin_reference_randomness): logits, loss, and EVERY trainable
@@ -318,6 +318,67 @@ def test_train_step_pinned_randomness_vs_reference(name):
     assert n_cmp == len(norms)
     assert worst[1] < 2e-2, worst
     assert sorted(k for k, p in named.items() if p.requires_grad and p.grad is None) == meta["unused"]
+
+
+# bf16-mode gradients against the fp32-mode gradients of the same HIP network: bound on every tensor's rel-L2 deviation in units of the
+# network's own sensitivity (the fp32-mode gradient's response to a bf16-sized perturbation of the INPUT alone), with an absolute floor;
+# measured distribution in profiles/r03_bf16_grad_parity.txt
+BF16_GRAD_FLOOR, BF16_GRAD_SENS = 5e-2, 4.0
+
+
+@pytest.mark.parametrize("model,B", [("dinounet_l", 8), ("dinounet_s", 16), ("dinounet_b", 32)])
+def test_bf16_train_step_vs_fp32_mode_512(model, B):
+    """The configuration bench.py times (BASELINE.json configs 2-4: 512 x 512, batch 8 / 16 / 32, bf16 kernels, train mode with
+    DropPath and the RoPE rescale live -- nnUNetTrainer.py:899-929) against the fp32 parity mode of the SAME HIP network with every
+    random draw pinned to the same values: forward + Dice/CE + backward once in each mode.  The bf16-only backward kernels that only
+    engage at these sizes (grouped / multi-phase TN weight gradients, ConvT gather dgrad / wgrad at 1024 -> 1024, the a_colsum / b_colsum
+    bias-gradient owners, DropPath's contraction-row scale and tile skip, M = B * 1029 ragged GEMM rows) are covered here by the model,
+    not only by op tests on synthetic shapes.
+    Criterion.  Gradients through the deformable attention's sampling locations are ill-conditioned (bilinear kinks, 16 x 16 / 32 x 32
+    maps): the fp32 network's OWN gradients move by tens of percent on the low-resolution branch when only its input is rounded to
+    bf16 (third run below, `sens`).  A bf16 kernel bug shows up as a tensor that deviates far beyond that sensitivity, as a wrong
+    norm ratio, or as a lost direction (cosine): rel-L2 <= max(5e-2, 4 x sens), |g16| / |g32| in [0.7, 1.4], cosine >= 0.85."""
+    x = weights.make_input(B, 3, 512, 512, seed=5).cuda()
+    tgt = weights.make_target(B, 512, 512, 2, seed=5).cuda()
+    res = {}
+    for tag, prec, xin in (("fp32", "fp32", x), ("fp32q", "fp32", x.bfloat16().float()), ("bf16", "bf16", x)):
+        net = _build(model, 2, prec).train()
+        _pin_randomness(net, B)
+        y = net(xin)
+        loss = O.dc_and_ce_loss(y, tgt)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[tag] = (float(loss.detach()), y.detach().float().cpu(),
+                    {k: p.grad.detach().float().cpu() for k, p in net.named_parameters() if p.grad is not None})
+        del net, y, loss
+        torch.cuda.empty_cache()
+    (l32, y32, g32), (_, _, g32q), (l16, y16, g16) = res["fp32"], res["fp32q"], res["bf16"]
+    assert np.isfinite(l16) and torch.isfinite(y16).all()
+    assert set(g16) == set(g32)
+    gmax = max(float(v.norm()) for v in g32.values())
+    rows = []
+    for k, ref in g32.items():
+        got = g16[k]
+        assert torch.isfinite(got).all(), k
+        # analytically-zero gradients (biases in front of a norm) carry round-off only: measured against the global scale
+        denom = max(float(ref.norm()), 1e-3 * gmax)
+        err = float((got - ref).norm()) / denom
+        sens = float((g32q[k] - ref).norm()) / denom
+        big = float(ref.norm()) > 1e-3 * gmax
+        ratio = float(got.norm()) / float(ref.norm()) if big else 1.0
+        cos = float((got.flatten().double() @ ref.flatten().double()) / (got.norm().double() * ref.norm().double())) if big else 1.0
+        rows.append((err, sens, ratio, cos, float(ref.norm()) / gmax, k))
+    rows.sort(reverse=True)
+    med = float(np.median([r[0] for r in rows]))
+    med_s = float(np.median([r[1] for r in rows]))
+    print(f"[{model} B{B} 512^2] loss bf16 {l16:.5f} vs fp32 {l32:.5f}; logits rel {rel(y16, y32):.3e}; {len(rows)} gradients: "
+          f"median rel-L2 bf16-vs-fp32 {med:.3e}, median fp32 input-rounding sensitivity {med_s:.3e}; worst:")
+    for err, sens, ratio, cos, n, k in rows[:10]:
+        print(f"    rel-L2 {err:.3e}  sens {sens:.3e}  |g16|/|g32| {ratio:.3f}  cos {cos:.4f}  (|g| / max|g| = {n:.1e})  {k}")
+    assert abs(l16 - l32) < 1e-2
+    for err, sens, ratio, cos, n, k in rows:
+        assert err < max(BF16_GRAD_FLOOR, BF16_GRAD_SENS * sens), (k, err, sens)
+        assert 0.7 < ratio < 1.4 and cos > 0.85, (k, ratio, cos)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

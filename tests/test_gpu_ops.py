@@ -197,6 +197,129 @@ def test_gemm_multiphase_wgrad(rows, N, K):
     assert rel(outs[0], ref) < 2e-5
 
 
+def test_gemm_tn_group_many_products_one_launch():
+    """du_gemm_tn_group (gemm_p8.hip: gemm_tn_group_kernel): a batch of weight-gradient products of very different shapes -- the adapter's
+    43008-token linears, a value projection with a short contraction (one split: plain stores), ragged / tiny M and N (192, 72, 8 columns:
+    tiles far from full), a strided dY view, K = 512 (two K-tile pairs, the minimum) -- queued and run by ONE launch, each against the fp32
+    product of the same bf16 operands; bias gradients (a_colsum) ride along for some of them.  Then every product alone (one job per
+    launch: the workgroups all go to that job, up to 32 splits) must give the same result."""
+    from dinounet_amd import ops
+    d = dev()
+    dt = torch.bfloat16
+    shapes = [(43008, 1024, 512, True), (43008, 192, 1024, True), (8192, 512, 1024, False), (5376, 72, 256, True), (512, 256, 384, True),
+              (2688, 8, 32, False), (16384, 320, 264, True), (1024, 1024, 1024, False)]
+    ins, refs = [], []
+    for i, (rows, N, K, cs) in enumerate(shapes):
+        dy, x = q(gen(rows, N + (8 if i == 3 else 0), seed=10 + i), dt), q(gen(rows, K, seed=40 + i), dt)
+        dyd = dy.to(d, dt)
+        if i == 3:
+            dy, dyd = dy[:, :N], dyd[:, :N]             # a column slice of a wider tensor: lda = N + 8
+        ins.append((dyd, x.to(d, dt), cs))
+        refs.append(((dy.double().t() @ x.double()).float(), dy.double().sum(0).float()))
+    W = ops.WGRAD
+    assert W.enabled
+    l0, q0 = W.launches, W.queued
+    W._armed = True                                    # hold the queue (outside a backward pass a job would be launched at once)
+    try:
+        outs = [ops.mm_wgrad(a, b, with_colsum=cs, defer=True) for a, b, cs in ins]
+        assert W.queued - q0 == len(shapes) and len(W.jobs) == len(shapes)
+    finally:
+        W._armed = False
+    W.flush()
+    assert W.launches - l0 == 1 and not W.jobs and not W.keep
+    for (rows, N, K, cs), o, (rw, rb) in zip(shapes, outs, refs):
+        dw, db = (o if cs else (o, None))
+        assert dw.shape == (N, K)
+        assert rel(dw, rw) < 2e-5, (rows, N, K)
+        if cs:
+            assert rel(db, rb) < 2e-5, (rows, N, K)
+    for (rows, N, K, cs), (a, b, _), (rw, rb) in zip(shapes, ins, refs):
+        dw = ops.mm_wgrad(a, b, defer=True)            # not inside a backward pass: launched at once, alone
+        assert rel(dw, rw) < 2e-5, ("alone", rows, N, K)
+    assert not W.jobs
+    # an illegal job (K % 128 != 0) is declined by the queue and served by the immediate path
+    dy, x = q(gen(1000, 64, seed=3), dt), q(gen(1000, 96, seed=4), dt)
+    n0 = W.queued
+    dw = ops.mm_wgrad(dy.to(d, dt), x.to(d, dt), defer=True)
+    assert W.queued == n0 and rel(dw, (dy.double().t() @ x.double()).float()) < 2e-5
+
+
+def test_deferred_weight_gradients_match_immediate_ones_through_autograd():
+    """ops.WgradQueue at model level: the same dinounet_s train step (256 x 256, bf16: 2688 query rows per step = 21 K-tile pairs, legal for
+    the grouped launch) with the queue on and off -- every gradient equal up to the summation order of the split-K partials; the queue
+    is empty after backward(); a gradient that already exists (accumulation over two backward calls) and a tensor hook on a weight keep
+    a product out of the queue; two forwards summed into one backward (two contributions per parameter in the pass) stay correct."""
+    from dinounet_amd import ops
+    from dinounet_amd.dinov3.adapter import DropPath
+    from dinounet_amd.network_architecture import DinoUNet
+    from dinounet_amd.training import dc_and_ce_loss
+    from oracle import weights
+    from oracle.refshim import PLANS_2D
+    dev()
+    net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name="dinounet_s", precision="bf16")
+    ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    net.load_state_dict(weights.make_state_dict(ks, seed=0), strict=True)
+    net = net.cuda().train()
+    for m in net.modules():
+        if isinstance(m, DropPath):
+            m.drop_prob = 0.0
+    net.encoder.dinov3_adapter.backbone.rope_embed.rescale_coords = None
+    x = weights.make_input(2, 3, 256, 256, seed=9).cuda()
+    t = weights.make_target(2, 256, 256, 2, seed=9).cuda()
+    W = ops.WGRAD
+
+    def grads(enabled, pre=None):
+        W.enabled = enabled
+        net.zero_grad(set_to_none=True)
+        q0, l0 = W.queued, W.launches
+        if pre is not None:
+            pre()
+        dc_and_ce_loss(net(x), t).backward()
+        assert not W.jobs and not W.keep and not W._armed and not W.seen
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().float().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}, W.queued - q0, W.launches - l0
+
+    try:
+        g_off, nq_off, _ = grads(False)
+        g_on, nq_on, nl_on = grads(True)
+        assert nq_off == 0 and nq_on >= 20 and 1 <= nl_on <= 4, (nq_off, nq_on, nl_on)
+        gmax = max(float(v.norm()) for v in g_off.values())
+        assert set(g_on) == set(g_off)
+        for k in g_off:
+            assert float((g_on[k] - g_off[k]).norm()) <= 1e-4 * max(float(g_off[k].norm()), 1e-3 * gmax), k
+        # a hook on one weight: that product is computed at once, the others are still queued
+        w = net.encoder.dinov3_adapter.interactions[0].extractor.attn.value_proj.weight
+        seen = []
+        h = w.register_hook(lambda g: seen.append(float(g.abs().sum())))
+        g_h, nq_h, _ = grads(True)
+        h.remove()
+        assert nq_h == nq_on - 1 and seen and seen[0] > 0
+        for k in g_off:
+            assert float((g_h[k] - g_off[k]).norm()) <= 1e-4 * max(float(g_off[k].norm()), 1e-3 * gmax), k
+        # gradient accumulation over two backward calls: the second call finds p.grad set and must add complete gradients
+        W.enabled = True
+        net.zero_grad(set_to_none=True)
+        dc_and_ce_loss(net(x), t).backward()
+        q1 = W.queued
+        dc_and_ce_loss(net(x), t).backward()
+        assert W.queued == q1                                 # nothing queued by the second call
+        torch.cuda.synchronize()
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                assert float((p.grad.float().cpu() - 2 * g_off[k]).norm()) <= 2e-4 * max(float(2 * g_off[k].norm()), 1e-3 * gmax), k
+        # two forwards, one backward: every parameter receives two contributions in the pass -- the queue is flushed before the second
+        # one is handed to the engine (which then adds the two buffers)
+        net.zero_grad(set_to_none=True)
+        (dc_and_ce_loss(net(x), t) + dc_and_ce_loss(net(x), t)).backward()
+        assert not W.jobs and not W.seen
+        torch.cuda.synchronize()
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                assert float((p.grad.float().cpu() - 2 * g_off[k]).norm()) <= 2e-4 * max(float(2 * g_off[k].norm()), 1e-3 * gmax), k
+    finally:
+        W.enabled = True
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_linear_autograd_with_residual_and_droppath(dt):
     from dinounet_amd import ops
