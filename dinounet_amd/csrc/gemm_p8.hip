@@ -668,7 +668,7 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
 #pragma unroll
         for (int b = 0; b < 2; b++) {
           const int m = m0 + i * 128 + wm * 64 + b * 32 + (lane & 31);
-          if (m < P.M) atomic_add_f32(P.a_colsum + m, csum[i][b]);
+          if (m < P.M) atomic_add_f32(P.a_colsum + m, csum[i][b] * P.alpha);
         }
     }
     if constexpr (GA) {
@@ -684,7 +684,7 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
     // lanes 0..31 = 32 consecutive columns (one 128-byte segment per row).  A product that is NOT split (grouped launches give short
     // products one workgroup per tile) owns its tile: plain stores, no read-modify-write at the memory side
     const int hi = lane >> 5;
-    const bool plain = P.split_k == 1;
+    const bool plain = P.split_k == 1 && !P.k_scale;     // (grouped launches set k_scale when several jobs accumulate into one C)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int n = n0 + j * 128 + wn * 32 + (lane & 31);
@@ -768,7 +768,9 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
 constexpr int TN_GROUP_MAX = 40;
 struct TnJob {
   const void* A; const void* B; float* C; float* a_colsum;
+  const float* alpha;                             // nullable: the product is scaled by *alpha (device memory); 0 = nothing to do
   int lda, ldb, ldc, M, N, K, splits, unit0;      // unit0: first (split, tile) unit of this job in the launch
+  int accumulate, pad_;                           // accumulate: other jobs add into the same C -> atomics even when unsplit
 };
 struct TnGroupArgs { int njobs, nunits, dbg, pad_; TnJob jobs[TN_GROUP_MAX]; };
 
@@ -786,6 +788,11 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroupArgs G) {
   P.M = G.jobs[j].M; P.N = G.jobs[j].N; P.K = G.jobs[j].K;
   P.split_k = G.jobs[j].splits;
   P.alpha = 1.0f;
+  if (G.jobs[j].alpha) {          // DropPath's per-sample scale (ops.mm_wgrad k_scale: one job per sample): dropped samples cost nothing
+    P.alpha = *G.jobs[j].alpha;
+    if (P.alpha == 0.f) return;
+  }
+  P.k_scale = G.jobs[j].accumulate;      // (re-used as the "several jobs share C" flag of the tile program's epilogue)
   P.a_colsum = G.jobs[j].a_colsum;
   P.tiles_m = (P.M + PBM - 1) / PBM; P.tiles_n = (P.N + PBN - 1) / PBN;
   P.dbg = G.dbg;
@@ -1232,7 +1239,7 @@ extern "C" int du_gemm_tn_group(const du_tn_job* jobs, int njobs, void* stream) 
     for (int k = 0; k < n; k++) {
       const du_tn_job& j = jobs[i0 + k];
       TnJob& d = G.jobs[k];
-      d.A = j.A; d.B = j.B; d.C = j.C; d.a_colsum = j.a_colsum;
+      d.A = j.A; d.B = j.B; d.C = j.C; d.a_colsum = j.a_colsum; d.alpha = j.alpha; d.accumulate = j.accumulate;
       d.lda = (int)j.lda; d.ldb = (int)j.ldb; d.ldc = (int)j.ldc; d.M = j.M; d.N = j.N; d.K = j.K;
       d.splits = splits[k]; d.unit0 = u;
       u += tiles[k] * splits[k];

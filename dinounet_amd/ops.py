@@ -529,7 +529,7 @@ class WgradQueue:
     def note_use(self, *ws):
         """forward side -> weak references to the leaf Parameters behind the weights for can_defer(), or None when they are not
         (views of) leaf Parameters or the forward runs inside a torch DDP wrapper."""
-        if not self.enabled or not torch.is_grad_enabled():
+        if not self.enabled:              # (grad mode is always off inside autograd.Function.forward: ctx.needs_input_grad decides later)
             return None
         if getattr(torch.nn.parallel.DistributedDataParallel, "_active_ddp_module", None) is not None:
             return None
@@ -612,15 +612,23 @@ def mm_wgrad(dy, x, with_colsum=False, k_scale=None, defer=False):
     Mr, N, lda = _rows2d(dy)
     Mr2, K, ldb = _rows2d(x)
     assert Mr == Mr2 and dy.dtype == x.dtype
-    if defer and WGRAD.enabled and k_scale is None and dy.dtype == torch.bfloat16 and (_WGRAD_COLSUM or not with_colsum):
-        job = _lib.TnJob(A=dy.data_ptr(), lda=lda, B=x.data_ptr(), ldb=ldb, C=0, ldc=K, a_colsum=None, M=N, N=K, K=Mr, reserved=0)
-        job.C = 1                                      # legality does not depend on the result's address
-        if WGRAD.legal(job):
+    if defer and WGRAD.enabled and dy.dtype == torch.bfloat16 and (_WGRAD_COLSUM or not with_colsum):
+        # k_scale (DropPath in backward): one job per sample, scaled by that sample's factor read on the device -- dropped samples (factor 0)
+        # cost nothing, and no scaled copy of dy is ever built
+        nj, rows_j = (1, Mr) if k_scale is None else (k_scale[0].numel(), k_scale[1])
+        job = _lib.TnJob(A=dy.data_ptr(), lda=lda, B=x.data_ptr(), ldb=ldb, C=1, ldc=K, a_colsum=None, alpha=None, M=N, N=K, K=rows_j,
+                         accumulate=0)
+        if nj * rows_j == Mr and (k_scale is None or (k_scale[0].dtype == torch.float32 and k_scale[0].is_contiguous())) and \
+                (nj == 1 or (rows_j * lda * 2) % 16 == 0 and (rows_j * ldb * 2) % 16 == 0) and WGRAD.legal(job):
             out = ZEROS.zeros((N, K), dy.device)
             db = ZEROS.zeros((N,), dy.device) if with_colsum else None
-            job.C = out.data_ptr()
-            job.a_colsum = db.data_ptr() if with_colsum else None
-            WGRAD.add(job, (dy, x))
+            for b in range(nj):
+                jb = _lib.TnJob(A=dy.data_ptr() + b * rows_j * lda * 2, lda=lda, B=x.data_ptr() + b * rows_j * ldb * 2, ldb=ldb,
+                                C=out.data_ptr(), ldc=K, a_colsum=db.data_ptr() if with_colsum else None,
+                                alpha=(k_scale[0].data_ptr() + 4 * b) if k_scale is not None else None, M=N, N=K, K=rows_j,
+                                accumulate=1 if nj > 1 else 0)
+                WGRAD.add(jb, (dy, x, k_scale[0]) if k_scale is not None else (dy, x))
+            WGRAD.queued -= nj - 1                     # statistics count products, not per-sample jobs
             return (out, db) if with_colsum else out
     out = ZEROS.zeros((N, K), dy.device)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)

@@ -146,7 +146,10 @@ typedef struct du_tn_job {
   const void* B; int64_t ldb;
   float* C; int64_t ldc;
   float* a_colsum;
-  int32_t M, N, K, reserved;
+  const float* alpha;        /* nullable: scale of the whole product, read from device memory at run time (DropPath's per-sample scale in
+                                backward, dinov3_adapter.py:18-37,148: the caller queues one job per sample); *alpha == 0 costs nothing */
+  int32_t M, N, K;
+  int32_t accumulate;        /* != 0: other jobs add into the same C / a_colsum (per-sample jobs, a parameter shared by several layers) */
 } du_tn_job;
 int du_gemm_tn_group_legal(const du_tn_job* job);
 int du_gemm_tn_group(const du_tn_job* jobs, int njobs, void* stream);

@@ -370,7 +370,11 @@ def test_linear_droppath_scale_inside_backward_gemms():
     ops.PACK.refresh()
     _, g0 = step()               # registers W^T: data gradient on the PLAIN_COL kernel, s . dy materialised
     ops.PACK.refresh()
+    nq = ops.WGRAD.queued
     y1, g1 = step()
+    # the weight gradient went through the grouped launch as one job per sample, scaled by the sample's factor on the device (dropped
+    # samples return at once): ops.mm_wgrad(k_scale=..., defer=True)
+    assert ops.WGRAD.queued == nq + 1 and not ops.WGRAD.jobs
     assert (ops.PLAIN_ROW, ops.PLAIN_COL) not in [(am, bm) for am, bm, _ in ops.ROUTES]
     assert rel(y1, yr) < TOL[bf]
     for a, b0, r_ in zip(g1, g0, gr):
