@@ -43,7 +43,9 @@ class TnJob(C.Structure):
     """du_tn_job (include/dinounet_hip.h): one queued weight-gradient product of du_gemm_tn_group."""
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64),
                 ("a_colsum", C.c_void_p), ("alpha", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
-                ("accumulate", C.c_int32)]
+                ("accumulate", C.c_int32), ("b_colsum", C.c_void_p),
+                ("gather", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32), ("Cb", C.c_int32),
+                ("taps", C.c_int32), ("inner", C.c_int32), ("inner_total", C.c_int32), ("c_off", C.c_int32)]
 
 
 _CTYPE = {"int": C.c_int, "int64_t": C.c_int64, "float": C.c_float, "int32_t": C.c_int32}

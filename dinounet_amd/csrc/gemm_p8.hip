@@ -36,6 +36,7 @@
 // 4 consecutive columns per register quad, so the epilogue stages 8-byte (bf16, after bias / activation / LayerScale in registers)
 // or 16-byte (fp32) pieces into a row-major LDS tile and writes whole 512-byte output rows (a lane-per-row store would touch 32
 // cache lines per instruction).
+#include <vector>
 #include "common.h"
 #include "gemm_params.h"
 
@@ -332,8 +333,13 @@ __device__ __forceinline__ int xcd_linear_index() {
 
 // The tile program of both launch forms: the plain kernel below (one product per launch) and gemm_tn_group_kernel (several weight-gradient
 // products per launch).  TN: `lin` = this workgroup's (split, tile) index inside the product, tiles of one split adjacent.
-template <typename TC, int SCHED, bool TN, bool GA>
+// GG (TN only, grouped launches): the B operand is gathered in place with a per-lane source offset -- ConvTranspose2d k2 s2 weight gradients
+// of ANY channel count (B(k = input pixel, n = (tap, co)) = dy[output pixel (2y + tap / 2, 2x + tap % 2)][co]) and 3 x 3 / stride 1 / pad 1
+// convolution weight gradients (B(k = pixel, n = (tap, ci)) = x[pixel + tap shift][ci], zero outside the image; two concatenated sources).
+// GG = 2: the ConvTranspose form, GG = 3: the 3 x 3 convolution form (compile-time: the kernel is at its register limit, scalar ones included).
+template <typename TC, int SCHED, bool TN, bool GA, int GG = 0>
 __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char* smem, const int lin) {
+  static_assert(GG == 0 || ((GG == 2 || GG == 3) && TN && !GA), "general gather: weight-gradient form only");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -366,7 +372,14 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
   if constexpr (TN) {
     Ab = (const bf16_t*)P.a.p + (long)batch * P.a.bstride + kbeg * P.a.ld + m0;
     abytes = ((P.K - kbeg - 1) * P.a.ld + (P.M - m0)) * 2;
-    if constexpr (GA) {       // the whole tile lies in one tap (C % 256 == 0): base = the tap's pixel offset + first channel
+    if constexpr (GG != 0) {       // the whole source tensor; every lane carries its own (pixel shift, channel) offset
+      Bb = (const bf16_t*)P.b.p;
+      bbytes = P.b.bstride;   // (bytes of the source, set by the group kernel)
+      if constexpr (GG == 3) {     // based one image row + one pixel before the tensor (see g_pv below)
+        Bb -= (long)(P.b.Wi + 1) * P.b.ld;
+        bbytes += (long)(P.b.Wi + 1) * P.b.ld * 2;
+      }
+    } else if constexpr (GA) {       // the whole tile lies in one tap (C % 256 == 0): base = the tap's pixel offset + first channel
       const int tapn = n0 / P.b.C, co0 = n0 - tapn * P.b.C;
       const long off = ((long)(tapn >> 1) * P.b.Wi + (tapn & 1)) * P.b.ld + co0;
       Bb = (const bf16_t*)P.b.p + off;
@@ -387,7 +400,7 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
     bbytes = ((long)(P.N - n0) * P.b.ld - (P.b.ld - P.K)) * 2;
   }
   if (abytes > 0x7fffffffL) abytes = 0x7fffffffL;
-  if (bbytes > 0x7fffffffL) bbytes = 0x7fffffffL;
+  if (bbytes > 0x7fffff00L) bbytes = 0x7fffff00L;
   const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)abytes, 0x00020000);
   const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)bbytes, 0x00020000);
 
@@ -430,7 +443,43 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
   // TN gather: contraction row = input pixel; with Wo a power of two, pixel p = (yy, x) reads output pixel (2 yy, 2 x) (+ the tap offset
   // folded into the descriptor base), yy = b * Ho + y
   int logW = 0;
-  if constexpr (GA && TN) logW = __builtin_ctz(P.b.Wo);
+  if constexpr ((GA || GG != 0) && TN) logW = __builtin_ctz(P.b.Wo);
+  // GG: this lane's 16-byte chunk of half h is column n0 + h * 128 + lc * 8 = (tap, channel).
+  //   GG == 2 (ConvT): g_off[h] = byte offset of (tap shift, channel) relative to the base pixel (1 = the column does not exist: byte
+  //     offsets are even); the base pixel of a contraction row is computed per piece (a K-tile may span several image rows).
+  //   GG == 3 (3 x 3): Ws % 64 == 0, so a K-tile (64 consecutive pixels) lies inside ONE image row: the source offset of a piece is
+  //     a per-lane CONSTANT g_pv[h][r] = ((local pixel + tap shift) * row pitch + channel) * 2 plus the tile's scalar base offset (the
+  //     buffer soffset) -- no address arithmetic in the loop.  The descriptor is based one image row + one pixel BEFORE the tensor so the
+  //     (dy, dx) = (-1, -1) shifts stay non-negative (the voffset is range-checked as an unsigned number).  Zero padding: g_mask holds, per
+  //     (h, r), 4 bits = "this lane's tap reaches above / below / left of / right of the image when the tile sits on that border and the
+  //     lane's pixel on that edge"; the tile's own 4 border bits are scalar.  A hit sends the load past the descriptor's range (zeros).
+  int g_off[2] = {1, 1};
+  unsigned g_pv[2][2] = {{0u, 0u}, {0u, 0u}};
+  unsigned g_mask = 0u;
+  const unsigned g_ldb = (unsigned)(P.b.ld * 2);      // row pitch of the source in bytes
+  if constexpr (GG != 0) {
+    const int r4 = lane >> 4, lc = (lane & 15) ^ (4 * r4);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int col0 = n0 + h * 128, tap0 = col0 / P.b.C, ci0 = col0 - tap0 * P.b.C;        // wave-uniform: first column of the half
+      const int ld = (int)P.b.ld;
+      int ci = ci0 + lc * 8, tap = tap0;                     // a half spans at most 128 / 8 = 16 taps' worth of 8-channel chunks
+      while (ci >= P.b.C) { ci -= P.b.C; tap++; }
+      const bool exists = col0 + lc * 8 < P.N;
+      if constexpr (GG == 2) {
+        g_off[h] = exists ? (((tap >> 1) * P.b.Wi + (tap & 1)) * ld + ci) * 2 : 1;
+      } else {
+        const int ty = tap / 3, tx = tap - ty * 3;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const int lr = (r * 8 + wave) * 4 + r4;            // this lane's pixel inside the K-tile
+          g_pv[h][r] = exists ? (unsigned)(((lr + ty * P.b.Wi + tx) * ld + ci) * 2) : 0x7fffff00u;
+          const unsigned bits = (ty == 0 ? 1u : 0u) | (ty == 2 ? 2u : 0u) | ((tx == 0 && lr == 0) ? 4u : 0u) | ((tx == 2 && lr == 63) ? 8u : 0u);
+          g_mask |= bits << (4 * (2 * h + r));
+        }
+      }
+    }
+  }
   const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
   // which: 0 = A-half0, 1 = A-half1, 2 = B-half0, 3 = B-half1 of K-tile kt, into buffer buf
   auto stage = [&](auto which_c, auto buf_c, int kt) {
@@ -444,10 +493,26 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
       const int k = kt * PBK, tap = k >> P.a.logC, within = k - (tap << P.a.logC);
       soff = (unsigned)((((tap >> 1) * P.a.Wi + (tap & 1)) * (int)P.a.ld + within) * 2);
     }
-    if constexpr (GA && TN && which >= 2) soff = 0;
+    if constexpr ((GA || GG == 2) && TN && which >= 2) soff = 0;
+    unsigned tile_bits = 0u;
+    if constexpr (GG == 3 && which >= 2) {
+      const int p0 = (int)kbeg + kt * PBK;                                  // first pixel of the K-tile (scalar): (image row y, x0)
+      const int x0 = p0 & (P.b.Wo - 1), y = (p0 >> logW) & (P.b.Ho - 1);
+      soff = (unsigned)p0 * g_ldb;
+      tile_bits = (y == 0 ? 1u : 0u) | (y == P.b.Ho - 1 ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + PBK == P.b.Wo ? 8u : 0u);
+    }
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       unsigned voff = which < 2 ? va[h][r] : vb[h][r];
+      if constexpr (GG == 3 && which >= 2) {
+        voff = ((g_mask >> (4 * (2 * h + r))) & tile_bits) ? 0x7fffff00u : g_pv[h][r];
+      }
+      if constexpr (GG == 2 && which >= 2) {
+        const int krow = (int)kbeg + kt * PBK + (r * 8 + wave) * 4 + (lane >> 4);
+        const int x = krow & (P.b.Wo - 1), yy = krow >> logW;
+        const int bp = 4 * (yy << logW) + 2 * x;                  // 2 yy * Wi + 2 x with Wi = 2 Wo
+        voff = g_off[h] != 1 ? (unsigned)bp * g_ldb + (unsigned)g_off[h] : 0x7fffff00u;       // past the descriptor's range: loads zeros
+      }
       if constexpr (GA && TN && which >= 2) {
         const int r4 = lane >> 4, lc = (lane & 15) ^ (4 * r4);
         const int krow = (int)kbeg + kt * PBK + (r * 8 + wave) * 4 + r4;
@@ -560,11 +625,11 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
   };
   // ConvT weight gradient (GA): bias gradient from the gathered dY operand (du_gemm_args.b_colsum): sum_k B(n, k) from the B fragments,
   // by the two waves with wm == 0 of ONE tile row per (tile column, split); B-half 0 fragments are complete in phase q3, B-half 1 in q0
-  const bool bsum_on = TN && GA && P.b_colsum != nullptr && wm == 0 && tm == my_split % P.tiles_m;
+  const bool bsum_on = TN && (GA || GG == 2) && P.b_colsum != nullptr && wm == 0 && tm == my_split % P.tiles_m;
   float bsum[2] = {0.f, 0.f};                       // [B half j]
   auto bsum_acc = [&](auto j_c, auto set_c) {
     constexpr int j = decltype(j_c)::value, set = decltype(set_c)::value;
-    if constexpr (TN && GA) {
+    if constexpr (TN && (GA || GG == 2)) {
       if (bsum_on) {
 #pragma unroll
         for (int kk = 0; kk < 4; kk++)
@@ -671,12 +736,12 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
           if (m < P.M) atomic_add_f32(P.a_colsum + m, csum[i][b] * P.alpha);
         }
     }
-    if constexpr (GA) {
+    if constexpr (GA || GG == 2) {
       if (bsum_on) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           const int n = n0 + j * 128 + wn * 32 + (lane & 31);
-          if (n < P.N) atomic_add_f32(P.b_colsum + n % P.b.C, bsum[j]);
+          if (n < P.N) atomic_add_f32(P.b_colsum + n % P.b.C, bsum[j] * P.alpha);
         }
       }
     }
@@ -685,10 +750,16 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
     // products one workgroup per tile) owns its tile: plain stores, no read-modify-write at the memory side
     const int hi = lane >> 5;
     const bool plain = P.split_k == 1 && !P.k_scale;     // (grouped launches set k_scale when several jobs accumulate into one C)
+    // DU_STORE_TAPS (grouped convolution jobs): column n = (tap, c) of the product goes to element (m, c_off + c, tap) of a torch-layout
+    // weight (Cout, Cin, KH, KW) / (Cin, Cout, 2, 2): ps_C channels per tap in this job, ps_W channels in the parameter (a job may cover one
+    // source of a channel concat: c_off = rope_prefix), ps_H taps; no permute copy afterwards
+    const bool taps = P.store_mode == DU_STORE_TAPS;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int n = n0 + j * 128 + wn * 32 + (lane & 31);
       if (n >= P.N) continue;
+      long noff = n, mld = P.ldc;
+      if (taps) { const int t = n / P.ps_C; noff = (long)(P.rope_prefix + n - t * P.ps_C) * P.ps_H + t; mld = (long)P.ps_W * P.ps_H; }
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -697,7 +768,7 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
           for (int r = 0; r < 16; r++) {
             const int m = m0 + i * 128 + wm * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (m < P.M) {
-              float* dst = (float*)Cb + (long)m * P.ldc + n;
+              float* dst = (float*)Cb + (long)m * mld + noff;
               if (plain) *dst = acc[i][j][b][r] * P.alpha;
               else atomic_add_f32(dst, acc[i][j][b][r] * P.alpha);
             }
@@ -765,16 +836,21 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
 // workgroups are then dealt out over ALL queued products in proportion to their contraction length -- 2-4 splits per product instead
 // of 16-64, an order of magnitude fewer partial tiles, unsplit products written with plain stores -- with the tile program above
 // unchanged.  The job table travels in the kernel arguments (no device-side table to keep alive across hipGraph replays).
-constexpr int TN_GROUP_MAX = 40;
 struct TnJob {
   const void* A; const void* B; float* C; float* a_colsum;
   const float* alpha;                             // nullable: the product is scaled by *alpha (device memory); 0 = nothing to do
+  float* b_colsum;                                // ConvT jobs: bias gradient
   int lda, ldb, ldc, M, N, K, splits, unit0;      // unit0: first (split, tile) unit of this job in the launch
-  int accumulate, pad_;                           // accumulate: other jobs add into the same C -> atomics even when unsplit
+  int accumulate;                                 // other jobs add into the same C -> atomics even when unsplit
+  int gather, Hs, Ws, Cb;                         // gather: 0 plain, 2 ConvT k2 s2, 3 conv 3 x 3 s1 p1; (Hs, Ws) = pixel grid of the contraction
+  int taps, inner, inner_total, c_off;            // taps > 1: torch-layout store C[m][c_off + c][tap] of a parameter with inner_total channels
+  int pad_;
 };
+constexpr int TN_GROUP_MAX = 32;
 struct TnGroupArgs { int njobs, nunits, dbg, pad_; TnJob jobs[TN_GROUP_MAX]; };
+static_assert(sizeof(TnGroupArgs) <= 4096, "kernel arguments");
 
-template <int SCHED>
+template <int SCHED, int GG>
 __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroupArgs G) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lin = xcd_linear_index();
@@ -796,7 +872,19 @@ __global__ __launch_bounds__(512) void gemm_tn_group_kernel(TnGroupArgs G) {
   P.a_colsum = G.jobs[j].a_colsum;
   P.tiles_m = (P.M + PBM - 1) / PBM; P.tiles_n = (P.N + PBN - 1) / PBN;
   P.dbg = G.dbg;
-  p8_tile_body<float, SCHED, true, false>(P, smem, lin - G.jobs[j].unit0);
+  if (G.jobs[j].taps > 1) {
+    P.store_mode = DU_STORE_TAPS; P.ps_H = G.jobs[j].taps; P.ps_C = G.jobs[j].inner; P.ps_W = G.jobs[j].inner_total; P.rope_prefix = G.jobs[j].c_off;
+  }
+  if constexpr (GG != 0) {
+    P.b.KH = GG;
+    P.b.C = G.jobs[j].Cb;
+    P.b.Ho = G.jobs[j].Hs; P.b.Wo = G.jobs[j].Ws;
+    P.b.Wi = GG == 2 ? 2 * G.jobs[j].Ws : G.jobs[j].Ws;             // row pitch (pixels) of the SOURCE tensor
+    // bytes of source 1: ConvT gathers from dy (4 pixels per contraction row), the convolution from x (one)
+    P.b.bstride = (long)P.K * (GG == 2 ? 4 : 1) * P.b.ld * 2;
+    if constexpr (GG == 2) P.b_colsum = G.jobs[j].b_colsum;
+  }
+  p8_tile_body<float, SCHED, true, false, GG>(P, smem, lin - G.jobs[j].unit0);
 }
 
 // ================================================================================================================================
@@ -827,7 +915,7 @@ __global__ __launch_bounds__(512) void gemm_nt_p8n_kernel(GemmParams P) {
   const bf16_t* Bb = (const bf16_t*)P.b.p + (long)batch * P.b.bstride + (long)n0 * P.b.ld;
   long abytes = ((long)(P.M - m0) * P.a.ld - (P.a.ld - P.K)) * 2, bbytes = ((long)(P.N - n0) * P.b.ld - (P.b.ld - P.K)) * 2;
   if (abytes > 0x7fffffffL) abytes = 0x7fffffffL;
-  if (bbytes > 0x7fffffffL) bbytes = 0x7fffffffL;
+  if (bbytes > 0x7fffff00L) bbytes = 0x7fffff00L;
   const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)abytes, 0x00020000);
   const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)bbytes, 0x00020000);
 
@@ -1183,26 +1271,37 @@ int du_gemm_tn_p8_splits(const du_gemm_args& a) {
 }
 
 // ---- grouped weight gradients (see gemm_tn_group_kernel) ----
+static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 static bool tn_group_legal(const du_tn_job& j) {
   if (!j.A || !j.B || !j.C || j.M <= 0 || j.N <= 0) return false;
   if (j.K % 128 || j.K < 512) return false;                       // whole K-tile pairs, at least two pairs per split
-  if (j.lda % 8 || j.ldb % 8 || j.lda < j.M || j.ldb < j.N || j.ldc < j.N) return false;
+  if (j.lda % 8 || j.ldb % 8 || j.lda < j.M) return false;
   if ((((uintptr_t)j.A) | ((uintptr_t)j.B)) & 15) return false;
   if (j.lda > 0x7fffffffL / 4 || j.ldb > 0x7fffffffL / 4 || j.ldc > 0x7fffffffL) return false;
-  // an unsplit product addresses its whole operand through one 32-bit buffer offset
-  const long ldmax = j.lda > j.ldb ? j.lda : j.ldb;
-  return ((long)j.K + 128) * ldmax * 2 <= 0x7fffffffL;
+  if (j.taps > 1 && (j.inner <= 0 || j.N != j.taps * j.inner)) return false;
+  if (j.taps <= 1 && j.ldc < j.N) return false;
+  if (((long)j.K + 128) * j.lda * 2 > 0x7fffffffL) return false;   // an unsplit product addresses its operand through one 32-bit offset
+  if (j.taps > 1 && (j.c_off < 0 || j.inner_total < j.c_off + j.inner)) return false;
+  if (j.gather == 0) {
+    if (j.ldb < j.N || j.b_colsum) return false;
+    return ((long)j.K + 128) * j.ldb * 2 <= 0x7fffffffL;
+  }
+  if (j.gather != 2 && j.gather != 3) return false;
+  if (j.Cb <= 0 || j.Cb % 8 || j.ldb < j.Cb || !pow2(j.Ws) || j.Hs <= 0 || j.K % (j.Hs * j.Ws)) return false;
+  if (j.gather == 2) {
+    if (j.N != 4 * j.Cb) return false;
+    return (long)j.K * 4 * j.ldb * 2 <= 0x7fffff00L;
+  }
+  if (j.N != 9 * j.Cb || !pow2(j.Hs) || j.b_colsum) return false;
+  return (long)j.K * j.ldb * 2 <= 0x7fffff00L;
 }
 extern "C" int du_gemm_tn_group_legal(const du_tn_job* job) { return (job && g_p8_mode != 0 && tn_group_legal(*job)) ? 1 : 0; }
 
-extern "C" int du_gemm_tn_group(const du_tn_job* jobs, int njobs, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  if (njobs < 0 || (njobs > 0 && !jobs)) return DU_ERR_BAD_ARG;
-  for (int i = 0; i < njobs; i++)
-    if (!tn_group_legal(jobs[i])) return DU_ERR_UNSUPPORTED;
+template <int GG>
+static int tn_group_launch(const du_tn_job* const* jobs, int njobs, hipStream_t st) {
   static const int target_units = getenv("DU_TN_GROUP_UNITS") ? atoi(getenv("DU_TN_GROUP_UNITS")) : 256;   // one 8-wave workgroup per CU
   static const int min_pairs = getenv("DU_TN_GROUP_MINPAIRS") ? atoi(getenv("DU_TN_GROUP_MINPAIRS")) : 8;  // >= 1024 contraction rows per split
-  void (*kfn)(TnGroupArgs) = g_p8_sched ? gemm_tn_group_kernel<1> : gemm_tn_group_kernel<0>;
+  void (*kfn)(TnGroupArgs) = g_p8_sched ? gemm_tn_group_kernel<1, GG> : gemm_tn_group_kernel<0, GG>;
   static bool attr_set[2] = {false, false};
   if (!attr_set[g_p8_sched ? 1 : 0]) {
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS) != hipSuccess) return DU_ERR_LAUNCH;
@@ -1214,7 +1313,7 @@ extern "C" int du_gemm_tn_group(const du_tn_job* jobs, int njobs, void* stream) 
     int tiles[TN_GROUP_MAX], pairs[TN_GROUP_MAX], splits[TN_GROUP_MAX];
     int n = 0, units = 0;
     while (i0 + n < njobs && n < TN_GROUP_MAX) {
-      const du_tn_job& j = jobs[i0 + n];
+      const du_tn_job& j = *jobs[i0 + n];
       const int t = ((j.M + PBM - 1) / PBM) * ((j.N + PBN - 1) / PBN);
       if (n > 0 && units + t > target_units) break;
       tiles[n] = t; pairs[n] = j.K / 128; splits[n] = 1;
@@ -1225,8 +1324,6 @@ extern "C" int du_gemm_tn_group(const du_tn_job* jobs, int njobs, void* stream) 
       int best = -1; double len = 0.0;
       for (int k = 0; k < n; k++) {
         if (units + tiles[k] > target_units || pairs[k] / (splits[k] + 1) < min_pairs) continue;
-        const long ldmax = jobs[i0 + k].lda > jobs[i0 + k].ldb ? jobs[i0 + k].lda : jobs[i0 + k].ldb;
-        (void)ldmax;
         const double l = (double)pairs[k] / splits[k];
         if (l > len) { len = l; best = k; }
       }
@@ -1237,10 +1334,13 @@ extern "C" int du_gemm_tn_group(const du_tn_job* jobs, int njobs, void* stream) 
     G.njobs = n; G.dbg = g_p8_debug;
     int u = 0;
     for (int k = 0; k < n; k++) {
-      const du_tn_job& j = jobs[i0 + k];
+      const du_tn_job& j = *jobs[i0 + k];
       TnJob& d = G.jobs[k];
       d.A = j.A; d.B = j.B; d.C = j.C; d.a_colsum = j.a_colsum; d.alpha = j.alpha; d.accumulate = j.accumulate;
+      d.b_colsum = j.b_colsum;
       d.lda = (int)j.lda; d.ldb = (int)j.ldb; d.ldc = (int)j.ldc; d.M = j.M; d.N = j.N; d.K = j.K;
+      d.gather = j.gather; d.Hs = j.Hs; d.Ws = j.Ws; d.Cb = j.Cb;
+      d.taps = j.taps; d.inner = j.inner; d.inner_total = j.taps > 1 ? j.inner_total : 0; d.c_off = j.taps > 1 ? j.c_off : 0;
       d.splits = splits[k]; d.unit0 = u;
       u += tiles[k] * splits[k];
     }
@@ -1251,6 +1351,21 @@ extern "C" int du_gemm_tn_group(const du_tn_job* jobs, int njobs, void* stream) 
     i0 += n;
   }
   return DU_OK;
+}
+
+extern "C" int du_gemm_tn_group(const du_tn_job* jobs, int njobs, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (njobs < 0 || (njobs > 0 && !jobs)) return DU_ERR_BAD_ARG;
+  for (int i = 0; i < njobs; i++)
+    if (!tn_group_legal(jobs[i])) return DU_ERR_UNSUPPORTED;
+  // plain products and in-place gathers run different instantiations of the tile program: one launch sequence each, queue order kept
+  std::vector<const du_tn_job*> plain, convt, conv3;
+  for (int i = 0; i < njobs; i++) (jobs[i].gather == 0 ? plain : jobs[i].gather == 2 ? convt : conv3).push_back(&jobs[i]);
+  int rc = DU_OK;
+  if (!plain.empty()) rc = tn_group_launch<0>(plain.data(), (int)plain.size(), st);
+  if (rc == DU_OK && !convt.empty()) rc = tn_group_launch<2>(convt.data(), (int)convt.size(), st);
+  if (rc == DU_OK && !conv3.empty()) rc = tn_group_launch<3>(conv3.data(), (int)conv3.size(), st);
+  return rc;
 }
 
 int du_gemm_tn_p8(const du_gemm_args& a, hipStream_t st) {

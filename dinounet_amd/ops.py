@@ -601,6 +601,40 @@ class WgradQueue:
 WGRAD = WgradQueue()
 
 
+def _pow2(v):
+    return v > 0 and (v & (v - 1)) == 0
+
+
+def _queue_conv_wgrad(kind, a, lda, srcs, dyB, Hs, Ws, M, w_shape, want_bias):
+    """Queue a convolution weight gradient on the grouped launch (du_tn_job.gather) -> (dw in torch layout, db or None), or None when a
+    job is not legal.  kind 3: 3 x 3 / s1 / p1, A = dy (pixels, Cout), srcs = [(x, ld, C), ...] the sources of the (fused concat) input, bias
+    gradient = column sums of A.  kind 2: ConvTranspose2d k2 s2, A = x (pixels, Cin), srcs = [(dy, ld, Cout)], bias gradient = sum of dy."""
+    K = dyB * Hs * Ws
+    taps = 9 if kind == 3 else 4
+    ctot = sum(c for _, _, c in srcs)
+    jobs = []
+    for i, (t, ld, cc) in enumerate(srcs):
+        j = _lib.TnJob(A=a.data_ptr(), lda=lda, B=t.data_ptr(), ldb=ld, C=1, ldc=0, a_colsum=None, alpha=None, M=M, N=taps * cc, K=K,
+                       accumulate=0, b_colsum=None, gather=kind, Hs=Hs, Ws=Ws, Cb=cc, taps=taps, inner=cc, inner_total=ctot,
+                       c_off=sum(c for _, _, c in srcs[:i]))
+        if (kind == 3 and Ws % 64) or not WGRAD.legal(j):
+            return None
+        jobs.append(j)
+    dw = ZEROS.zeros(w_shape, a.device)
+    db = None
+    if want_bias:
+        db = ZEROS.zeros((M if kind == 3 else ctot,), a.device)
+        if kind == 3:
+            jobs[0].a_colsum = db.data_ptr()
+        else:
+            jobs[0].b_colsum = db.data_ptr()
+    for j, (t, _, _) in zip(jobs, srcs):
+        j.C = dw.data_ptr()
+        WGRAD.add(j, (a, t))
+    WGRAD.queued -= len(jobs) - 1
+    return dw, db
+
+
 def mm_wgrad(dy, x, with_colsum=False, k_scale=None, defer=False):
     """dw[n][k] = sum_m dy[m][n] * x[m][k]  -> fp32 (N,K); split-K over the rows with fp32 atomics.
     with_colsum: also return the bias gradient db[n] = sum_m dy[m][n] -- taken inside the weight-gradient kernel from the dY fragments
@@ -851,6 +885,7 @@ class _Conv2d(torch.autograd.Function):
             y = conv_fwd(x, wp, _f32(bias), KH, KW, stride, pad, x2)
         ctx.save_for_backward(x, x2, w)
         ctx.conf = (KH, KW, stride, pad, bias is not None)
+        ctx.wrefs = WGRAD.note_use(*([w] if bias is None else [w, bias]))
         if part is None:
             part = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(part)
@@ -891,10 +926,21 @@ class _Conv2d(torch.autograd.Function):
                     dx, dx2 = dfull[..., :C1], dfull[..., C1:]
         want_db = has_bias and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[2]:
-            g = conv_wgrad(x, dy, KH, KW, stride, pad, x2, with_db=want_db)
-            if want_db:
-                g, db = g
-            dw = g.view(w.shape[0], KH, KW, w.shape[1]).permute(0, 3, 1, 2).contiguous()
+            r = None
+            Bo, Ho, Wo, Cout, lddy = _nhwc(dy)
+            # 3 x 3 layers the LDS-tiled weight-gradient kernel does not serve (128 output channels): in-place gather on the grouped launch
+            if (KH, KW, stride, pad) == (3, 3, 1, 1) and dy.dtype == torch.bfloat16 and _lib.lib().du_conv3x3_wgrad_halo_blocks(
+                    C1, C1 + (x2.shape[-1] if x2 is not None else 0), Cout, B, Hi, Wi) <= 0 and _pow2(Hi) and _pow2(Wi) and \
+                    (_WGRAD_COLSUM or not want_db) and WGRAD.can_defer(ctx.wrefs):
+                srcs = [(x, _nhwc(x)[4], C1)] + ([(x2, _nhwc(x2)[4], x2.shape[-1])] if x2 is not None else [])
+                r = _queue_conv_wgrad(3, dy, lddy, srcs, B, Hi, Wi, Cout, tuple(w.shape), want_db)
+            if r is not None:
+                dw, db = r
+            else:
+                g = conv_wgrad(x, dy, KH, KW, stride, pad, x2, with_db=want_db)
+                if want_db:
+                    g, db = g
+                dw = g.view(w.shape[0], KH, KW, w.shape[1]).permute(0, 3, 1, 2).contiguous()
         elif want_db:
             db = colsum(dy.view(-1, dy.shape[-1]))
         return dx, dx2, dw, db, None, None, None
@@ -1159,6 +1205,7 @@ class _ConvT2x2(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
+        ctx.wrefs = WGRAD.note_use(*([w] if bias is None else [w, bias]))
         return out
 
     @staticmethod
@@ -1179,7 +1226,15 @@ class _ConvT2x2(torch.autograd.Function):
                      N=Cin, K=4 * Cout, A=dy.data_ptr(), lda=lddy, B=wd.data_ptr(), ldb=4 * Cout, Cmat=dx.data_ptr(),
                      ldc=Cin, geom=g)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
+        queued = None
+        if ctx.needs_input_grad[1] and dy.dtype == torch.bfloat16 and _pow2(W) and (_WGRAD_COLSUM or not want_db) and \
+                x.is_contiguous() and WGRAD.can_defer(ctx.wrefs):
+            # grouped launch, dy gathered in place, result written in the parameter's (Cin, Cout, 2, 2) layout
+            queued = _queue_conv_wgrad(2, x, ld, [(dy, lddy, Cout)], B, H, W, Cin, tuple(w.shape), want_db)
+        if queued is not None:
+            dw, db = queued
+            want_db = False
+        elif ctx.needs_input_grad[1]:
             gw = ZEROS.zeros((Cin, 4 * Cout), dy.device)
             npix = B * H * W
             tiles = ((Cin + 127) // 128) * ((4 * Cout + 127) // 128)

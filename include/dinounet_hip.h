@@ -68,6 +68,8 @@ extern "C" {
 
 /* du_gemm store modes */
 #define DU_STORE_PLAIN 0
+#define DU_STORE_TAPS 3 /* grouped convolution weight gradients only (du_gemm_tn_group: du_tn_job.taps): column n = (tap, c) of the product is
+                           element (m, c, tap) of a torch-layout weight gradient */
 #define DU_STORE_QKV_ROPE 2 /* the ViT's qkv projection stored head-major with RoPE: row m = (b, token t) of M = B * ps_H tokens, column
                               n = (which, h, d) of N = 3 * ps_C * 64 -> out[which][b][h][t][d] in three (B, ps_C, ps_W = Npad, 64) planes ldc
                               elements apart; q and k of tokens >= rope_prefix are rotated (rotate-half, fp32) with rope_sin / rope_cos
@@ -140,7 +142,18 @@ int du_gemm_route(const du_gemm_args* args);
    the caller (jobs that get more than one K split add into it atomically); a_colsum (nullable, zeroed, M floats): += sum_k A[k][m], the
    bias gradient.  The 256 workgroups of a launch are dealt out over the jobs in proportion to their contraction length.
    du_gemm_tn_group_legal: 1 if a job can be queued (K % 128 == 0, K >= 512, lda / ldb % 8 == 0, 16-byte aligned operands, < 2 GB
-   operands); du_gemm_tn_group returns DU_ERR_UNSUPPORTED if any job is not. */
+   operands); du_gemm_tn_group returns DU_ERR_UNSUPPORTED if any job is not.
+   Convolution weight gradients (gather != 0) read B in place from an NHWC tensor, K = B * Hs * Ws contraction pixels (Ws -- and for
+   gather 3 also Hs -- a power of two), Cb channels per tap (Cb % 8 == 0), N = taps * Cb:
+     gather 2: nn.ConvTranspose2d(k 2, s 2) (dinounet_training.py:255-264,558; dinov3_adapter.py:360): A = x (K, M = Cin), B(k, (tap, co)) =
+               dy[pixel (2y + tap / 2, 2x + tap % 2)][co] with dy (B, 2 Hs, 2 Ws, Cb), pixel stride ldb; b_colsum (nullable, Cb floats,
+               zeroed) += the bias gradient sum_pixels dy;
+     gather 3: 3 x 3 / stride 1 / pad 1 convolution (the U-Net decoder blocks, dinounet_training.py:581-592): A = dy (K, M = Cout),
+               B(k, (tap, ci)) = x[pixel + (tap / 3 - 1, tap % 3 - 1)][ci], zero outside the image; x (B, Hs, Ws, Cb), pixel stride ldb.
+               A convolution over a fused channel concat (dinounet_training.py:614) is queued as one job per source.
+   taps > 1: C is written in torch's weight layout, element (m, c_off + c, tap) at (m * inner_total + c_off + c) * taps + tap (inner = Cb
+   channels in this job, inner_total in the parameter): the gradient of a (Cout, Cin, 3, 3) or (Cin, Cout, 2, 2) parameter without a
+   permute afterwards; ldc is ignored. */
 typedef struct du_tn_job {
   const void* A; int64_t lda;
   const void* B; int64_t ldb;
@@ -150,6 +163,8 @@ typedef struct du_tn_job {
                                 backward, dinov3_adapter.py:18-37,148: the caller queues one job per sample); *alpha == 0 costs nothing */
   int32_t M, N, K;
   int32_t accumulate;        /* != 0: other jobs add into the same C / a_colsum (per-sample jobs, a parameter shared by several layers) */
+  float* b_colsum;
+  int32_t gather, Hs, Ws, Cb, taps, inner, inner_total, c_off;
 } du_tn_job;
 int du_gemm_tn_group_legal(const du_tn_job* job);
 int du_gemm_tn_group(const du_tn_job* jobs, int njobs, void* stream);

@@ -489,6 +489,67 @@ def test_conv_transpose2x2_bwd_on_gather_kernels(B, H, W, Cin, Cout):
     assert rel(res[1][1], res[0][1]) < 1e-4
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,bias", [(2, 16, 16, 256, 128, True), (2, 16, 32, 32, 32, True), (4, 16, 16, 384, 384, False),
+                                                 (2, 32, 32, 64, 32, True), (1, 32, 64, 24, 40, True)])
+def test_conv_transpose2x2_weight_gradient_on_the_grouped_launch(B, H, W, Cin, Cout, bias):
+    """ConvTranspose2d k2 s2 weight (and bias) gradient as a queued job of du_gemm_tn_group (du_tn_job.gather = 2): dy gathered in place
+    for ANY channel count (an N tile may span several taps: per-lane tap offsets), result written straight in the parameter's
+    (Cin, Cout, 2, 2) layout.  Weights are nn.Parameters (only those are queued) and the gradient is taken inside an autograd pass; the
+    fp32 sums of exact bf16 products agree with the fp64 reference to round-off, so a wrong tap / column / layout cannot hide."""
+    from dinounet_amd import ops
+    d = dev()
+    dt = torch.bfloat16
+    x, w, b = q(gen(B, Cin, H, W, seed=1), dt), q(gen(Cin, Cout, 2, 2, seed=2, scale=Cin ** -0.5), dt), gen(Cout, seed=3)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, br if bias else None, stride=2)
+    go = q(gen(*yr.shape, seed=4), dt)
+    gr = torch.autograd.grad(yr, (wr, br) if bias else (wr,), go.double())
+    xg = nhwc(x).to(d, dt).requires_grad_(True)
+    wg = torch.nn.Parameter(w.to(d))
+    bg = torch.nn.Parameter(b.to(d)) if bias else None
+    n0 = ops.WGRAD.queued
+    y = ops.conv_transpose2x2(xg, wg, bg)
+    gg = torch.autograd.grad(y, (wg, bg) if bias else (wg,), nhwc(go).to(d, dt))
+    assert ops.WGRAD.queued == n0 + 1 and not ops.WGRAD.jobs
+    assert gg[0].shape == wg.shape and gg[0].is_contiguous()
+    assert rel(gg[0], gr[0].float()) < 2e-5
+    if bias:
+        assert rel(gg[1], gr[1].float()) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout,bias", [(1, 64, 64, 128, 128, 128, True), (2, 32, 64, 128, 0, 128, True), (1, 64, 128, 256, 0, 128, False),
+                                                   (2, 16, 64, 40, 24, 128, True)])
+def test_conv3x3_weight_gradient_on_the_grouped_launch(B, H, W, C1, C2, Cout, bias):
+    """3 x 3 / stride 1 / pad 1 weight gradient of the layers the LDS-tiled kernel does not serve (128 output channels: the first U-Net
+    decoder stage, dinounet_training.py:581-592) as queued jobs of du_gemm_tn_group (gather = 3): x gathered in place with per-lane tap
+    offsets, zero padding by a border bit mask, one job per source of the fused channel concat, (Cout, Cin, 3, 3) written directly."""
+    from dinounet_amd import ops
+    d = dev()
+    dt = torch.bfloat16
+    Cin = C1 + C2
+    x = q(gen(B, H, W, C1, seed=31), dt)
+    x2 = q(gen(B, H, W, C2, seed=32), dt) if C2 else None
+    w = q(gen(Cout, Cin, 3, 3, seed=33, scale=0.1), dt)
+    bv = gen(Cout, seed=34, scale=0.1)
+    go = q(gen(B, H, W, Cout, seed=35), dt)
+    xin = torch.cat([x, x2], -1) if C2 else x
+    wr, br = w.double().requires_grad_(True), bv.double().requires_grad_(True)
+    yr = F.conv2d(xin.double().permute(0, 3, 1, 2), wr, br if bias else None, 1, 1).permute(0, 2, 3, 1)
+    gr = torch.autograd.grad(yr, (wr, br) if bias else (wr,), go.double())
+    xg = x.to(d, dt).requires_grad_(True)
+    x2g = x2.to(d, dt).requires_grad_(True) if C2 else None
+    wg = torch.nn.Parameter(w.to(d))
+    bg = torch.nn.Parameter(bv.to(d)) if bias else None
+    n0 = ops.WGRAD.queued
+    y = ops.conv2d(xg, wg, bg, 1, 1, x2g)
+    gg = torch.autograd.grad(y, (wg, bg) if bias else (wg,), go.to(d, dt))
+    assert ops.WGRAD.queued == n0 + 1 and not ops.WGRAD.jobs
+    assert gg[0].shape == wg.shape and gg[0].is_contiguous()
+    assert rel(gg[0].flatten(1), gr[0].float().flatten(1)) < 2e-5
+    if bias:
+        assert rel(gg[1], gr[1].float()) < 2e-5
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_conv_transpose2x2_fused_residual(dt):
     """ConvTranspose + skip add in the epilogue (dinov3_adapter.py:467): the residual has the OUTPUT (pixel-shuffled) layout."""
