@@ -64,7 +64,9 @@ class GPUAugment2D:
         noise = np.zeros((B, Cc), np.float32)
         for b in range(B):
             if rs.uniform() < 0.1:
-                noise[b] = np.sqrt(rs.uniform(0, 0.1))          # one variance per sample (per_channel=False)
+                # batchgenerators' augment_gaussian_noise draws `variance = uniform(0, 0.1)` and hands it to np.random.normal as the
+                # STANDARD DEVIATION (scale): the noise std is U(0, 0.1), not its square root (per_channel=False: one draw per sample)
+                noise[b] = rs.uniform(0, 0.1)
         blur = np.zeros((B, Cc), np.float32)
         for b in range(B):
             if rs.uniform() < 0.2:

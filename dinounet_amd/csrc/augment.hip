@@ -12,7 +12,7 @@
 //                       cval -1 outside the image, ascending labels overwrite; pixels no label claims are 0, which is also what
 //                       RemoveLabelTransform(-1, 0) leaves)
 //   du_aug_plane_stats  per (sample, channel) plane: mean, std (population), min, max
-//   du_aug_noise_mult   GaussianNoiseTransform (x + N(0, var)) then BrightnessMultiplicativeTransform (x * m)
+//   du_aug_noise_mult   GaussianNoiseTransform (x + N(0, sigma^2), sigma ~ U(0, 0.1) drawn by the host) then BrightnessMultiplicativeTransform (x * m)
 //   du_aug_contrast     ContrastAugmentationTransform, preserve_range: clip((x - mean) * f + mean, min, max)
 //   du_aug_gamma        GammaTransform body: [negate] ((x - min) / (range + 1e-7))^gamma * range + min   (retain_stats: du_aug_affine)
 //   du_aug_affine       x * a + b per plane (retain_stats rescale, final negate)

@@ -490,24 +490,27 @@ def _split_for(tiles, kdim, target=512):
 
 
 class WgradQueue:
-    """Deferred weight gradients of the linear layers (du_gemm_tn_group: several dW = dY^T X products in ONE launch).
+    """Deferred weight gradients (du_gemm_tn_group: several dW = dY^T X products in ONE launch).
 
     Nothing reads a weight gradient before clip_grad_norm_ / the optimizer (nnUNetTrainer.py:919-928), while one product alone has to be
     cut into 16-64 K splits to fill 256 CUs and pays a full fp32 read-modify-write of its result per split (more than its MFMA loop for
-    most adapter layers, tools/gemm_tn_bench.py).  mm_wgrad(defer=True) therefore only allocates the (zeroed) result, records the job and
+    most adapter layers, tools/gemm_tn_bench.py).  A backward node therefore only allocates the (zeroed) result, records the job and
     keeps dY / X alive; flush() launches everything queued -- the workgroups are dealt out over all jobs, 2-4 splits per product.
 
     flush() runs (a) from an autograd-engine callback at the end of the backward pass that queued the job (`p.grad` is complete when
     backward() / autograd.grad() returns, whatever the caller does next), (b) from GradAllReducer just before a bucket of gradients is
     gathered for its all-reduce, (c) at once when a job is queued outside a backward pass (op tests, tools).
 
-    What keeps a product OUT of the queue (it is then computed at once, as before), checked per backward node by can_defer():
-      * the parameter already has a gradient (AccumulateGrad would add the unfinished buffer into it immediately);
-      * the parameter carries tensor hooks, or post-accumulate hooks other than GradAllReducer's (which flushes before it reads);
-      * the forward ran inside a torch DistributedDataParallel wrapper (its reducer copies gradients out of the accumulators as they arrive);
-      * the parameter has ALREADY received a contribution in this backward pass (the engine sums the contributions of a parameter with
-        several uses as soon as the second one is returned): the queue is flushed first, so the earlier buffer is complete.
-    DINOUNET_WGRAD_DEFER=0 disables the queue."""
+    Protocol of a backward node: grp = begin(weak refs of its weight / bias parameters) -> None: compute now, as before; else queue the
+    products with mm_wgrad(defer=grp) / _queue_conv_wgrad(grp, ...) and hand the buffers to autograd iff grp["ret"].  What the queue
+    guarantees: the autograd engine adds the contributions of a parameter that is used several times in a pass (the ConvTranspose of
+    LearnableUpsampleBlock is applied twice, dinounet_training.py:255-264; FAPM's shared basis four times, :423) AS SOON AS the second one
+    is returned -- so every contribution of a pass goes into ONE buffer (later jobs accumulate into the first one's result and the
+    node returns None), and once a contribution of a parameter has been handed over complete (flushed, or computed at once because a
+    job was not legal) all its later ones are computed at once too.  Kept OUT of the queue: parameters that already have a gradient
+    (AccumulateGrad would add the unfinished buffer immediately), carry tensor hooks or foreign post-accumulate hooks (GradAllReducer's
+    flush before they read), or whose forward ran inside a torch DistributedDataParallel wrapper (its reducer copies gradients out of
+    the accumulators as they arrive).  DINOUNET_WGRAD_DEFER=0 disables the queue."""
 
     def __init__(self):
         self.enabled = os.environ.get("DINOUNET_WGRAD_DEFER", "1") != "0"
@@ -516,7 +519,8 @@ class WgradQueue:
         self.flops = 0.0
         self.nbytes = 0.0
         self._armed = False     # an end-of-pass callback is queued with the autograd engine
-        self.seen = set()       # id(parameter) of every weight that received a contribution in the running backward pass
+        self.state = {}         # id(parameter) -> group key (contributions pending in that group's buffers) | "done" (handed over complete)
+        self.groups = {}        # group key (ids of a node's parameters) -> {"bufs", "jobs", "first", "ret", "key"}
         self.flush_aware_hooks = 0   # > 0: the post-accumulate hooks on the parameters belong to GradAllReducer
         self.launches = 0       # statistics (tests)
         self.queued = 0
@@ -527,7 +531,7 @@ class WgradQueue:
         return b if (isinstance(b, torch.nn.Parameter) and b.is_leaf) else None
 
     def note_use(self, *ws):
-        """forward side -> weak references to the leaf Parameters behind the weights for can_defer(), or None when they are not
+        """forward side -> weak references to the leaf Parameters behind the weights for begin(), or None when they are not
         (views of) leaf Parameters or the forward runs inside a torch DDP wrapper."""
         if not self.enabled:              # (grad mode is always off inside autograd.Function.forward: ctx.needs_input_grad decides later)
             return None
@@ -547,29 +551,71 @@ class WgradQueue:
                 return False
         return True
 
-    def can_defer(self, refs):
-        """backward side (called once per node, before its weight-gradient products): see the class docstring."""
+    def _hand_over(self, ids):
+        """the parameters `ids` are about to receive a COMPLETE contribution: whatever is queued for them must be complete first"""
+        for i in ids:
+            key = self.state.get(i)
+            if key not in (None, "done") and self.groups.get(key, {}).get("jobs"):
+                self.flush()
+                break
+        for i in ids:
+            key = self.state.get(i)
+            if key not in (None, "done"):
+                self.groups.pop(key, None)
+            self.state[i] = "done"
+
+    def begin(self, refs):
+        """backward side, once per node before its weight-gradient products -> group dict or None (see the class docstring)."""
         if not self.enabled or refs is None:
-            return False
+            return None
         ps = [r() for r in refs]
         if any(p is None for p in ps) or not self._arm():
-            return False
-        again = any(id(p) in self.seen for p in ps)
-        self.seen.update(id(p) for p in ps)
-        if again:
-            self.flush()
-            return False
+            return None
+        ids = tuple(id(p) for p in ps)
+        ok = True
         for p in ps:
             if p.grad is not None or p._backward_hooks:
-                return False
+                ok = False
             if getattr(p, "_post_accumulate_grad_hooks", None) and not self.flush_aware_hooks:
-                return False
-        return True
+                ok = False
+        if not ok or any(self.state.get(i) not in (None, ids) for i in ids):
+            self._hand_over(ids)
+            return None
+        grp = self.groups.get(ids)
+        if grp is None:
+            grp = {"key": ids, "bufs": {}, "jobs": [], "first": True, "ret": True}
+            self.groups[ids] = grp
+            for i in ids:
+                self.state[i] = ids
+        else:
+            grp["first"] = grp["ret"] = False
+            for j in grp["jobs"]:          # the earlier products now share their result: no plain stores
+                j.accumulate = 1
+        return grp
+
+    def abort(self, grp):
+        """a node that was given a group computes its products at once after all (job not legal)"""
+        self._hand_over(grp["key"])
+        self.groups.pop(grp["key"], None)
+        grp["ret"] = True
+
+    def buffer(self, grp, name, shape, device):
+        """the group's result buffer `name` (zeroed on first use; later contributions of the pass add into it)"""
+        if grp is None:
+            return ZEROS.zeros(shape, device)
+        t = grp["bufs"].get(name)
+        if t is None:
+            t = grp["bufs"][name] = ZEROS.zeros(shape, device)
+        return t
 
     def legal(self, job):
         return bool(_lib.lib().du_gemm_tn_group_legal(C.byref(job)))
 
-    def add(self, job, keep):
+    def add(self, job, keep, grp=None):
+        if grp is not None:
+            if not grp["first"]:
+                job.accumulate = 1
+            grp["jobs"].append(job)
         self.jobs.append(job)
         self.keep.extend(keep)
         self.queued += 1
@@ -580,10 +626,14 @@ class WgradQueue:
 
     def _end_of_pass(self):
         self._armed = False
-        self.seen.clear()
         self.flush()
+        self.state.clear()
 
     def flush(self):
+        for ids in list(self.groups):
+            for i in ids:
+                self.state[i] = "done"
+        self.groups.clear()
         if not self.jobs:
             return
         n = len(self.jobs)
@@ -595,7 +645,7 @@ class WgradQueue:
         _lib.check(rc, "du_gemm_tn_group")
         self.launches += 1
         if PROFILE is not None:
-            PROFILE.stop("gemm_tn_group_kernel<bf16,linear_wgrad>" + (f" jobs{n}" if PROFILE.detail else ""), e0, fl, nb)
+            PROFILE.stop("gemm_tn_group_kernel<bf16,wgrad>" + (f" jobs{n}" if PROFILE.detail else ""), e0, fl, nb)
 
 
 WGRAD = WgradQueue()
@@ -605,7 +655,7 @@ def _pow2(v):
     return v > 0 and (v & (v - 1)) == 0
 
 
-def _queue_conv_wgrad(kind, a, lda, srcs, dyB, Hs, Ws, M, w_shape, want_bias):
+def _queue_conv_wgrad(grp, kind, a, lda, srcs, dyB, Hs, Ws, M, w_shape, want_bias):
     """Queue a convolution weight gradient on the grouped launch (du_tn_job.gather) -> (dw in torch layout, db or None), or None when a
     job is not legal.  kind 3: 3 x 3 / s1 / p1, A = dy (pixels, Cout), srcs = [(x, ld, C), ...] the sources of the (fused concat) input, bias
     gradient = column sums of A.  kind 2: ConvTranspose2d k2 s2, A = x (pixels, Cin), srcs = [(dy, ld, Cout)], bias gradient = sum of dy."""
@@ -620,17 +670,17 @@ def _queue_conv_wgrad(kind, a, lda, srcs, dyB, Hs, Ws, M, w_shape, want_bias):
         if (kind == 3 and Ws % 64) or not WGRAD.legal(j):
             return None
         jobs.append(j)
-    dw = ZEROS.zeros(w_shape, a.device)
+    dw = WGRAD.buffer(grp, "dw", w_shape, a.device)
     db = None
     if want_bias:
-        db = ZEROS.zeros((M if kind == 3 else ctot,), a.device)
+        db = WGRAD.buffer(grp, "db", (M if kind == 3 else ctot,), a.device)
         if kind == 3:
             jobs[0].a_colsum = db.data_ptr()
         else:
             jobs[0].b_colsum = db.data_ptr()
     for j, (t, _, _) in zip(jobs, srcs):
         j.C = dw.data_ptr()
-        WGRAD.add(j, (a, t))
+        WGRAD.add(j, (a, t), grp)
     WGRAD.queued -= len(jobs) - 1
     return dw, db
 
@@ -640,12 +690,14 @@ def mm_wgrad(dy, x, with_colsum=False, k_scale=None, defer=False):
     with_colsum: also return the bias gradient db[n] = sum_m dy[m][n] -- taken inside the weight-gradient kernel from the dY fragments
     it streams anyway (du_gemm_args.a_colsum) where the kernel family can, by du_colsum (two more launches, one more pass over dY)
     otherwise.
-    defer: the caller hands the result to autograd as the gradient of a parameter used ONCE in the step; the product may then be queued
-    (WgradQueue) and computed later in the backward pass together with others -- the returned tensors are valid after WGRAD.flush()."""
+    defer: a group from WGRAD.begin() (a backward node: the product is queued and computed later in the pass together with others; the
+    returned tensors are the group's buffers, complete after WGRAD.flush()) or True (stand-alone job: tests / tools).  A product that
+    cannot be queued is computed at once and the group is told (WGRAD.abort)."""
     _req(dy, x)
     Mr, N, lda = _rows2d(dy)
     Mr2, K, ldb = _rows2d(x)
     assert Mr == Mr2 and dy.dtype == x.dtype
+    grp = defer if isinstance(defer, dict) else None
     if defer and WGRAD.enabled and dy.dtype == torch.bfloat16 and (_WGRAD_COLSUM or not with_colsum):
         # k_scale (DropPath in backward): one job per sample, scaled by that sample's factor read on the device -- dropped samples (factor 0)
         # cost nothing, and no scaled copy of dy is ever built
@@ -654,16 +706,18 @@ def mm_wgrad(dy, x, with_colsum=False, k_scale=None, defer=False):
                          accumulate=0)
         if nj * rows_j == Mr and (k_scale is None or (k_scale[0].dtype == torch.float32 and k_scale[0].is_contiguous())) and \
                 (nj == 1 or (rows_j * lda * 2) % 16 == 0 and (rows_j * ldb * 2) % 16 == 0) and WGRAD.legal(job):
-            out = ZEROS.zeros((N, K), dy.device)
-            db = ZEROS.zeros((N,), dy.device) if with_colsum else None
+            out = WGRAD.buffer(grp, "dw", (N, K), dy.device)
+            db = WGRAD.buffer(grp, "db", (N,), dy.device) if with_colsum else None
             for b in range(nj):
                 jb = _lib.TnJob(A=dy.data_ptr() + b * rows_j * lda * 2, lda=lda, B=x.data_ptr() + b * rows_j * ldb * 2, ldb=ldb,
                                 C=out.data_ptr(), ldc=K, a_colsum=db.data_ptr() if with_colsum else None,
                                 alpha=(k_scale[0].data_ptr() + 4 * b) if k_scale is not None else None, M=N, N=K, K=rows_j,
                                 accumulate=1 if nj > 1 else 0)
-                WGRAD.add(jb, (dy, x, k_scale[0]) if k_scale is not None else (dy, x))
+                WGRAD.add(jb, (dy, x, k_scale[0]) if k_scale is not None else (dy, x), grp)
             WGRAD.queued -= nj - 1                     # statistics count products, not per-sample jobs
             return (out, db) if with_colsum else out
+    if grp is not None:
+        WGRAD.abort(grp)
     out = ZEROS.zeros((N, K), dy.device)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     kw = dict(dtype=_code(dy.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=PLAIN_COL, M=N, N=K, K=Mr,
@@ -931,9 +985,15 @@ class _Conv2d(torch.autograd.Function):
             # 3 x 3 layers the LDS-tiled weight-gradient kernel does not serve (128 output channels): in-place gather on the grouped launch
             if (KH, KW, stride, pad) == (3, 3, 1, 1) and dy.dtype == torch.bfloat16 and _lib.lib().du_conv3x3_wgrad_halo_blocks(
                     C1, C1 + (x2.shape[-1] if x2 is not None else 0), Cout, B, Hi, Wi) <= 0 and _pow2(Hi) and _pow2(Wi) and \
-                    (_WGRAD_COLSUM or not want_db) and WGRAD.can_defer(ctx.wrefs):
-                srcs = [(x, _nhwc(x)[4], C1)] + ([(x2, _nhwc(x2)[4], x2.shape[-1])] if x2 is not None else [])
-                r = _queue_conv_wgrad(3, dy, lddy, srcs, B, Hi, Wi, Cout, tuple(w.shape), want_db)
+                    (_WGRAD_COLSUM or not want_db):
+                grp = WGRAD.begin(ctx.wrefs)
+                if grp is not None:
+                    srcs = [(x, _nhwc(x)[4], C1)] + ([(x2, _nhwc(x2)[4], x2.shape[-1])] if x2 is not None else [])
+                    r = _queue_conv_wgrad(grp, 3, dy, lddy, srcs, B, Hi, Wi, Cout, tuple(w.shape), want_db)
+                    if r is None:
+                        WGRAD.abort(grp)
+                    elif not grp["ret"]:
+                        r = (None, None)
             if r is not None:
                 dw, db = r
             else:
@@ -1009,10 +1069,13 @@ class _Linear(torch.autograd.Function):
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
+            grp = WGRAD.begin(ctx.wrefs)
             if want_db:
-                dw, db = mm_wgrad(dyc, x, with_colsum=True, k_scale=ks, defer=WGRAD.can_defer(ctx.wrefs))
+                dw, db = mm_wgrad(dyc, x, with_colsum=True, k_scale=ks, defer=grp)
             else:
-                dw = mm_wgrad(dyc, x, k_scale=ks, defer=WGRAD.can_defer(ctx.wrefs))
+                dw = mm_wgrad(dyc, x, k_scale=ks, defer=grp)
+            if grp is not None and not grp["ret"]:     # a later use of the same weight in this pass: added into the first one's result
+                dw = db = None
         elif want_db:
             dys = dyc if ks is None else (dyc.view(row_scale.numel(), ctx.rs_rows, -1) * row_scale.view(-1, 1, 1).to(dyc.dtype)).view(dyc.shape)
             db = colsum(dys)
@@ -1065,11 +1128,14 @@ class _LinearCat(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = mm(dyc, ctx.wT) if ctx.wT is not None else mm_dgrad(dyc, wq)
         db1 = db2 = None
+        grp = WGRAD.begin(ctx.wrefs)
         if has_bias:
-            dw, db = mm_wgrad(dyc, x, with_colsum=True, defer=WGRAD.can_defer(ctx.wrefs))
+            dw, db = mm_wgrad(dyc, x, with_colsum=True, defer=grp)
             db1, db2 = db[:n1], db[n1:]
         else:
-            dw = mm_wgrad(dyc, x, defer=WGRAD.can_defer(ctx.wrefs))
+            dw = mm_wgrad(dyc, x, defer=grp)
+        if grp is not None and not grp["ret"]:
+            return dx, None, None, None, None, None
         return dx, dw[:n1].view(s1), dw[n1:].view(s2), db1, db2, None
 
 
@@ -1127,6 +1193,8 @@ class _FAPMProject(torch.autograd.Function):
         if _DGRAD_NT and ws.dtype != dt and (2 * R) % 64 == 0:
             ctx.wqT = PACK.get((ws.reshape(R, -1), wp.reshape(R, -1)), PK_TRANSPOSE, dt)
             ctx.wfT = PACK.get(wf.reshape(2 * R, -1), PK_TRANSPOSE, dt)
+        ctx.wrefs = (WGRAD.note_use(*([ws] if bs is None else [ws, bs])), WGRAD.note_use(*([wp] if bp is None else [wp, bp])),
+                     WGRAD.note_use(*([wf] if bf is None else [wf, bf])))
         z2 = mm(xm, wq, bias=bq)
         gb = mm(z2[:, :R], wfq, bias=_f32(bf))
         z = torch.empty((rows, R), dtype=dt, device=x.device)
@@ -1149,20 +1217,36 @@ class _FAPMProject(torch.autograd.Function):
             mm(dgb, ctx.wfT, out=dz2[:, :R])
         else:
             mm_dgrad(dgb, wfq, out=dz2[:, :R])
+        # weight gradients: queued (WgradQueue) in three groups -- the shared basis (used by all four scales, dinounet_training.py:423: its
+        # contributions add into one buffer), this scale's basis, the film generator
+        g_s, g_p, g_f = (WGRAD.begin(r) for r in ctx.wrefs)
         if has_bf:
-            dwf, dbf = mm_wgrad(dgb, z2[:, :R], with_colsum=True)
+            dwf, dbf = mm_wgrad(dgb, z2[:, :R], with_colsum=True, defer=g_f if g_f is not None else False)
         else:
-            dwf, dbf = mm_wgrad(dgb, z2[:, :R]), None
+            dwf, dbf = mm_wgrad(dgb, z2[:, :R], defer=g_f if g_f is not None else False), None
+        if g_f is not None and not g_f["ret"]:
+            dwf = dbf = None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = (mm(dz2, ctx.wqT) if ctx.wqT is not None else mm_dgrad(dz2, wq)).view(B, H, W, Cc)
         dbs = dbp = None
-        if has_b:
-            dw, db = mm_wgrad(dz2, xm, with_colsum=True)
-            dbs, dbp = db[:R], db[R:]
+        if g_s is None and g_p is None:
+            if has_b:
+                dw, db = mm_wgrad(dz2, xm, with_colsum=True)
+                dbs, dbp = db[:R], db[R:]
+            else:
+                dw = mm_wgrad(dz2, xm)
+            dws, dwp = dw[:R], dw[R:]
         else:
-            dw = mm_wgrad(dz2, xm)
-        return dx, dw[:R].view(s_ws), dw[R:].view(s_wp), dbs, dbp, dwf.view(s_wf), dbf
+            rs = mm_wgrad(dz2[:, :R], xm, with_colsum=has_b, defer=g_s if g_s is not None else False)
+            rp = mm_wgrad(dz2[:, R:], xm, with_colsum=has_b, defer=g_p if g_p is not None else False)
+            (dws, dbs), (dwp, dbp) = (rs, rp) if has_b else ((rs, None), (rp, None))
+            if g_s is not None and not g_s["ret"]:
+                dws = dbs = None
+            if g_p is not None and not g_p["ret"]:
+                dwp = dbp = None
+        return (dx, None if dws is None else dws.view(s_ws), None if dwp is None else dwp.view(s_wp), dbs, dbp,
+                None if dwf is None else dwf.view(s_wf), dbf)
 
 
 def fapm_project(x, ws, wp, bs, bp, wf, bf):
@@ -1227,10 +1311,16 @@ class _ConvT2x2(torch.autograd.Function):
                      ldc=Cin, geom=g)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         queued = None
-        if ctx.needs_input_grad[1] and dy.dtype == torch.bfloat16 and _pow2(W) and (_WGRAD_COLSUM or not want_db) and \
-                x.is_contiguous() and WGRAD.can_defer(ctx.wrefs):
-            # grouped launch, dy gathered in place, result written in the parameter's (Cin, Cout, 2, 2) layout
-            queued = _queue_conv_wgrad(2, x, ld, [(dy, lddy, Cout)], B, H, W, Cin, tuple(w.shape), want_db)
+        if ctx.needs_input_grad[1] and dy.dtype == torch.bfloat16 and _pow2(W) and (_WGRAD_COLSUM or not want_db):
+            # grouped launch, dy gathered in place, result written in the parameter's (Cin, Cout, 2, 2) layout; the same ConvTranspose
+            # applied twice in a forward (LearnableUpsampleBlock's loop, dinounet_training.py:259-261) adds into one buffer
+            grp = WGRAD.begin(ctx.wrefs)
+            if grp is not None:
+                queued = _queue_conv_wgrad(grp, 2, x, ld, [(dy, lddy, Cout)], B, H, W, Cin, tuple(w.shape), want_db)
+                if queued is None:
+                    WGRAD.abort(grp)
+                elif not grp["ret"]:
+                    queued = (None, None)
         if queued is not None:
             dw, db = queued
             want_db = False

@@ -75,6 +75,7 @@ class TrainStep:
         self.use_graph = graph
         self.warmup = warmup
         self._n = 0
+        self.comm_events = None          # list -> eager steps record (start, end) events around reducer.finish()
 
     def _step(self):
         self.opt.zero_grad(set_to_none=True)
@@ -85,7 +86,14 @@ class TrainStep:
             from . import ops
             ops.WGRAD.flush()          # deferred weight gradients (already flushed by the engine callback; idempotent)
         if self.reducer is not None:
-            self.reducer.finish()
+            if self.comm_events is not None:               # bench.py: how long the step waits for the gradient all-reduce after backward
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.reducer.finish()
+                e1.record()
+                self.comm_events.append((e0, e1))
+            else:
+                self.reducer.finish()
         if isinstance(self.opt, FusedClipSGD):              # clip + SGD in three launches (csrc/optim.hip)
             self.opt.max_norm = self.max_norm
             self.opt.step()

@@ -502,7 +502,8 @@ def test_bench_roofline_reads_pmc_summaries_only_for_matching_kernel_sources(mon
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     from dinounet_amd import _build
-    head = open(os.path.join(root, "profiles", "r02_pmc_fetch_size_eager.txt")).read().splitlines()[0]
+    newest = [f for f in (os.path.join(root, "profiles", f"{r}_pmc_fetch_size_eager.txt") for r in bench.PMC_ROUNDS) if os.path.exists(f)][0]
+    head = open(newest).read().splitlines()[0]
     recorded = re.match(r"# csrc-digest ([0-9a-f]{64})", head).group(1)
     kernel = "gemm_nt_p8n_kernel<bf16,linear>"
 
