@@ -36,6 +36,7 @@
 // 4 consecutive columns per register quad, so the epilogue stages 8-byte (bf16, after bias / activation / LayerScale in registers)
 // or 16-byte (fp32) pieces into a row-major LDS tile and writes whole 512-byte output rows (a lane-per-row store would touch 32
 // cache lines per instruction).
+#include <algorithm>
 #include <vector>
 #include "common.h"
 #include "gemm_params.h"
@@ -1307,12 +1308,13 @@ static int tn_group_launch(const du_tn_job* const* jobs, int njobs, hipStream_t 
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS) != hipSuccess) return DU_ERR_LAUNCH;
     attr_set[g_p8_sched ? 1 : 0] = true;
   }
+  static const int max_jobs = getenv("DU_TN_GROUP_MAXJOBS") ? std::max(1, std::min(TN_GROUP_MAX, atoi(getenv("DU_TN_GROUP_MAXJOBS")))) : TN_GROUP_MAX;
   int i0 = 0;
   while (i0 < njobs) {
     // one launch: consecutive jobs while their tiles fit one round of workgroups
     int tiles[TN_GROUP_MAX], pairs[TN_GROUP_MAX], splits[TN_GROUP_MAX];
     int n = 0, units = 0;
-    while (i0 + n < njobs && n < TN_GROUP_MAX) {
+    while (i0 + n < njobs && n < max_jobs) {
       const du_tn_job& j = *jobs[i0 + n];
       const int t = ((j.M + PBM - 1) / PBM) * ((j.N + PBN - 1) / PBN);
       if (n > 0 && units + t > target_units) break;

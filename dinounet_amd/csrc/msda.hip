@@ -12,6 +12,7 @@
 // here the D-reduction of grad_loc / grad_attn is an in-wave xor-shuffle tree and several (q, head) pairs share a wave.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -502,11 +503,235 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// bf16 fast path (round 3): D % 8 == 0 with D / 8 in {4, 8, 16} (dinounet_l: 32 channels per head; the 7B adapter: 128), 4 points.
+//
+// The kernels above were VALU-bound (SQ counters: VALU issue 0.92 / 0.89 of the launch): every one of the D / 4 lanes of a (query, head)
+// pair recomputed the bilinear setup of all 4 points (floor, 4 weights, 4 range tests, 4 corner offsets through 64-bit multiplies) and
+// gathered 8 bytes per corner.  Here
+//   * a pair is served by LPP = D / 8 lanes (16-byte gathers: half the gather instructions),
+//   * lane (l & 3) of every quad sets up ONE of the 4 points and the others fetch its 4 corner offsets / coefficients with
+//     v_mov_b32_dpp quad_perm broadcasts (one full-rate VALU op each; the LPP >= 4 lanes of a pair are whole quads),
+//   * offsets are 32-bit BYTE offsets into one buffer descriptor over `value` (the product pixel * (M * D * 2) is a 24-bit multiply done
+//     once in the setup lane), so a gather costs one v_add + one buffer_load_dwordx4,
+//   * corners outside the level are gathered from offset 0 with zero coefficients (no branches: all 16 gathers of a pair in flight).
+// The backward variant adds the three per-point reductions (grad_attn, grad_loc x / y) over the channels: 8 FMAs per corner into one
+// dot product with this lane's grad_out slice, three scalar FMAs with the corner's coefficients, quad butterflies (DPP) at the end.
+// ------------------------------------------------------------------------------------------------------
+template <int P_> __device__ __forceinline__ int quad_bcast(int v) {
+  return __builtin_amdgcn_mov_dpp(v, P_ | (P_ << 2) | (P_ << 4) | (P_ << 6), 0xf, 0xf, true);
+}
+template <int P_> __device__ __forceinline__ float quad_bcastf(float v) { return __builtin_bit_cast(float, quad_bcast<P_>(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)); }   // quad_perm [2,3,0,1]
+
+struct PointSetup { int off[4]; float cw[4]; float lh, lw; bool in; bool ok[4]; };
+// this lane's point: pixel coordinates -> 4 corner byte offsets (pixel * pix_bytes, 0 when the corner is outside) and bilinear weights (0 outside)
+__device__ __forceinline__ PointSetup point_setup(float lx, float ly, int H, int W, unsigned pix_bytes) {
+  PointSetup s;
+  float h = ly * H - 0.5f, w = lx * W - 0.5f;
+  s.in = h > -1.f && w > -1.f && h < (float)H && w < (float)W;
+  h = s.in ? h : 0.f; w = s.in ? w : 0.f;
+  const float hf = floorf(h), wf = floorf(w);
+  const int h0 = (int)hf, w0 = (int)wf;
+  s.lh = h - hf; s.lw = w - wf;
+  const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+  const bool okh0 = s.in && h0 >= 0, okh1 = s.in && h0 + 1 <= H - 1, okw0 = w0 >= 0, okw1 = w0 + 1 <= W - 1;
+  const bool ok[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
+#pragma unroll
+  for (int k = 0; k < 4; k++) s.ok[k] = ok[k];
+  const int pix[4] = {h0 * W + w0, h0 * W + w0 + 1, (h0 + 1) * W + w0, (h0 + 1) * W + w0 + 1};
+  const float wt[4] = {hh * hw, hh * s.lw, s.lh * hw, s.lh * s.lw};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    s.off[k] = ok[k] ? (int)__umul24((unsigned)pix[k], pix_bytes) : 0;
+    s.cw[k] = ok[k] ? wt[k] : 0.f;
+  }
+  return s;
+}
+__device__ __forceinline__ void bf16x8_to_f32(const uint4& u, float* f) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    f[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+    f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+  }
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256) void msda_fwd_q8_kernel(const bf16_t* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                          const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+                                                          const float* __restrict__ attn, bf16_t* __restrict__ out, int N, int S, int M,
+                                                          int D, int L, int Lq, long npairs) {
+  constexpr int GPW = 256 / LPP;
+  const int tid = threadIdx.x;
+  const int sub = tid % LPP, pt = tid & 3;
+  const unsigned pix_bytes = (unsigned)(M * D * 2);
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)value, 0, (int)((long)N * S * M * D * 2), 0x00020000);
+  const long rounds = (npairs + (long)gridDim.x * GPW - 1) / ((long)gridDim.x * GPW);
+  for (long it = 0; it < rounds; it++) {
+    const long pair = (it * gridDim.x + blockIdx.x) * GPW + tid / LPP;
+    const bool live = pair < npairs;
+    const long pr = live ? pair : npairs - 1;             // (whole quads stay active for the DPP exchanges)
+    const int m = (int)(pr % M);
+    const int b = (int)(pr / ((long)M * Lq));
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.f;
+    for (int l = 0; l < L; l++) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const float2 lxy = *(const float2*)(loc + ((pr * L + l) * 4 + pt) * 2);
+      const float a = attn[(pr * L + l) * 4 + pt];
+      PointSetup ps = point_setup(lxy.x, lxy.y, H, W, pix_bytes);
+      float ca[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) ca[k] = ps.cw[k] * a;
+      const unsigned base = (unsigned)(((b * S + (int)lsi[l]) * M + m) * D + sub * 8) * 2u;
+      // two batches of 8 gathers (two points each): 32 registers of loads in flight per wave, 4-5 waves per SIMD
+      auto two_points = [&](auto p_c) {
+        constexpr int p = decltype(p_c)::value;
+        uint4 v[8];
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          f[k] = quad_bcastf<p>(ca[k]);
+          v[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)quad_bcast<p>(ps.off[k]), 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          f[4 + k] = quad_bcastf<p + 1>(ca[k]);
+          v[4 + k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + (unsigned)quad_bcast<p + 1>(ps.off[k]), 0, 0));
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          float x[8];
+          bf16x8_to_f32(v[c], x);
+#pragma unroll
+          for (int j = 0; j < 8; j++) acc[j] = fmaf(f[c], x[j], acc[j]);
+        }
+      };
+      two_points(std::integral_constant<int, 0>{});
+      two_points(std::integral_constant<int, 2>{});
+    }
+    if (live) {
+      bf16x8 o8;
+#pragma unroll
+      for (int j = 0; j < 8; j++) o8[j] = (bf16_t)acc[j];
+      *(uint4*)(out + pr * (long)D + sub * 8) = __builtin_bit_cast(uint4, o8);
+    }
+  }
+}
+
+// gather-only backward (grad_sampling_loc, grad_attn_weight): same lane assignment; lane (l & 3) of the pair's FIRST quad writes point (l & 3)
+template <int LPP>
+__global__ __launch_bounds__(256) void msda_bwd_q8_kernel(const bf16_t* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                          const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+                                                          const float* __restrict__ attn, const bf16_t* __restrict__ gout,
+                                                          float* __restrict__ gloc, float* __restrict__ gattn, int N, int S, int M, int D,
+                                                          int L, int Lq, long npairs) {
+  constexpr int GPW = 256 / LPP;
+  const int tid = threadIdx.x;
+  const int sub = tid % LPP, pt = tid & 3;
+  const unsigned pix_bytes = (unsigned)(M * D * 2);
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)value, 0, (int)((long)N * S * M * D * 2), 0x00020000);
+  const long rounds = (npairs + (long)gridDim.x * GPW - 1) / ((long)gridDim.x * GPW);
+  for (long it = 0; it < rounds; it++) {
+    const long pair = (it * gridDim.x + blockIdx.x) * GPW + tid / LPP;
+    const bool live = pair < npairs;
+    const long pr = live ? pair : npairs - 1;
+    const int m = (int)(pr % M);
+    const int b = (int)(pr / ((long)M * Lq));
+    float tg[8];
+    bf16x8_to_f32(*(const uint4*)(gout + pr * (long)D + sub * 8), tg);
+    for (int l = 0; l < L; l++) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const float2 lxy = *(const float2*)(loc + ((pr * L + l) * 4 + pt) * 2);
+      const float a = attn[(pr * L + l) * 4 + pt];
+      PointSetup ps = point_setup(lxy.x, lxy.y, H, W, pix_bytes);
+      // d(val)/dh and d(val)/dw corner coefficients (cuh:122-158), scaled by H * a / W * a like the reference's grad_loc; zero outside
+      const float hh = 1.f - ps.lh, hw = 1.f - ps.lw;
+      const float dh0[4] = {-hw, -ps.lw, hw, ps.lw}, dw0[4] = {-hh, hh, -ps.lh, ps.lh};
+      float dh[4], dw[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        dh[k] = ps.ok[k] ? dh0[k] * ((float)H * a) : 0.f;
+        dw[k] = ps.ok[k] ? dw0[k] * ((float)W * a) : 0.f;
+      }
+      const unsigned base = (unsigned)(((b * S + (int)lsi[l]) * M + m) * D + sub * 8) * 2u;
+      float ga[4], gx[4], gy[4];
+      auto point = [&](auto p_c) {
+        constexpr int p = decltype(p_c)::value;
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned o = base + (unsigned)quad_bcast<p>(ps.off[k]);
+          v[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0));
+        }
+        float sa = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          float x[8];
+          bf16x8_to_f32(v[k], x);
+          float t = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; j++) t = fmaf(tg[j], x[j], t);
+          sa = fmaf(quad_bcastf<p>(ps.cw[k]), t, sa);
+          sx = fmaf(quad_bcastf<p>(dw[k]), t, sx);
+          sy = fmaf(quad_bcastf<p>(dh[k]), t, sy);
+        }
+        ga[p] = sa; gx[p] = sx; gy[p] = sy;
+      };
+      point(std::integral_constant<int, 0>{}); point(std::integral_constant<int, 1>{});
+      point(std::integral_constant<int, 2>{}); point(std::integral_constant<int, 3>{});
+      // sum over the LPP lanes of the pair: inside the quad by DPP, across the pair's quads by shuffles
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        ga[p] += quad_xor1(ga[p]); gx[p] += quad_xor1(gx[p]); gy[p] += quad_xor1(gy[p]);
+        ga[p] += quad_xor2(ga[p]); gx[p] += quad_xor2(gx[p]); gy[p] += quad_xor2(gy[p]);
+#pragma unroll
+        for (int o = 4; o < LPP; o <<= 1) {
+          ga[p] += __shfl_xor(ga[p], o, 64); gx[p] += __shfl_xor(gx[p], o, 64); gy[p] += __shfl_xor(gy[p], o, 64);
+        }
+      }
+      const float oa = pt == 0 ? ga[0] : pt == 1 ? ga[1] : pt == 2 ? ga[2] : ga[3];
+      const float ox = pt == 0 ? gx[0] : pt == 1 ? gx[1] : pt == 2 ? gx[2] : gx[3];
+      const float oy = pt == 0 ? gy[0] : pt == 1 ? gy[1] : pt == 2 ? gy[2] : gy[3];
+      if (live && sub < 4) {
+        const long e = (pr * L + l) * 4 + pt;
+        gattn[e] = oa;
+        *(float2*)(gloc + e * 2) = make_float2(ox, oy);
+      }
+    }
+  }
+}
+
 int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+// the round-3 fast kernels serve: bf16, 4 points, D / 8 in {4, 8, 16}, value < 2 GB (32-bit byte offsets), < 2^24 pixels and row bytes
+static bool q8_serves(int N, int S, int M, int D, int P) {
+  static const bool off = getenv("DU_MSDA_NO_Q8") != nullptr;      // debugging / A-B aid
+  if (off || P != 4 || D % 8) return false;
+  const int lpp = D / 8;
+  if (lpp != 4 && lpp != 8 && lpp != 16) return false;
+  return (long)N * S * M * D * 2 < 0x7fffffffL && (long)N * S < (1L << 24) && (long)M * D * 2 < (1L << 24);
+}
 
 template <typename T>
 int fwd_dispatch(const void* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn, void* out,
                  int N, int S, int M, int D, int L, int Lq, int P, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if (q8_serves(N, S, M, D, P)) {
+      const int lpp = D / 8;
+      const long npairs = (long)N * Lq * M;
+      const long gpw = 256 / lpp;
+      long blocks = (npairs + gpw - 1) / gpw;
+      if (blocks > 256 * 32) blocks = 256 * 32;
+#define MSDA_FWD_Q8(LPP_) hipLaunchKernelGGL((msda_fwd_q8_kernel<LPP_>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)value, shapes, lsi, loc, attn, (bf16_t*)out, N, S, M, D, L, Lq, npairs)
+      if (lpp == 4) MSDA_FWD_Q8(4); else if (lpp == 8) MSDA_FWD_Q8(8); else MSDA_FWD_Q8(16);
+#undef MSDA_FWD_Q8
+      return du_check_launch();
+    }
+  }
   if (D % 4 == 0) {
     long total = (long)N * Lq * M * (D / 4);
     int grid = (int)((total + 255) / 256 > 65535 * 4 ? 65535 * 4 : (total + 255) / 256);
@@ -550,6 +775,14 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
   if constexpr (sizeof(T) == 2) {
     if (!no_mfma && L == 1 && P == 4 && D <= 32 && LP <= 4) {
       // (1) gather-only pass: grad_sampling_loc / grad_attn_weight (no atomics)
+      if (q8_serves(N, S, M, D, P)) {
+        const long gpw8 = 256 / (D / 8);
+        long b8 = (npairs + gpw8 - 1) / gpw8;
+        if (b8 > 256 * 32) b8 = 256 * 32;
+#define MSDA_BWD_Q8(LPP_) hipLaunchKernelGGL((msda_bwd_q8_kernel<LPP_>), dim3((unsigned)b8), dim3(256), 0, st, (const bf16_t*)value, shapes, lsi, loc, attn, (const bf16_t*)gout, gl, ga, N, S, M, D, L, Lq, npairs)
+        if (D == 32) MSDA_BWD_Q8(4); else if (D == 64) MSDA_BWD_Q8(8); else MSDA_BWD_Q8(16);
+#undef MSDA_BWD_Q8
+      } else
       hipLaunchKernelGGL((msda_bwd_kernel<T, CPT, 4, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value, shapes, lsi, loc, attn,
                          (const T*)gout, gv, gl, ga, N, S, M, D, L, Lq, P, LPP, npairs);
       // (2) grad_value on the MFMA pipe

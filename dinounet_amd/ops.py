@@ -606,7 +606,9 @@ class WgradQueue:
         t = grp["bufs"].get(name)
         if t is None:
             t = grp["bufs"][name] = ZEROS.zeros(shape, device)
-        return t
+        # a fresh alias, never the object kept in the group: AccumulateGrad adopts an incoming gradient by reference only when nobody
+        # else holds that tensor object (use_count), otherwise it CLONES it on the spot -- i.e. copies the still-unfinished buffer
+        return t.view(t.shape)
 
     def legal(self, job):
         return bool(_lib.lib().du_gemm_tn_group_legal(C.byref(job)))

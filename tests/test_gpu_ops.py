@@ -275,7 +275,7 @@ def test_deferred_weight_gradients_match_immediate_ones_through_autograd():
         if pre is not None:
             pre()
         dc_and_ce_loss(net(x), t).backward()
-        assert not W.jobs and not W.keep and not W._armed and not W.seen
+        assert not W.jobs and not W.keep and not W._armed and not W.state and not W.groups
         torch.cuda.synchronize()
         return {k: p.grad.detach().float().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}, W.queued - q0, W.launches - l0
 
@@ -311,7 +311,7 @@ def test_deferred_weight_gradients_match_immediate_ones_through_autograd():
         # one is handed to the engine (which then adds the two buffers)
         net.zero_grad(set_to_none=True)
         (dc_and_ce_loss(net(x), t) + dc_and_ce_loss(net(x), t)).backward()
-        assert not W.jobs and not W.seen
+        assert not W.jobs and not W.state
         torch.cuda.synchronize()
         for k, p in net.named_parameters():
             if p.grad is not None:
