@@ -39,7 +39,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
   constexpr int CV = CK / 8;                            // 16-byte vectors per pixel per chunk
   constexpr int HV = (HW_ * CV + 255) / 256;            // halo vectors per thread
   constexpr int WV = (9 * COUT * CV + 255) / 256;       // weight vectors per thread
-  constexpr int W_EL = 9 * COUT * LD, H_EL = HW_ * LD;
+  // halo image: pixel pitch LD (144 / 80 bytes: the 16 pixels of a row land on 16 different 16-byte bank groups), ROW pitch padded to a
+  // multiple of 256 bytes -- the A-fragment ds_read_b128 serves lanes {0-3, 12-15} of one image row together with lanes {20-27} of the
+  // NEXT row in one LDS cycle; with the natural pitch (18 pixels) the second row started on another bank phase and collided with the
+  // first (SQ_LDS_BANK_CONFLICT 22-35 % of the LDS cycles, profiles/r02_pmc_sq_cycles_eager.txt)
+  constexpr int HROW = ((HXW * LD * 2 + 255) / 256 * 256) / 2;
+  constexpr int W_EL = 9 * COUT * LD, H_EL = (TH + 2) * HROW;
   constexpr int STG_LD = COUT + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Ws = (bf16_t*)smem_raw;                       // [9][COUT][LD]
@@ -77,7 +82,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
 #pragma unroll
     for (int i = 0; i < HV; i++) {
       const int v = tid + i * 256;
-      if (v < HW_ * CV) *(uint4*)(Hs + (v / CV) * LD + (v % CV) * 8) = hreg[i];
+      if (v < HW_ * CV) {
+        const int pix = v / CV;
+        *(uint4*)(Hs + (pix / HXW) * HROW + (pix % HXW) * LD + (v % CV) * 8) = hreg[i];
+      }
     }
   };
   auto w_load = [&](int ch) {
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
 #pragma unroll
       for (int tap = 0; tap < 9; tap++) {
         const int dy = tap / 3, dx = tap % 3;
-        const bf16_t* arow = Hs + ((py + dy) * HXW + px + dx) * LD + half * 8;
+        const bf16_t* arow = Hs + (py + dy) * HROW + (px + dx) * LD + half * 8;
         const bf16_t* brow = Ws + (tap * COUT + (lane & 31)) * LD + half * 8;
 #pragma unroll
         for (int kk = 0; kk < CK / 16; kk++) {
@@ -211,8 +219,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
 template <int CK, int TN>
 int launch(const HaloParams& P, hipStream_t st) {
   constexpr int COUT = TN * 32, LD = CK + 8;
+  constexpr int HROW = ((HXW * LD * 2 + 255) / 256 * 256) / 2;
   const int nch = P.Cin / CK;
-  const size_t main_bytes = (size_t)(9 * COUT * LD + HW_ * LD) * 2;
+  const size_t main_bytes = (size_t)(9 * COUT * LD + (TH + 2) * HROW) * 2;
   const size_t stg_bytes = (size_t)128 * (COUT + 4) * 4 + (size_t)4 * COUT * 2 * 4;   // fp32 tile + statistics scratch [4][COUT][2]
   const size_t lds = nch == 1 ? main_bytes + stg_bytes : (main_bytes > stg_bytes ? main_bytes : stg_bytes);
   if (lds > 160 * 1024) return DU_ERR_UNSUPPORTED;
