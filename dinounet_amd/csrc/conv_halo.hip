@@ -12,6 +12,7 @@
 // following norm layer) fall out of the same staged tile and are written as partials (no second pass over the output).
 //
 // Roofline: HBM for Cout <= 64 at 256^2 / 512^2 (algorithmic bytes = (Cin + Cout) * 2 per pixel), MFMA for the 128-channel layers.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -251,10 +252,11 @@ extern "C" int du_conv3x3_halo(const void* x, int64_t ldx, const void* x2, int64
   P.B = B; P.H = H; P.W = W; P.w = (const bf16_t*)w; P.bias = bias; P.y = (bf16_t*)y; P.ldy = ldy; P.stats_part = stats_part;
   P.tilesX = W / TW; P.tilesY = H / TH; P.ntiles = B * P.tilesX * P.tilesY;
   // channel chunk: 64 when both sources split on 64-channel boundaries, else 32
+  static const bool ck32 = getenv("DU_HALO_CK32") != nullptr;     // A-B aid: 32-channel chunks for the 64-output layers too (2 workgroups / CU)
   const bool c64 = Cin % 64 == 0 && C1 % 64 == 0;
   const bool c32 = Cin % 32 == 0 && C1 % 32 == 0;
   if (Cout == 32) { if (c64) return launch<64, 1>(P, st); if (c32) return launch<32, 1>(P, st); }
-  if (Cout == 64) { if (c64) return launch<64, 2>(P, st); if (c32) return launch<32, 2>(P, st); }
+  if (Cout == 64) { if (c64 && !ck32) return launch<64, 2>(P, st); if (c32) return launch<32, 2>(P, st); }
   if (Cout == 128) { if (c32) return launch<32, 4>(P, st); }
   return DU_ERR_UNSUPPORTED;
 }
@@ -458,7 +460,11 @@ extern "C" int du_conv3x3_wgrad_halo_blocks(int C1, int Cin, int Cout, int B, in
   if (!(Cout == 32 || Cout == 64) || Cin % 32 || C1 % 32) return 0;   // 128 output channels: 9 accumulator tiles per wave spill
   if ((long)Cout * 9 * Cin > 80L * 1024) return 0;                 // larger filters: MFMA-bound anyway, partial slabs too big
   const int ntiles = B * (H / TH) * (W / TW);
-  return ntiles < 256 ? ntiles : 256;
+  // persistent workgroups = partial dW slabs.  36-50 KB of LDS and 4 waves each: one per CU leaves every SIMD with a single wave and
+  // nothing to switch to while it waits for its LDS writes / barrier / transpose reads (1.4 TB/s measured); two per CU double the
+  // slab traffic of the finalize (<= 2 x 75 MB) and hide that latency.  DU_HALO_WGRAD_BLOCKS overrides (A-B aid).
+  static const int cap = getenv("DU_HALO_WGRAD_BLOCKS") ? atoi(getenv("DU_HALO_WGRAD_BLOCKS")) : 512;
+  return ntiles < cap ? ntiles : cap;
 }
 
 // x / x2 as in du_conv3x3_halo, dy (B,H,W,Cout) bf16; part: du_conv3x3_wgrad_halo_blocks(...) x Cout x 9*Cin fp32 scratch;

@@ -351,14 +351,19 @@ __global__ __launch_bounds__(1024) void msda_bwd_lds_kernel(const T* __restrict_
 
 // grad_value = sum over the query chunks of the partial planes
 __global__ __launch_bounds__(256) void msda_gv_finalize_kernel(const float* __restrict__ part, float* __restrict__ gvalue, int nchunk,
-                                                               long n4) {
+                                                               long n4, int out_bf16) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 a = ((const float4*)part)[i];
     for (int c = 1; c < nchunk; c++) {
       float4 t = ((const float4*)part)[i + (long)c * n4];
       a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
     }
-    ((float4*)gvalue)[i] = a;
+    if (out_bf16) {
+      bf16x4 o; o[0] = (bf16_t)a.x; o[1] = (bf16_t)a.y; o[2] = (bf16_t)a.z; o[3] = (bf16_t)a.w;
+      ((uint2*)gvalue)[i] = __builtin_bit_cast(uint2, o);
+    } else {
+      ((float4*)gvalue)[i] = a;
+    }
   }
 }
 
@@ -391,7 +396,7 @@ constexpr int GV_GLD = 128 + 8;
 __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __restrict__ gout, const int64_t* __restrict__ shapes,
                                                             const float* __restrict__ loc, const float* __restrict__ attn,
                                                             float* __restrict__ gvalue, int N, int S, int M, int D, int Lq,
-                                                            int q_per_chunk, int tiles, long chunk_stride) {
+                                                            int q_per_chunk, int tiles, long chunk_stride, int out_bf16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ unsigned step_mask[3];
   bf16_t* Wl = (bf16_t*)smem_raw;                       // [GV_PT][GV_WLD]
@@ -498,7 +503,11 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int pix = pix0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (pix < S) dst[((long)b * S + pix) * ((long)M * D) + (long)m * D + c] = acc[r];
+      const long e = ((long)b * S + pix) * ((long)M * D) + (long)m * D + c;
+      if (pix < S) {
+        if (out_bf16) ((bf16_t*)gvalue)[e] = (bf16_t)acc[r];       // (one query chunk: the result itself, in the activation dtype)
+        else dst[e] = acc[r];
+      }
     }
   }
 }
@@ -761,7 +770,7 @@ static void lds_chunking(int N, int M, int Lq, int LPP, int* nchunk_out, int* qp
 template <typename T, int CPT>
 int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn, const void* gout,
                float* gv, float* gl, float* ga, int N, int S, int M, int D, int L, int Lq, int P, float* ws, long ws_elems,
-               hipStream_t st) {
+               hipStream_t st, int gv_bf16 = 0) {
   const int chunks = (D + CPT - 1) / CPT;
   int LPP = next_pow2(chunks);
   if (LPP > 64) LPP = 64;
@@ -807,16 +816,17 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
           attr_set = true;
         }
         hipLaunchKernelGGL(msda_gv_mfma_kernel, dim3(nchunk, N * M * tiles), dim3(1024), lds_bytes, st, (const bf16_t*)gout, shapes, loc, attn,
-                           dstp, N, S, M, D, Lq, qpc, tiles, cstride);
+                           dstp, N, S, M, D, Lq, qpc, tiles, cstride, (gv_bf16 && nchunk == 1) ? 1 : 0);
         if (nchunk > 1) {
           const long n4 = plane_all / 4;
           long g = (n4 + 255) / 256; if (g > 4096) g = 4096;
-          hipLaunchKernelGGL(msda_gv_finalize_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)ws, gv, nchunk, n4);
+          hipLaunchKernelGGL(msda_gv_finalize_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)ws, gv, nchunk, n4, gv_bf16);
         }
         return du_check_launch();
       }
     }
   }
+  if (gv_bf16) return DU_ERR_UNSUPPORTED;                            // only the MFMA grad_value path above writes the activation dtype
   static const bool no_lds = getenv("DU_MSDA_NO_LDS") != nullptr;   // debugging aid: force the global-atomics kernel
   if (!no_lds && plane <= 144 * 1024 && LP <= 8 && LPP <= 64) {
     int nchunk, qpc;
@@ -837,7 +847,7 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
     if (part) {
       const long n4 = plane_all / 4;
       long g = (n4 + 255) / 256; if (g > 4096) g = 4096;
-      hipLaunchKernelGGL(msda_gv_finalize_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)part, gv, nchunk, n4);
+      hipLaunchKernelGGL(msda_gv_finalize_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)part, gv, nchunk, n4, 0);
     }
     return du_check_launch();
   }
@@ -892,4 +902,19 @@ extern "C" int du_msda_backward(int dtype, const void* value, const int64_t* sha
     return bwd_launch<bf16_t, 1>(value, shapes, lsi, loc, attn, gout, gv, gl, ga, N, S, M, D, L, Lq, P, ws, ws_elems, st);
   }
   return DU_ERR_BAD_ARG;
+}
+
+// The same with grad_value written in bf16 (the dtype of `value`: what the value projection's backward consumes) instead of fp32: saves
+// the cast pass.  Served on the MFMA grad_value path only (bf16, one level, 4 points, D <= 32); DU_ERR_UNSUPPORTED otherwise -- the caller
+// then uses du_msda_backward and casts.
+extern "C" int du_msda_backward_bf16gv(const void* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn,
+                                       const void* gout, void* gv_bf16, float* gl, float* ga, int N, int S, int M, int D, int L, int Lq,
+                                       int P, float* ws, int64_t ws_elems, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!value || !shapes || !lsi || !loc || !attn || !gout || !gv_bf16 || !gl || !ga || N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 ||
+      Lq <= 0 || P <= 0)
+    return DU_ERR_BAD_ARG;
+  static const bool no_mfma = getenv("DU_MSDA_NO_MFMA") != nullptr;
+  if (no_mfma || !(L == 1 && P == 4 && D <= 32 && D % 4 == 0)) return DU_ERR_UNSUPPORTED;
+  return bwd_launch<bf16_t, 4>(value, shapes, lsi, loc, attn, gout, (float*)gv_bf16, gl, ga, N, S, M, D, L, Lq, P, ws, ws_elems, st, 1);
 }

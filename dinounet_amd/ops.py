@@ -1607,15 +1607,25 @@ def msda_forward_raw(value, shapes, lsi, loc, attn):
     return out
 
 
-def msda_backward_raw(value, shapes, lsi, loc, attn, grad_out):
+def msda_backward_raw(value, shapes, lsi, loc, attn, grad_out, gv_like_value=False):
+    """-> (grad_value, grad_loc, grad_attn), fp32; gv_like_value: grad_value in value's dtype where the library can write it directly
+    (du_msda_backward_bf16gv: no cast pass), else fp32 cast here."""
     _req(value, shapes, lsi, loc, attn, grad_out)
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = loc.shape
-    gv = torch.empty((N, S, M, D), dtype=torch.float32, device=value.device)      # all three are fully written by the library
     gl = torch.empty(loc.shape, dtype=torch.float32, device=value.device)
     ga = torch.empty(attn.shape, dtype=torch.float32, device=value.device)
     n = int(_lib.lib().du_msda_bwd_ws_elems(N, S, M, D, L, Lq, P))
     ws = torch.empty(max(n, 1), dtype=torch.float32, device=value.device)
+    if gv_like_value and value.dtype == torch.bfloat16:
+        gvb = torch.empty((N, S, M, D), dtype=torch.bfloat16, device=value.device)
+        rc = _lib.lib().du_msda_backward_bf16gv(_p(value), _p(shapes), _p(lsi), _p(loc), _p(attn), _p(grad_out), _p(gvb), _p(gl), _p(ga),
+                                                N, S, M, D, L, Lq, P, _p(ws), n, _st())
+        if rc == 0:
+            return gvb, gl, ga
+        if rc != -2:
+            _lib.check(rc, "du_msda_backward_bf16gv")
+    gv = torch.empty((N, S, M, D), dtype=torch.float32, device=value.device)      # all three are fully written by the library
     _lib.check(_lib.lib().du_msda_backward(_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(attn), _p(grad_out), _p(gv),
                                            _p(gl), _p(ga), N, S, M, D, L, Lq, P, _p(ws), n, _st()), "du_msda_backward")
     return gv, gl, ga
@@ -1635,8 +1645,8 @@ class _MSDA(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         value, shapes, lsi, loc, attn = ctx.saved_tensors
-        gv, gl, ga = msda_backward_raw(value, shapes, lsi, loc, attn, go.contiguous())
-        return gv.to(value.dtype), None, None, gl, ga
+        gv, gl, ga = msda_backward_raw(value, shapes, lsi, loc, attn, go.contiguous(), gv_like_value=True)
+        return (gv if gv.dtype == value.dtype else gv.to(value.dtype)), None, None, gl, ga
 
 
 def msda(value, shapes, lsi, loc, attn):

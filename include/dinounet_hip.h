@@ -278,6 +278,13 @@ int du_msda_backward(int dtype, const void* value, const int64_t* spatial_shapes
                      float* grad_sampling_loc, float* grad_attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
                      float* ws, int64_t ws_elems, void* stream);
 
+/* The same with grad_value written in bf16 (value's dtype: what the value projection's backward reads) -- no cast pass afterwards.
+   bf16, one level, 4 points, D <= 32 only (the MFMA grad_value path); DU_ERR_UNSUPPORTED otherwise: use du_msda_backward and cast. */
+int du_msda_backward_bf16gv(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index, const float* sampling_loc,
+                            const float* attn_weight, const void* grad_out, void* grad_value_bf16, float* grad_sampling_loc,
+                            float* grad_attn_weight, int N, int S, int M, int D, int L, int Lq, int P, float* ws, int64_t ws_elems,
+                            void* stream);
+
 /* MSDeformAttn glue (ms_deform_attn.py:188-197, single level): raw (rows, M*P*2 + M*P) = [offsets | logits] from the
    fused sampling_offsets/attention_weights GEMM; ref (Lq, 2) reference points (x, y);
    loc (rows, M, P, 2) = ref + off / (Ws, Hs); attn (rows, M, P) = softmax over P. */
