@@ -463,7 +463,10 @@ extern "C" int du_conv3x3_wgrad_halo_blocks(int C1, int Cin, int Cout, int B, in
   // persistent workgroups = partial dW slabs.  36-50 KB of LDS and 4 waves each: one per CU leaves every SIMD with a single wave and
   // nothing to switch to while it waits for its LDS writes / barrier / transpose reads (1.4 TB/s measured); two per CU double the
   // slab traffic of the finalize (<= 2 x 75 MB) and hide that latency.  DU_HALO_WGRAD_BLOCKS overrides (A-B aid).
-  static const int cap = getenv("DU_HALO_WGRAD_BLOCKS") ? atoi(getenv("DU_HALO_WGRAD_BLOCKS")) : 512;
+  // measured (bench A-B, round 3): 512^2 64->32 257 -> 168 us, 32->32 138 -> 93 us with 512 workgroups; the 64-output layers at 256^2
+  // (147-295 KB slabs) lose 10 % to the doubled finalize traffic: two per CU only while a slab stays under 80 KB
+  static const int cap_env = getenv("DU_HALO_WGRAD_BLOCKS") ? atoi(getenv("DU_HALO_WGRAD_BLOCKS")) : 0;
+  const int cap = cap_env > 0 ? cap_env : ((long)Cout * 9 * Cin * 4 <= 80L * 1024 ? 512 : 256);
   return ntiles < cap ? ntiles : cap;
 }
 

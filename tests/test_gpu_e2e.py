@@ -438,3 +438,34 @@ def test_vit7b_width_block_vs_torch_fp32():
     e = max(rel(patch, rp), rel(cls, rc))
     print(f"[7B-width block bf16 vs torch fp32] rel err {e:.2e}")
     assert e < 4e-2
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_dinounet_7b_width_end_to_end_vs_reference(precision, monkeypatch):
+    """`DinoUNet('dinounet_7b')` end to end (hub/backbones.py:452-496 + the adapter / FAPM / decoder at D = 4096: MSDeformAttn head width 128,
+    ConvTranspose 4096 -> 4096, FAPM 4096 -> 256) against the reference's own module, backbone cut to depth 4 on both sides so the 0.9 G
+    synthetic parameters stay manageable (tests/golden/dinounet_7b_d4_64_eval.npz, oracle/make_golden_7b.py).  fp32 mode: the 1e-3 bar of
+    the other end-to-end cases; bf16 mode: the bf16 bounds."""
+    from dinounet_amd.dinov3 import vision_transformer as VT
+    from dinounet_amd.network_architecture import dinounet as DU
+    g, meta = _load("dinounet_7b_d4_64_eval")
+    monkeypatch.setitem(VT.VIT_CONFIGS, "dinounet_7b", dict(VT.VIT_CONFIGS["dinounet_7b"], depth=meta["depth"]))
+    monkeypatch.setitem(DU.DINOv3_INTERACTION_INDEXES, "dinounet_7b", list(meta["interaction_indexes"]))
+    net = DU.DinoUNet.from_config(PLANS_2D, 3, meta["num_classes"], dinov3_pretrained_path=None, dinov3_model_name="dinounet_7b",
+                                  precision=precision)
+    ks = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    assert len(ks) == meta["n_keys"]
+    net.load_state_dict(weights.make_state_dict(ks, seed=0), strict=True)
+    net = net.cuda().eval()
+    x = weights.make_input(meta["B"], meta["C"], meta["H"], meta["W"], seed=0).cuda()
+    with torch.no_grad():
+        y = net(x)
+    ref = torch.from_numpy(g["logits"])
+    e = rel(y, ref)
+    agree = float((y.float().cpu().argmax(1) == ref.argmax(1)).float().mean())
+    print(f"[dinounet_7b depth {meta['depth']} {precision}] logits rel err {e:.2e}, argmax agreement {agree:.4f}")
+    if precision == "fp32":
+        mism, bad = argmax_check(y, ref, 1e-3)
+        assert e < 1e-3 and bad == 0
+    else:
+        assert e < 0.15 and agree > 0.97
