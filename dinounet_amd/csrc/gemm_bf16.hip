@@ -436,7 +436,8 @@ int du_gemm_nt_glds(const du_gemm_args& a, hipStream_t st);   // gemm_glds.hip
 int du_gemm_skinny(const du_gemm_args& a, hipStream_t st);    // gemm_skinny.hip
 int64_t du_gemm_skinny_ws_elems(int N, int K);
 
-int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st);     // gemm_p8.hip
+int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st, int tail_rows = 0);     // gemm_p8.hip
+bool du_gemm_p8_tail_ok(const du_gemm_args& whole, int r);
 bool du_gemm_p8_wants(const du_gemm_args& a);
 int du_gemm_p8_choice(const du_gemm_args& a);
 bool du_gemm_glds_serves(const du_gemm_args& a);              // gemm_glds.hip
@@ -513,6 +514,11 @@ int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
       if (a.row_scale) tail.row_scale = a.row_scale + m0 / a.rs_rows;
       du_gemm_args head = a;
       head.M = (int)m0;
+      // round 3: where the head runs on a multi-phase kernel, the tail rides in the SAME launch (extra workgroups behind the tiles)
+      if (du_gemm_p8_wants(head) && du_gemm_p8_tail_ok(a, r)) {
+        const int rc_m = du_gemm_nt_p8(head, st, r);
+        if (rc_m != DU_ERR_UNSUPPORTED) return rc_m;
+      }
       // (forking the tail onto a side stream with event edges measured slower both times it was tried, inside the hipGraph: round 1 beside
       // the 128 x 128 kernels 191.6 vs 194.0 slices/s; round 2 beside the multi-phase kernels, 8 KB-LDS tail form, 33.9 vs 33.2 ms per step)
       int rc = nt_tiles(head, st);

@@ -40,6 +40,7 @@
 #include <vector>
 #include "common.h"
 #include "gemm_params.h"
+#include "gemm_skinny_body.h"
 
 namespace {
 
@@ -86,7 +87,7 @@ __device__ __forceinline__ void wait_vm_count(int n) {      // n = LDS-DMA instr
 // XCD-aware tile order shared by both kernels: an XCD owns a run of tiles; inside it bands of group_m tile rows are walked column
 // by column so the ~32 resident tiles of an XCD share few A / B panels through its L2.
 __device__ __forceinline__ void tile_coords(const GemmParams& P, int& tm, int& tn) {
-  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int nwg = P.main_wgs ? P.main_wgs : (int)gridDim.x, bid = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;     // bijective
   if (P.group_m > 1) {
@@ -325,6 +326,21 @@ constexpr int P8_LDS = 256 * P8_STG_LDB * 2;   // 135 168 B >= 2 * BUF_B and >= 
 
 // GA ("gather"): the ConvTranspose2d k2 s2 backward products read their im2col operand in place -- NT: A(m = input pixel, k = (tap, co)) =
 // dy[out pixel (2y + tap/2, 2x + tap%2)][co] (data gradient); TN: B(k = input pixel, n = (tap, co)) likewise (weight gradient).
+// The ragged tail of a tall product inside the tile kernel's own launch (du_gemm_bf16_fast: M = head + r, r <= 64 -- the ViT's 8 x 1029 =
+// 32 x 256 + 40 rows): workgroups behind the main tiles run the K-parallel skinny program on rows [P.M, P.M + tail_rows).  They are
+// dispatched when the first tiles retire and overlap the stragglers; as launches of their own the 40-row tails cost ~8 us each, 72 of
+// them per dinounet_l step (profiles/r02_launch_counts_v5.txt).
+template <typename TC>
+__device__ __forceinline__ void p8_tail(const GemmParams& P, unsigned char* smem) {
+  SkinnyEpi E;
+  E.C = (TC*)P.C + (long)P.M * P.ldc; E.ldc = P.ldc;
+  E.residual = P.residual ? (const void*)((const TC*)P.residual + (long)P.M * P.ldr) : nullptr; E.ldr = P.ldr;
+  E.bias = P.bias; E.gamma = P.gamma; E.row_scale = P.row_scale;
+  E.alpha = P.alpha; E.act = P.act; E.rs_rows = P.rs_rows; E.out_bf16 = sizeof(TC) == 2; E.row0 = P.M;
+  skinny_fused_body<8>((const bf16_t*)P.a.p + (long)P.M * P.a.ld, P.a.ld, (const bf16_t*)P.b.p, P.b.ld, P.tail_rows, P.N, P.K, E, (float*)smem,
+                       (int)blockIdx.x - P.main_wgs);
+}
+
 // workgroup -> XCD-contiguous linear index: the hardware places workgroup b on XCD b % 8; an XCD then owns a contiguous run of indices
 __device__ __forceinline__ int xcd_linear_index() {
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -826,6 +842,9 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
 template <typename TC, int SCHED, bool TN, bool GA>
 __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if constexpr (!TN && !GA) {
+    if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<TC>(P, smem); return; }
+  }
   p8_tile_body<TC, SCHED, TN, GA>(P, smem, TN ? xcd_linear_index() : 0);
 }
 
@@ -904,6 +923,7 @@ constexpr int P8N_LDS = 3 * NBUF_B;            // 147 456 B >= 256 * N_STG_LDF *
 template <typename TC, int SCHED>
 __global__ __launch_bounds__(512) void gemm_nt_p8n_kernel(GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<TC>(P, smem); return; }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -1110,7 +1130,7 @@ int g_p8_group = 4;
 int g_p8_debug = 0;      // bit 0: skip the bf16 global stores, bit 1: skip the whole epilogue (timing ablations only)
 
 template <typename TC, int SCHED, bool NARROW, bool GA = false>
-int launch_p8(const du_gemm_args& a, hipStream_t st) {
+int launch_p8(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
   static_assert(!(NARROW && GA), "the gather form exists for the 256 x 256 kernel only");
   constexpr int LDS_BYTES = NARROW ? P8N_LDS : P8_LDS;
   constexpr int TBN = NARROW ? NBN : PBN;
@@ -1119,6 +1139,10 @@ int launch_p8(const du_gemm_args& a, hipStream_t st) {
   P.group_m = g_p8_group;
   P.dbg = g_p8_debug;
   dim3 grid(P.tiles_m * P.tiles_n, a.batch < 1 ? 1 : a.batch);
+  if (tail_rows > 0 && !GA) {       // the ragged rows behind M ride along: one extra workgroup per 32 output columns
+    P.tail_rows = tail_rows; P.main_wgs = P.tiles_m * P.tiles_n;
+    grid.x += (a.N + SK_BN - 1) / SK_BN;
+  }
   void (*kfn)(GemmParams);
   if constexpr (NARROW) kfn = gemm_nt_p8n_kernel<TC, SCHED>; else kfn = gemm_nt_p8_kernel<TC, SCHED, false, GA>;
   static bool attr_set = false;
@@ -1226,19 +1250,32 @@ int du_gemm_p8_choice(const du_gemm_args& a) {
 bool du_gemm_p8_wants(const du_gemm_args& a) { return du_gemm_p8_choice(a) != 0; }
 
 // returns DU_ERR_UNSUPPORTED when these kernels cannot serve the product; the caller then uses gemm_glds.hip
-int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st) {
+// tail_rows > 0: rows [a.M, a.M + tail_rows) of the same operands / result are computed in the same launch (p8_tail); the caller has checked
+// du_gemm_p8_tail_ok
+int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st, int tail_rows) {
   int c = du_gemm_p8_choice(a);
   if (c == 0 && a.act == DU_ACT_SWIGLU && p8_legal(a)) c = 2;     // the gate epilogue exists only here: take the narrow tile when the
                                                                   // heuristic would have preferred another kernel family
   if (c == 0) return DU_ERR_UNSUPPORTED;
   if (a.a_mode == DU_IM2COL_ROW) return g_p8_sched ? launch_p8<bf16_t, 1, false, true>(a, st) : launch_p8<bf16_t, 0, false, true>(a, st);
   const bool bf = a.out_dtype == DU_BF16;
+  const int tr = tail_rows;
   if (c == 1) {
-    if (bf) return g_p8_sched ? launch_p8<bf16_t, 1, false>(a, st) : launch_p8<bf16_t, 0, false>(a, st);
-    return g_p8_sched ? launch_p8<float, 1, false>(a, st) : launch_p8<float, 0, false>(a, st);
+    if (bf) return g_p8_sched ? launch_p8<bf16_t, 1, false>(a, st, tr) : launch_p8<bf16_t, 0, false>(a, st, tr);
+    return g_p8_sched ? launch_p8<float, 1, false>(a, st, tr) : launch_p8<float, 0, false>(a, st, tr);
   }
-  if (bf) return g_p8_sched ? launch_p8<bf16_t, 1, true>(a, st) : launch_p8<bf16_t, 0, true>(a, st);
-  return g_p8_sched ? launch_p8<float, 1, true>(a, st) : launch_p8<float, 0, true>(a, st);
+  if (bf) return g_p8_sched ? launch_p8<bf16_t, 1, true>(a, st, tr) : launch_p8<bf16_t, 0, true>(a, st, tr);
+  return g_p8_sched ? launch_p8<float, 1, true>(a, st, tr) : launch_p8<float, 0, true>(a, st, tr);
+}
+
+// the ragged tail of `whole` (rows M - r .. M) may ride in the head's launch: the single-launch skinny form serves it (K <= 2048: longer
+// rows put every load of the tail on the same few memory channels, gemm_skinny.hip), plain store, no gate epilogue
+bool du_gemm_p8_tail_ok(const du_gemm_args& whole, int r) {
+  static const bool off = getenv("DU_P8_NO_TAIL") != nullptr;      // debugging / A-B aid
+  static const int kmax = getenv("DU_SKINNY_FUSE_KMAX") ? atoi(getenv("DU_SKINNY_FUSE_KMAX")) : 2048;
+  if (off || r < 1 || r > 64 || whole.K > kmax || whole.K % SK_CHUNK || whole.N % 4 || whole.batch > 1) return false;
+  if (whole.store_mode != DU_STORE_PLAIN || whole.act == DU_ACT_SWIGLU || whole.a_mode != DU_PLAIN_ROW || whole.b_mode != DU_PLAIN_ROW) return false;
+  return 8 * 64 * (SK_BN + 1) * 4 <= P8_LDS;
 }
 
 // Weight gradients on the multi-phase kernel: 0 = not served, else the number of K splits it would run with.  Only products the caller

@@ -28,6 +28,8 @@ struct GemmParams {
   float* b_colsum;        // ConvT weight gradient: b_colsum[n % b.C] += sum_k B(n, k) (bias gradient over the four taps); NULL = off
   const float* rope_sin; const float* rope_cos; int rope_prefix; float rope_qscale;     // DU_STORE_QKV_ROPE
   int k_scale;            // weight-gradient form (A contraction-major): row_scale[k / rs_rows] scales the CONTRACTION rows of A, not output rows
+  int tail_rows;          // gemm_p8.hip NT kernels: rows [M, M + tail_rows) (<= 64) are computed by the workgroups behind the first main_wgs
+  int main_wgs;           //   ones (skinny_fused_body, gemm_skinny_body.h); 0 = no tail in this launch
 };
 
 // element offset of C / residual element (m, n) for row stride ld: plain rows, or the pixel-shuffle store of ConvTranspose2d k2 s2

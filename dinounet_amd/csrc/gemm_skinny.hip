@@ -13,18 +13,9 @@
 //   (2) gemm_skinny_finish_kernel: sums the slices and applies the du_gemm epilogue (alpha, bias, act, gamma, row_scale, residual).
 // Scratch: du_gemm_ws_elems() floats lent by the caller (du_gemm_args.ws).
 #include "gemm_params.h"
+#include "gemm_skinny_body.h"
 
 namespace {
-
-// epilogue of the single-slice (fused) form, by value in constant memory: the kernel-argument copy of it
-struct SkinnyEpi {
-  void* C; long ldc; const void* residual; long ldr;
-  const float* bias; const float* gamma; const float* row_scale;
-  float alpha; int act, rs_rows, out_bf16;
-};
-
-constexpr int SK_BN = 32;          // output columns per workgroup
-constexpr int SK_CHUNK = 64;       // contraction elements per wave step (4 MFMAs)
 
 __global__ __launch_bounds__(256) void gemm_skinny_partial_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                                   long ldb, float* __restrict__ part, int M, int N, int K,
@@ -134,99 +125,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_fused_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                                     long ldb, int M, int N, int K, SkinnyEpi P) {
   extern __shared__ __attribute__((aligned(16))) float sk_red[];      // [NW][64][SK_BN + 1]
-  constexpr int SLOT = 64 * (SK_BN + 1);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * SK_BN;
-  const int nrb = (M + 31) >> 5;
-  const int kh = (lane >> 5) * 32;
-  const int n = n0 + (lane & 31);
-  const bf16_t* bp = B + (long)min(n, N - 1) * ldb + kh;
-  const bf16_t* ap0 = A + (long)min(lane & 31, M - 1) * lda + kh;
-  const bf16_t* ap1 = A + (long)min(32 + (lane & 31), M - 1) * lda + kh;
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  // workgroup j starts its walk over the K chunks at a different chunk (and wraps): with long rows (K = 4096: 8 KB pitch) every load of
-  // the launch otherwise hits the same few memory channels at the same time (32 rows at ONE column offset per load, all workgroups in step)
-  const int nchunk = K / SK_CHUNK;
-  const int rot = (int)((blockIdx.x * 5u) % (unsigned)nchunk);
-#pragma unroll 2
-  for (int ci = wave; ci < nchunk; ci += NW) {
-    int cc = ci + rot; if (cc >= nchunk) cc -= nchunk;
-    const int k = cc * SK_CHUNK;
-    bf16x8 fb[4], fa0[4], fa1[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) fb[j] = *(const bf16x8*)(bp + k + j * 8);
-#pragma unroll
-    for (int j = 0; j < 4; j++) fa0[j] = *(const bf16x8*)(ap0 + k + j * 8);
-    if (nrb > 1) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) fa1[j] = *(const bf16x8*)(ap1 + k + j * 8);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[j], fb[j], acc0, 0, 0, 0);
-    if (nrb > 1) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[j], fb[j], acc1, 0, 0, 0);
-    }
-  }
-  {   // D layout: column lane & 31, row (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* slot = sk_red + wave * SLOT;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      slot[row * (SK_BN + 1) + (lane & 31)] = acc0[r];
-      if (nrb > 1) slot[(32 + row) * (SK_BN + 1) + (lane & 31)] = acc1[r];
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < M * (SK_BN / 4); i += NW * 64) {
-    const int m = i / (SK_BN / 4), c = (i % (SK_BN / 4)) * 4;
-    const int nn = n0 + c;
-    if (nn >= N) continue;
-    float o[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < NW; w++) {
-      const float* q = sk_red + w * SLOT + m * (SK_BN + 1) + c;
-      o[0] += q[0]; o[1] += q[1]; o[2] += q[2]; o[3] += q[3];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; e++) o[e] *= P.alpha;
-    if (P.bias) {
-      const float4 bb = *(const float4*)(P.bias + nn);
-      o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
-    }
-    if (P.act != DU_ACT_NONE) {
-#pragma unroll
-      for (int e = 0; e < 4; e++) o[e] = apply_act(o[e], P.act);
-    }
-    if (P.gamma) {
-      const float4 gg = *(const float4*)(P.gamma + nn);
-      o[0] *= gg.x; o[1] *= gg.y; o[2] *= gg.z; o[3] *= gg.w;
-    }
-    if (P.row_scale) {
-      const float rs = P.row_scale[m / P.rs_rows];
-#pragma unroll
-      for (int e = 0; e < 4; e++) o[e] *= rs;
-    }
-    if (P.out_bf16) {
-      if (P.residual) {
-        const bf16_t* rp = (const bf16_t*)P.residual + (long)m * P.ldr + nn;
-#pragma unroll
-        for (int e = 0; e < 4; e++) o[e] += (float)rp[e];
-      }
-      bf16x4 t;
-#pragma unroll
-      for (int e = 0; e < 4; e++) t[e] = (bf16_t)o[e];
-      *(uint2*)((bf16_t*)P.C + (long)m * P.ldc + nn) = __builtin_bit_cast(uint2, t);
-    } else {
-      if (P.residual) {
-        const float4 rr = *(const float4*)((const float*)P.residual + (long)m * P.ldr + nn);
-        o[0] += rr.x; o[1] += rr.y; o[2] += rr.z; o[3] += rr.w;
-      }
-      *(float4*)((float*)P.C + (long)m * P.ldc + nn) = make_float4(o[0], o[1], o[2], o[3]);
-    }
-  }
+  skinny_fused_body<NW>(A, lda, B, ldb, M, N, K, P, sk_red, (int)blockIdx.x);
 }
 
 template <int NW>
