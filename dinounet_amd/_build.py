@@ -66,7 +66,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # a kernel whose host stub the compiler dropped (seen once: a helper-lambda call inside an LDS-DMA builtin's arguments) links as an
     # undefined file-local symbol and only fails at dlopen on the GPU box: catch it here
     und = subprocess.run(["nm", "-D", "--undefined-only", LIB], capture_output=True, text=True).stdout
-    bad = [ln.split()[-1] for ln in und.splitlines() if "_GLOBAL__N_" in ln]
+    # ... and a function of ours declared with a stale signature in another source file (C++ mangling: the reference to the old signature
+    # stays undefined; seen once: du_gemm_nt_p8 gained a parameter)
+    bad = [ln.split()[-1] for ln in und.splitlines() if "_GLOBAL__N_" in ln or ("_Z" in ln and "du_" in ln)]
     if bad:
         os.remove(LIB)
         raise RuntimeError("undefined file-local symbols in libdinounet_hip.so (dropped kernel stubs?): " + ", ".join(bad[:4]))

@@ -294,7 +294,7 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 }  // namespace
 
 int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st);   // gemm_bf16.hip
-int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st);       // gemm_p8.hip
+int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st, int tail_rows = 0);       // gemm_p8.hip
 int du_gemm_ragged_rows(const du_gemm_args& a);                      // gemm_bf16.hip
 int64_t du_gemm_skinny_ws_elems(int N, int K);                      // gemm_skinny.hip
 
