@@ -1,5 +1,6 @@
 // HBM-bound NHWC helpers for gfx950: depthwise 3x3, max-pool 3x3/s2, bilinear upsample+add, layout conversion,
 // MSDeformAttn sampling-location / softmax preparation.  All use 16-byte channel vectors per thread.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -91,10 +92,96 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, lo
   }
 }
 
+// Row form of the kernel above (round 3): a thread computes XT = 4 CONSECUTIVE outputs of one image row for its channel vector and slides
+// the 3-column window over the XT + 2 input columns it loads per filter row: 18 sixteen-byte loads per 4 outputs instead of 36, one pixel
+// decode (integer divisions) per 4 outputs instead of 4.  The per-pixel form ran at 1.1 TB/s on the (8, 5376, 256) token pyramid -- load /
+// VALU issue bound, not HBM.  Every grid row width must be a multiple of XT (the caller checks).
+template <typename T, bool FLIP, bool PYR>
+__global__ __launch_bounds__(256) void dwconv_row4_kernel(const T* __restrict__ x, long ldx, long xbs, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, T* __restrict__ y, long ldy, long ybs,
+                                                          T* __restrict__ z, int B, int H, int W, int C, int act) {
+  constexpr int V = Elem<T>::VEC;
+  constexpr int XT = 4;
+  const int cvn = C / V;
+  const int cvb = min(cvn, 256);
+  const int np = 256 / cvb;
+  const int tp = threadIdx.x / cvb, tcv = threadIdx.x % cvb;
+  if (tp >= np) return;
+  const long ngroups = (PYR ? (long)B * 21 * ((H * W) >> 2) : (long)B * H * W) / XT;
+  for (int cv = tcv; cv < cvn; cv += cvb) {
+    const int c0 = cv * V;
+    float wt[9][V], bs[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      bs[j] = bias ? bias[c0 + j] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; t++) wt[t][j] = w[(c0 + j) * 9 + (FLIP ? 8 - t : t)];
+    }
+    for (long g = (long)blockIdx.x * np + tp; g < ngroups; g += (long)gridDim.x * np) {
+      const long p = g * XT;
+      int xo, yo, b, Hs = H, Ws = W, s0 = 0;
+      if constexpr (PYR) {
+        const PyrPix q = pyr_decode(p, H, W);
+        xo = q.xo; yo = q.yo; b = q.b; Hs = q.Hs; Ws = q.Ws; s0 = q.s0;
+      } else {
+        xo = (int)(p % W); long t2 = p / W;
+        yo = (int)(t2 % H); b = (int)(t2 / H);
+      }
+      float acc[XT][V];
+#pragma unroll
+      for (int t = 0; t < XT; t++)
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[t][j] = bs[j];
+#pragma unroll
+      for (int dy = 0; dy < 3; dy++) {
+        const int yi = yo + dy - 1;
+        if (yi < 0 || yi >= Hs) continue;
+        const T* row = x + (long)b * xbs + (s0 + (long)yi * Ws) * ldx + c0;
+        uint4 raw[XT + 2];
+#pragma unroll
+        for (int c = 0; c < XT + 2; c++) {
+          const int xi = xo - 1 + c;
+          raw[c] = (xi >= 0 && xi < Ws) ? *(const uint4*)(row + (long)xi * ldx) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < XT + 2; c++) {
+          const Vec16<T> v = as_vec<T>(raw[c]);
+          float f[V];
+#pragma unroll
+          for (int j = 0; j < V; j++) f[j] = to_f32(v.v[j]);
+#pragma unroll
+          for (int dx = 0; dx < 3; dx++) {
+            const int t = c - dx;                      // column c is tap dx of output t = c - dx
+            if (t >= 0 && t < XT) {
+#pragma unroll
+              for (int j = 0; j < V; j++) acc[t][j] += f[j] * wt[dy * 3 + dx][j];
+            }
+          }
+        }
+      }
+      const long off = (long)b * ybs + (s0 + (long)yo * Ws + xo) * ldy + c0;
+#pragma unroll
+      for (int t = 0; t < XT; t++) {
+        Vec16<T> o;
+        if (z) {
+#pragma unroll
+          for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(acc[t][j]);
+          *(uint4*)(z + off + (long)t * ldy) = as_u4(o);
+        }
+#pragma unroll
+        for (int j = 0; j < V; j++) o.v[j] = from_f32<T>(apply_act(acc[t][j], act));
+        *(uint4*)(y + off + (long)t * ldy) = as_u4(o);
+      }
+    }
+  }
+}
+
 // dw[c][tap] += sum_pix x[pix+tap][c] * dy[pix][c]; db[c] += sum dy.  Block = strip of pixels, thread = (pixel lane, cvec);
 // per-thread register partials are reduced across the block's pixel lanes through LDS in two passes of five taps (every thread
 // takes part in the column sums), so each block issues one store / atomic per (channel, tap).
-template <typename T, bool PYR>
+// ROW4: the pixel loop walks groups of 4 consecutive pixels of one image row (strip % 4 == 0, every row width % 4 == 0): 4 dy loads + 18 x
+// loads per group instead of 4 + 36, one pixel decode per group.
+template <typename T, bool PYR, bool ROW4 = false>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, long ldx, long xbs,
                                                                 const T* __restrict__ dy, long lddy, long dybs,
                                                                 float* __restrict__ dw, float* __restrict__ db, int B, int H,
@@ -116,6 +203,54 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
     for (int k = 0; k < 10; k++)
 #pragma unroll
       for (int j = 0; j < V; j++) aw[k][j] = 0.f;
+    if constexpr (ROW4) {
+      if (active) {
+        for (int p = p0 + 4 * tp; p < p1; p += 4 * np) {
+          int xo, yo, b, Hs = H, Ws = W, s0 = 0;
+          if constexpr (PYR) {
+            const PyrPix q = pyr_decode(p, H, W);
+            xo = q.xo; yo = q.yo; b = q.b; Hs = q.Hs; Ws = q.Ws; s0 = q.s0;
+          } else {
+            xo = p % W; const int t = p / W; yo = t % H; b = t / H;
+          }
+          float gf[4][V];
+          const T* gp = dy + (long)b * dybs + (s0 + (long)yo * Ws + xo) * lddy + c0;
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const Vec16<T> g = as_vec<T>(*(const uint4*)(gp + (long)t * lddy));
+#pragma unroll
+            for (int j = 0; j < V; j++) { gf[t][j] = to_f32(g.v[j]); aw[9][j] += gf[t][j]; }
+          }
+#pragma unroll
+          for (int ky = 0; ky < 3; ky++) {
+            const int yi = yo + ky - 1;
+            if (yi < 0 || yi >= Hs) continue;
+            const T* row = x + (long)b * xbs + (s0 + (long)yi * Ws) * ldx + c0;
+            uint4 raw[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+              const int xi = xo - 1 + c;
+              raw[c] = (xi >= 0 && xi < Ws) ? *(const uint4*)(row + (long)xi * ldx) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+              const Vec16<T> v = as_vec<T>(raw[c]);
+              float f[V];
+#pragma unroll
+              for (int j = 0; j < V; j++) f[j] = to_f32(v.v[j]);
+#pragma unroll
+              for (int kx = 0; kx < 3; kx++) {
+                const int t = c - kx;                  // input column c is tap kx of output pixel t
+                if (t >= 0 && t < 4) {
+#pragma unroll
+                  for (int j = 0; j < V; j++) aw[ky * 3 + kx][j] += f[j] * gf[t][j];
+                }
+              }
+            }
+          }
+        }
+      }
+    } else
     if (active) {
       int p = p0 + tp;
       int xo = 0, yo = 0, b = 0, Hs = H, Ws = W, s0 = 0;
@@ -748,12 +883,19 @@ extern "C" int du_dwconv3x3_bwd_data(int dtype, const void* dy, int64_t lddy, in
   return du_check_launch();
 }
 
+// the row forms (4 consecutive pixels of a row per thread) need every grid of the token pyramid -- widths 2W, W, W / 2 -- to be a multiple of 4
+static inline bool dwconv_row4_ok(int W) {
+  static const bool off = getenv("DU_DWCONV_NO_ROW4") != nullptr;      // debugging / A-B aid
+  return !off && W % 8 == 0;
+}
+
 static inline int dwconv_wgrad_strip(long npix, int C, int v) {
   // ~512 workgroups per launch, but at least 4 pixels per pixel lane so the LDS reduction stays amortised
   const int cvb_ = (C / v) < 256 ? (C / v) : 256;
   const int np_ = 256 / cvb_;
   long strip_l = (npix + 511) / 512;        // 512 strips: the partial buffer the finalize kernel re-reads halves (measured vs 1024)
   if (strip_l < (long)np_ * 4) strip_l = (long)np_ * 4;
+  strip_l = (strip_l + 3) / 4 * 4;          // whole 4-pixel groups (row form of the kernel)
   return (int)strip_l;
 }
 
@@ -790,6 +932,11 @@ extern "C" int du_dwconv3x3_tokens_fwd(int dtype, const void* x, const float* w,
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C % v) return DU_ERR_BAD_ARG;
   const long N = 21L * ((H * W) >> 2);
+  if (dwconv_row4_ok(W) && dtype == DU_BF16) {       // W / 2 (the narrowest grid) % 4 == 0: 4 outputs per thread (dwconv_row4_kernel)
+    const int grid4 = dwconv_grid((long)B * N / 4, C, v);
+    hipLaunchKernelGGL((dwconv_row4_kernel<bf16_t, false, true>), dim3(grid4), dim3(256), 0, st, (const bf16_t*)x, (long)C, N * C, w, bias, (bf16_t*)y, (long)C, N * C, (bf16_t*)z, B, H, W, C, act);
+    return du_check_launch();
+  }
   const int grid = dwconv_grid((long)B * N, C, v);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((dwconv_kernel<bf16_t, false, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (long)C, N * C, w, bias, (bf16_t*)y, (long)C, N * C, (bf16_t*)z, B, H, W, C, act, 0),
@@ -802,6 +949,11 @@ extern "C" int du_dwconv3x3_tokens_bwd_data(int dtype, const void* dy, const flo
   const int v = dtype == DU_BF16 ? 8 : 4;
   if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C % v) return DU_ERR_BAD_ARG;
   const long N = 21L * ((H * W) >> 2);
+  if (dwconv_row4_ok(W) && dtype == DU_BF16) {
+    const int grid4 = dwconv_grid((long)B * N / 4, C, v);
+    hipLaunchKernelGGL((dwconv_row4_kernel<bf16_t, true, true>), dim3(grid4), dim3(256), 0, st, (const bf16_t*)dy, (long)C, N * C, w, (const float*)nullptr, (bf16_t*)dx, (long)C, N * C, (bf16_t*)nullptr, B, H, W, C, DU_ACT_NONE);
+    return du_check_launch();
+  }
   const int grid = dwconv_grid((long)B * N, C, v);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((dwconv_kernel<bf16_t, true, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (long)C, N * C, w, (const float*)nullptr, (bf16_t*)dx, (long)C, N * C, (bf16_t*)nullptr, B, H, W, C, DU_ACT_NONE, 0),
@@ -821,6 +973,11 @@ extern "C" int du_dwconv3x3_tokens_bwd_weight(int dtype, const void* x, const vo
   long blocks = (npix + strip - 1) / strip;
   float* part = (ws && ws_elems >= blocks * C * 10) ? ws : nullptr;
   if (!part) return DU_ERR_BAD_ARG;          // the partial + finalize form overwrites dw / db: no zero-fill contract on this entry point
+  if (dwconv_row4_ok(W) && dtype == DU_BF16 && strip % 4 == 0) {
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (long)C, N * C, (const bf16_t*)dy, (long)C, N * C, dw, db, B, H, W, C, strip, part);
+    hipLaunchKernelGGL(dwconv_wgrad_finalize_kernel, dim3((C * 10 + 31) / 32), dim3(256), 0, st, (const float*)part, dw, db, (int)blocks, C, 0);
+    return du_check_launch();
+  }
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((dwconv_bwd_weight_kernel<bf16_t, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x, (long)C, N * C, (const bf16_t*)dy, (long)C, N * C, dw, db, B, H, W, C, strip, part),
              hipLaunchKernelGGL((dwconv_bwd_weight_kernel<float, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (long)C, N * C, (const float*)dy, (long)C, N * C, dw, db, B, H, W, C, strip, part));

@@ -472,8 +472,14 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
       if (my_off >= 0) Wl[my_off] = (bf16_t)0.f;
       if (woff >= 0) Wl[woff] = (bf16_t)wv;
       my_off = woff;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) blk |= (unsigned)__shfl_xor((int)blk, o, 64);
+      // OR over the wave: DPP inside the 16-lane rows (4 full-rate VALU ops), scalar reads across the 4 rows -- the xor-shuffle tree
+      // it replaces was six dependent ds_bpermute round trips on the critical path of every one of the 168 barrier-paced steps
+      blk |= (unsigned)__builtin_amdgcn_mov_dpp((int)blk, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+      blk |= (unsigned)__builtin_amdgcn_mov_dpp((int)blk, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+      blk |= (unsigned)__builtin_amdgcn_mov_dpp((int)blk, 0x141, 0xf, 0xf, true);     // row_half_mirror: lane i <-> 7 - i of its 8
+      blk |= (unsigned)__builtin_amdgcn_mov_dpp((int)blk, 0x140, 0xf, 0xf, true);     // row_mirror: lane i <-> 15 - i of its 16
+      blk = (unsigned)(__builtin_amdgcn_readlane((int)blk, 0) | __builtin_amdgcn_readlane((int)blk, 16) |
+                       __builtin_amdgcn_readlane((int)blk, 32) | __builtin_amdgcn_readlane((int)blk, 48));
       if (lane == 0 && blk) atomicOr(&step_mask[par], blk);
     }
     {
