@@ -226,19 +226,32 @@ class SpatialPriorModule(nn.Module):
         return c1, tok(c2), tok(c3), tok(c4)
 
 
-_BN_TICKS = []       # num_batches_tracked counters bumped during the current adapter forward: flushed as ONE multi-tensor add
+_TICK_STACK = []     # one list per running DINOv3_Adapter.forward: the num_batches_tracked counters to bump when it ends
 
 
 def _tick(bn):
-    """nn.BatchNorm2d.forward's `num_batches_tracked += 1` (state_dict parity with the reference), deferred: ten scalar adds are ten
-    ~5 us launches in the replayed step; DINOv3_Adapter.forward flushes them with one torch._foreach_add_."""
-    _BN_TICKS.append(bn.num_batches_tracked)
+    """nn.BatchNorm2d.forward's `num_batches_tracked += 1` (state_dict parity with the reference).  Inside DINOv3_Adapter.forward the
+    bumps are collected and applied by ONE torch._foreach_add_ when the forward ends (ten scalar adds are ten ~5 us launches in the
+    replayed step); a BatchNorm used on its own (SpatialPriorModule / bn_act outside an adapter forward) is bumped at once."""
+    if _TICK_STACK:
+        _TICK_STACK[-1].append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
 
 
-def _flush_ticks():
-    if _BN_TICKS:
-        torch._foreach_add_(_BN_TICKS, 1)
-        del _BN_TICKS[:]
+class _collect_ticks:
+    """context of one adapter forward: nested / concurrent adapters each own a list; the bumps of the BatchNorms that ran are applied
+    even when the forward leaves through an exception (their running statistics were updated as well)"""
+
+    def __enter__(self):
+        _TICK_STACK.append([])
+        return self
+
+    def __exit__(self, *exc):
+        ticks = _TICK_STACK.pop()
+        if ticks:
+            torch._foreach_add_(ticks, 1)
+        return False
 
 
 def bn_act(x, bn, act, training, group, stats_part=None):
@@ -314,6 +327,10 @@ class DINOv3_Adapter(nn.Module):
 
     def forward(self, x):
         """x: (B, 3, H, W) fp32 NCHW.  Returns {"1".."4"}: NHWC feature maps (B, H/4.., W/4.., D) in the activation dtype."""
+        with _collect_ticks():
+            return self._forward(x)
+
+    def _forward(self, x):
         dt = _act_dtype(self)
         B, _, H, W = x.shape
         D = self.backbone.embed_dim
@@ -326,7 +343,6 @@ class DINOv3_Adapter(nn.Module):
         ref = self._ref_cache[key]                              # deform_inputs2, ADP:65-68
         shapes = [(H_t, W_t)]
 
-        del _BN_TICKS[:]                                        # nothing left over from an interrupted forward
         if self.training:
             # all DropPath masks of this forward in one draw (ADP:18-26 draws per call: same distribution, 2 launches instead of 12)
             dps = [m for m in self.modules() if isinstance(m, DropPath) and m.drop_prob > 0.0 and m.pinned_mask is None]
@@ -368,5 +384,4 @@ class DINOv3_Adapter(nn.Module):
             fs = ops.sync_bn_multi(cs, norms, ACT_NONE, group)
         else:
             fs = [bn_act(cs[j], norms[j], ACT_NONE, self.training, group) for j in range(4)]    # ADP:479-482
-        _flush_ticks()
         return {"1": fs[0], "2": fs[1], "3": fs[2], "4": fs[3]}

@@ -724,12 +724,14 @@ def mm_wgrad(dy, x, with_colsum=False, k_scale=None, defer=False):
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     kw = dict(dtype=_code(dy.dtype), out_dtype=DU_F32, a_mode=PLAIN_COL, b_mode=PLAIN_COL, M=N, N=K, K=Mr,
               A=dy.data_ptr(), lda=lda, B=x.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=K, split_k=_split_for(tiles, Mr))
+    scaled_in_kernel = False
     if k_scale is not None:
         # k_scale = (per-sample scale (B,) fp32, rows per sample): scales the contraction rows of dy inside the kernel (du_gemm: row_scale
         # with a contraction-major A).  Only the bf16 tile engine does it; otherwise the scaled copy is built here
         kws = dict(kw, row_scale=k_scale[0].data_ptr(), rs_rows=k_scale[1])
         if gemm_route(**kws) == 1:
             kw = kws
+            scaled_in_kernel = True
         else:
             dy = (dy.view(k_scale[0].numel(), k_scale[1], -1) * k_scale[0].view(-1, 1, 1).to(dy.dtype)).view(dy.shape)
             kw = dict(kw, A=dy.data_ptr(), lda=dy.stride(0))
@@ -741,6 +743,8 @@ def mm_wgrad(dy, x, with_colsum=False, k_scale=None, defer=False):
         gemm_raw(a_colsum=db.data_ptr(), **kw)
         return out, db
     gemm_raw(**kw)
+    if scaled_in_kernel:        # the bias gradient is the column sum of the SCALED dy: the kernel scaled its own copy only
+        dy = (dy.view(k_scale[0].numel(), k_scale[1], -1) * k_scale[0].view(-1, 1, 1).to(dy.dtype)).view(dy.shape)
     return out, colsum(dy)
 
 

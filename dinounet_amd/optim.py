@@ -90,6 +90,9 @@ class FusedClipSGD(torch.optim.Optimizer):
                 self._hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
                 self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)
             self._sig = sig
+            # a hipGraph captured against the previous tables / momentum buffers copies from and updates memory this optimizer no longer
+            # owns: holders of such a graph (training.TrainStep) compare this counter before every replay and capture again on a change
+            self.generation = getattr(self, "generation", 0) + 1
         # a hipGraph capture records the host->device copy of the table; replays re-read the pinned source, so the capture gets its own
         # (its gradient addresses, from the graph's private pool, stay valid) and later eager steps cannot overwrite it
         capturing = torch.cuda.is_current_stream_capturing()

@@ -76,6 +76,7 @@ class TrainStep:
         self.warmup = warmup
         self._n = 0
         self.comm_events = None          # list -> eager steps record (start, end) events around reducer.finish()
+        self._opt_generation = 0
 
     def _step(self):
         self.opt.zero_grad(set_to_none=True)
@@ -129,6 +130,7 @@ class TrainStep:
                 with torch.cuda.graph(graph, capture_error_mode=mode):
                     self.loss = self._step()
                 self.graph = graph
+                self._opt_generation = getattr(self.opt, "generation", 0)
             except Exception as e:  # noqa: BLE001   capture is an optimisation: a step that cannot be captured still has to train
                 import warnings
                 warnings.warn(f"hipGraph capture of the train step failed ({e!r}); continuing with eager steps")
@@ -138,6 +140,13 @@ class TrainStep:
                 self.loss = self._step()
                 return self.loss
         if isinstance(self.opt, FusedClipSGD):
+            if getattr(self.opt, "generation", 0) != self._opt_generation:
+                # optimizer.load_state_dict / reallocated parameters since the capture: the recorded step points at retired tables and
+                # momentum buffers -- drop it and capture again
+                self.graph.reset()
+                self.graph = None
+                self._n = max(0, self.warmup - 1)
+                return self.__call__()
             self.opt.refresh_hyper()                        # the captured step re-reads lr & co. from the pinned host buffer
         self.graph.replay()
         return self.loss
