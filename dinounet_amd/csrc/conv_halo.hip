@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
   const int half = lane >> 5;
   const int py = 2 * wave + ((lane & 31) >> 4), px = lane & 15;   // this lane's output pixel inside the tile (A-fragment row)
 
-  uint4 hreg[HV], wreg[WV];
-  auto halo_load = [&](int tile, int ch) {
+  // TWO halo chunks in flight (round 3): with one workgroup-tile of prefetch per wave the HBM-bound layers were latency x concurrency
+  // bound (2 workgroups / CU x 11-23 KB in flight = 6-12 MB chip-wide at ~2.5 us loaded latency ~ 2.4-3 TB/s, what was measured)
+  uint4 hregA[HV], hregB[HV], wreg[WV];
+  auto halo_load = [&](uint4 (&hreg)[HV], int tile, int ch) {
     const int tx0 = (tile % P.tilesX) * TW;
     const int t2 = tile / P.tilesX;
     const int ty0 = (t2 % P.tilesY) * TH, b = t2 / P.tilesY;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
       hreg[i] = r;
     }
   };
-  auto halo_store = [&]() {
+  auto halo_store = [&](const uint4 (&hreg)[HV]) {
 #pragma unroll
     for (int i = 0; i < HV; i++) {
       const int v = tid + i * 256;
@@ -112,9 +114,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
 
   int tile = blockIdx.x;
   if (tile >= P.ntiles) return;
+  // chunk sequence of this (persistent) workgroup: (tile, 0..nch-1), (tile + grid, 0..nch-1), ...
+  auto advance = [&](int& t, int& c) { if (++c == nch) { c = 0; t += (int)gridDim.x; } };
   w_load(0);
-  halo_load(tile, 0);
+  halo_load(hregA, tile, 0);
+  {
+    int t2 = tile, c2 = 0;
+    advance(t2, c2);
+    if (t2 < P.ntiles) halo_load(hregB, t2, c2);
+  }
   bool w_pending = true;
+  int par = 0;                      // which register set holds the chunk to install next
   while (tile < P.ntiles) {
     f32x16 acc[TN];
 #pragma unroll
@@ -122,18 +132,19 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
     for (int ch = 0; ch < nch; ch++) {
-      // ---- install the staged chunk, prefetch the next one ----
-      halo_store();
+      // ---- install the staged chunk, prefetch the chunk after the next one into the registers it frees ----
+      if (par == 0) halo_store(hregA); else halo_store(hregB);
       if (w_pending) w_store();
       __syncthreads();
       {
-        int ntile = tile, nchk = ch + 1;
-        if (nchk == nch) { nchk = 0; ntile = tile + gridDim.x; }
-        if (ntile < P.ntiles) {
-          halo_load(ntile, nchk);
-          if (nch > 1) w_load(nchk);
-        }
+        int t1 = tile, c1 = ch;
+        advance(t1, c1);                               // next chunk: its weights (one chunk ahead: they come from L2)
+        if (t1 < P.ntiles && nch > 1) w_load(c1);
         w_pending = nch > 1;
+        int t2 = t1, c2 = c1;
+        advance(t2, c2);                               // the chunk after it: its halo
+        if (t2 < P.ntiles) { if (par == 0) halo_load(hregA, t2, c2); else halo_load(hregB, t2, c2); }
+        par ^= 1;
       }
       // ---- 9 taps x CK/16 k-steps ----
 #pragma unroll
