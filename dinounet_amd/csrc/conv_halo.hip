@@ -59,26 +59,30 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
   const int py = 2 * wave + ((lane & 31) >> 4), px = lane & 15;   // this lane's output pixel inside the tile (A-fragment row)
 
   // TWO halo chunks in flight (round 3): with one workgroup-tile of prefetch per wave the HBM-bound layers were latency x concurrency
-  // bound (2 workgroups / CU x 11-23 KB in flight = 6-12 MB chip-wide at ~2.5 us loaded latency ~ 2.4-3 TB/s, what was measured)
+  // bound (2 workgroups / CU x 11-23 KB in flight = 6-12 MB chip-wide at ~2.5 us loaded latency ~ 2.4-3 TB/s, what was measured).
+  // The two register sets are used by two STATIC copies of the chunk step (step(hregA); step(hregB); ...): with a run-time set index the
+  // compiler's wait-count pass cannot tell which set the oldest loads went to and drains the whole queue (s_waitcnt vmcnt(0)) before
+  // every install.  The loads are raw buffer loads of ONE image (descriptor rebuilt per chunk from wave-uniform values): a pixel outside
+  // the image -- or a chunk past the end of this workgroup's work -- gets an out-of-range offset and reads zeros, no branch per load.
   uint4 hregA[HV], hregB[HV], wreg[WV];
-  auto halo_load = [&](uint4 (&hreg)[HV], int tile, int ch) {
+  const unsigned img_bytes = (unsigned)P.H * (unsigned)P.W;     // x bytes-per-pixel below
+  auto halo_load = [&](uint4 (&hreg)[HV], int tile, int ch, bool live) {
     const int tx0 = (tile % P.tilesX) * TW;
     const int t2 = tile / P.tilesX;
-    const int ty0 = (t2 % P.tilesY) * TH, b = t2 / P.tilesY;
+    const int ty0 = (t2 % P.tilesY) * TH, b = live ? t2 / P.tilesY : 0;
     const int c0 = ch * CK;
     const bf16_t* src = P.x; long ld = P.ldx; int cofs = c0;
     if (c0 >= P.C1) { src = P.x2; ld = P.ldx2; cofs = c0 - P.C1; }
+    const unsigned pixb = (unsigned)ld * 2u;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)b * P.H * P.W * ld), 0, (int)(img_bytes * pixb), 0x00020000);
 #pragma unroll
     for (int i = 0; i < HV; i++) {
       const int v = tid + i * 256;
-      uint4 r = make_uint4(0, 0, 0, 0);
-      if (v < HW_ * CV) {
-        const int pix = v / CV, cv = v % CV;
-        const int gy = ty0 + pix / HXW - 1, gx = tx0 + pix % HXW - 1;
-        if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W)
-          r = *(const uint4*)(src + (((long)b * P.H + gy) * P.W + gx) * ld + cofs + cv * 8);
-      }
-      hreg[i] = r;
+      const int pix = v / CV, cv = v % CV;
+      const int gy = ty0 + pix / HXW - 1, gx = tx0 + pix % HXW - 1;
+      const bool ok = live && v < HW_ * CV && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+      const unsigned off = ok ? ((unsigned)(gy * P.W + gx) * pixb + (unsigned)(cofs + cv * 8) * 2u) : 0x80000000u;
+      hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
   };
   auto halo_store = [&](const uint4 (&hreg)[HV]) {
@@ -114,37 +118,44 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
 
   int tile = blockIdx.x;
   if (tile >= P.ntiles) return;
+  // this lane's bias values, read ONCE: a load in the epilogue queues behind the halo prefetches (vector memory returns in order) and made
+  // every tile wait for the chunks it had just requested
+  float bias_r[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++) bias_r[j] = P.bias ? P.bias[j * 32 + (lane & 31)] : 0.f;
   // chunk sequence of this (persistent) workgroup: (tile, 0..nch-1), (tile + grid, 0..nch-1), ...
   auto advance = [&](int& t, int& c) { if (++c == nch) { c = 0; t += (int)gridDim.x; } };
   w_load(0);
-  halo_load(hregA, tile, 0);
+  halo_load(hregA, tile, 0, true);
   {
     int t2 = tile, c2 = 0;
     advance(t2, c2);
-    if (t2 < P.ntiles) halo_load(hregB, t2, c2);
+    halo_load(hregB, t2, c2, t2 < P.ntiles);
   }
   bool w_pending = true;
-  int par = 0;                      // which register set holds the chunk to install next
-  while (tile < P.ntiles) {
-    f32x16 acc[TN];
+  int ch = 0;
+  f32x16 acc[TN];
+  // one chunk: install it from `hreg`, refill `hreg` with the chunk after the next one, multiply; the tile's epilogue after its last chunk.
+  // Returns false when this workgroup has no further chunk.
+  auto step = [&](uint4 (&hreg)[HV]) -> bool {
+    if (ch == 0) {
 #pragma unroll
-    for (int j = 0; j < TN; j++)
+      for (int j = 0; j < TN; j++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
-    for (int ch = 0; ch < nch; ch++) {
-      // ---- install the staged chunk, prefetch the chunk after the next one into the registers it frees ----
-      if (par == 0) halo_store(hregA); else halo_store(hregB);
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    }
+    {
+      halo_store(hreg);
       if (w_pending) w_store();
       __syncthreads();
       {
         int t1 = tile, c1 = ch;
         advance(t1, c1);                               // next chunk: its weights (one chunk ahead: they come from L2)
-        if (t1 < P.ntiles && nch > 1) w_load(c1);
-        w_pending = nch > 1;
         int t2 = t1, c2 = c1;
         advance(t2, c2);                               // the chunk after it: its halo
-        if (t2 < P.ntiles) { if (par == 0) halo_load(hregA, t2, c2); else halo_load(hregB, t2, c2); }
-        par ^= 1;
+        if (t1 < P.ntiles && nch > 1) w_load(c1);      // before the halo: the next install waits for the weights only
+        w_pending = nch > 1;
+        halo_load(hreg, t2, c2, t2 < P.ntiles);
       }
       // ---- 9 taps x CK/16 k-steps ----
 #pragma unroll
@@ -164,11 +175,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
       }
       __syncthreads();       // everyone is done with Hs / Ws before the next chunk (or the staging tile) overwrites them
     }
+    if (ch != nch - 1) { ch++; return true; }
     // ---- epilogue: stage the 128 x COUT fp32 tile, add bias, row stores, per-channel statistics ----
     // accumulator register r of lane l: output pixel (wave*32 + (r&3) + 8*(r>>2) + 4*(l>>5)), channel j*32 + (l&31)
 #pragma unroll
     for (int j = 0; j < TN; j++) {
-      const float bv = P.bias ? P.bias[j * 32 + (lane & 31)] : 0.f;
+      const float bv = bias_r[j];
 #pragma unroll
       for (int r = 0; r < 16; r++)
         stg[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * STG_LD + j * 32 + (lane & 31)] = acc[j][r] + bv;
@@ -224,7 +236,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
       }
     }
     __syncthreads();
+    ch = 0;
     tile += gridDim.x;
+    return tile < P.ntiles;
+  };
+  for (;;) {
+    if (!step(hregA)) break;
+    if (!step(hregB)) break;
   }
 }
 
@@ -237,6 +255,8 @@ int launch(const HaloParams& P, hipStream_t st) {
   const size_t stg_bytes = (size_t)128 * (COUT + 4) * 4 + (size_t)4 * COUT * 2 * 4;   // fp32 tile + statistics scratch [4][COUT][2]
   const size_t lds = nch == 1 ? main_bytes + stg_bytes : (main_bytes > stg_bytes ? main_bytes : stg_bytes);
   if (lds > 160 * 1024) return DU_ERR_UNSUPPORTED;
+  // the halo loads address one image through a 32-bit buffer descriptor whose out-of-range sentinel is offset 2^31
+  if ((long)P.H * P.W * (P.ldx > P.ldx2 ? P.ldx : P.ldx2) * 2 >= (1L << 31)) return DU_ERR_UNSUPPORTED;
   auto kfn = conv3x3_halo_kernel<CK, TN>;
   if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DU_ERR_LAUNCH;
   const int per_cu = (int)((160 * 1024) / lds);

@@ -104,17 +104,30 @@ __device__ __forceinline__ void tile_coords(const GemmParams& P, int& tm, int& t
 // ---- epilogue pieces.  Accumulator layout (MFMA fed with (B fragment, A fragment)): lane l holds output row (l & 31) of the 32 x 32
 // block and columns 8 g + 4 (l >> 5) + e of it in registers 4 g + e. ----
 
-// erf GELU without branches (the libm erff takes two exec-masked paths, ~40 VALU per element): Abramowitz-Stegun 7.1.26, |erf error|
-// < 1.5e-7, i.e. far inside the bf16 rounding of the stored value; used only on the bf16-output path (fc1 of the frozen ViT)
-__device__ __forceinline__ float gelu_fast(float v) {
-  const float x = fabsf(v) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = p * t * __expf(-x * x);          // erfc(|x|)
-  return 0.5f * v * (v < 0.f ? e : 2.0f - e);
+// erf GELU of the bf16-output path (fc1 of the frozen ViT), two elements per call on the PACKED fp32 pipe.  The epilogue of a 256 x 256
+// tile is 128 activations per lane with the matrix pipe idle (one workgroup per CU), so its VALU cycles are exposed: ~22 us of a 90 us
+// fc1 product with the previous form (Abramowitz-Stegun 7.1.26: v_rcp + v_exp + ~12 full-rate VALU per element = ~80 cycles / wave).
+//   gelu(v) = max(v, 0) - u * E(u),   u = min(|v|, 5.6),   E(u) = 0.5 * erfc(u / sqrt 2) = 2 ^ q(u)
+// q = degree-7 least-squares (Chebyshev-node) fit of log2(0.5 erfc(u / sqrt 2)) on [0, 5.6] (tools: numpy.polynomial.chebyshev.fit, fp32
+// Horner checked): RELATIVE error of E < 1.1e-5 everywhere (so the tiny negative tail keeps its relative accuracy), |gelu error| < 5e-7,
+// both far inside the bf16 rounding of the stored value.  Past u = 5.6, E < 1.1e-8 and u * E is held there (|error| < 1e-7 |v|).
+// Cost: 2 v_med3 + 4 v_pk_fma (8 packed FMAs / 2) + 1 v_exp per element = ~40 cycles / wave.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float c) { f32x2 r; r.x = c; r.y = c; return r; }
+__device__ __forceinline__ f32x2 gelu_pk(f32x2 v) {
+  f32x2 u, m, e;
+  u.x = __builtin_amdgcn_fmed3f(fabsf(v.x), 0.f, 5.6f); u.y = __builtin_amdgcn_fmed3f(fabsf(v.y), 0.f, 5.6f);
+  m.x = __builtin_amdgcn_fmed3f(v.x, 0.f, __builtin_inff()); m.y = __builtin_amdgcn_fmed3f(v.y, 0.f, __builtin_inff());
+  f32x2 q = splat2(-1.99582904e-06f);
+  q = q * u + splat2(6.48327432e-05f);
+  q = q * u + splat2(-9.56180914e-04f);
+  q = q * u + splat2(8.60978469e-03f);
+  q = q * u + splat2(-5.41717858e-02f);
+  q = q * u + splat2(-4.58246213e-01f);
+  q = q * u + splat2(-1.15134465e+00f);
+  q = q * u + splat2(-9.99985061e-01f);
+  e.x = __builtin_amdgcn_exp2f(q.x); e.y = __builtin_amdgcn_exp2f(q.y);
+  return m - u * e;
 }
 
 // bf16 staging of one 32 x 32 block: bias (+ GELU) in registers, 4 columns packed into one ds_write_b64.  ACT == SWIGLU: the 4 columns
@@ -131,8 +144,9 @@ __device__ __forceinline__ void stage_block_bf16(const f32x16& a, const float4 (
       *(unsigned*)(stg + srow * ldb + ((scol + 8 * g + 4 * hi) >> 1)) = __builtin_bit_cast(unsigned, t);
     } else {
       if constexpr (ACT == DU_ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) o[e] = gelu_fast(o[e]);
+        f32x2 p0 = {o[0], o[1]}, p1 = {o[2], o[3]};
+        p0 = gelu_pk(p0); p1 = gelu_pk(p1);
+        o[0] = p0.x; o[1] = p0.y; o[2] = p1.x; o[3] = p1.y;
       }
       bf16x4 t;
 #pragma unroll
@@ -296,6 +310,52 @@ __device__ __forceinline__ void readout_f32(const GemmParams& P, const float* st
       for (int e = 0; e < W; e++) o[e] += rr[u][e];
       RowVec<TC, W>::store(Cb + out_offset(P, m, n, P.ldc), o);
     }
+  }
+}
+// fp32 result WITH a residual, plain store, 256 x 128 tile (the ViT's proj / fc2: x + LayerScale(...)): the whole residual tile of this
+// thread (16 x 16 bytes) is requested BEFORE the accumulators are staged, so its HBM latency is paid once and under the staging pass;
+// readout_f32 keeps 4 loads in flight and pays it four times in a row (the epilogue was ~15 us of a 40 us proj product, r02 table).
+struct ResidualTile { float4 r[16]; };
+template <int TBN>
+__device__ __forceinline__ void residual_prefetch(const GemmParams& P, const float* Rb, int mrow0, int n0, int tid, ResidualTile& R) {
+  constexpr int CW = TBN / 4;
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int v = tid + u * 512;
+    const int m = mrow0 + v / CW, n = n0 + (v % CW) * 4;
+    R.r[u] = (m < P.M && n < P.N) ? *(const float4*)(Rb + (long)m * P.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int TBN>
+__device__ __forceinline__ void readout_f32_prefetched(const GemmParams& P, const float* stg, int ldf, int mrow0, int n0, float* Cb, int tid,
+                                                       const ResidualTile& R) {
+  constexpr int CW = TBN / 4;
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int v = tid + u * 512;
+    const int row = v / CW, cw = v % CW;
+    const int m = mrow0 + row, n = n0 + cw * 4;
+    if (m >= P.M || n >= P.N) continue;
+    const float4 tt = *(const float4*)(stg + row * ldf + cw * 4);
+    float o[4] = {tt.x * P.alpha, tt.y * P.alpha, tt.z * P.alpha, tt.w * P.alpha};
+    if (P.bias) {
+      const float4 bb = *(const float4*)(P.bias + n);
+      o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
+    }
+    if (P.act != DU_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] = apply_act(o[e], P.act);
+    }
+    if (P.gamma) {
+      const float4 gg = *(const float4*)(P.gamma + n);
+      o[0] *= gg.x; o[1] *= gg.y; o[2] *= gg.z; o[3] *= gg.w;
+    }
+    if (P.row_scale) {
+      const float rs = P.row_scale[m / P.rs_rows];
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] *= rs;
+    }
+    *(float4*)(Cb + (long)m * P.ldc + n) = make_float4(o[0] + R.r[u].x, o[1] + R.r[u].y, o[2] + R.r[u].z, o[3] + R.r[u].w);
   }
 }
 template <typename TC, int TBN>
@@ -1114,12 +1174,21 @@ __global__ __launch_bounds__(512) void gemm_nt_p8n_kernel(GemmParams P) {
   }
   if (!done) {
     float* stg = (float*)smem;
+    bool pre = false;
+    ResidualTile R;
+    if constexpr (sizeof(TC) == 4) {
+      pre = Rb && P.store_mode == DU_STORE_PLAIN && !(P.dbg & 4) && P.ldr % 4 == 0 && P.ldc % 4 == 0 && !((((uintptr_t)Rb) | ((uintptr_t)Cb)) & 15);
+      if (pre) residual_prefetch<NBN>(P, (const float*)Rb, m0, n0, tid, R);
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int c = 0; c < 2; c++)
         stage_block_f32(acc[i][c], stg, N_STG_LDF, i * 128 + wm * 32 + (lane & 31), wn * 64 + c * 32, lane);
     __syncthreads();
+    if constexpr (sizeof(TC) == 4) {
+      if (pre) { readout_f32_prefetched<NBN>(P, stg, N_STG_LDF, m0, n0, (float*)Cb, tid, R); return; }
+    }
     readout_f32_any<TC, NBN>(P, stg, N_STG_LDF, 256, m0, n0, Cb, Rb, tid);
   }
 }

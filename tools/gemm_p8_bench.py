@@ -84,7 +84,8 @@ def time_variants(rounds):
     g = torch.Generator(device="cpu").manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g).to(dev).to(bf)
     variants = [("old128", dict(mode=0)), ("256x256", dict(mode=1)), ("256 nostore", dict(mode=1, debug=1)), ("256 noepi", dict(mode=1, debug=2)),
-                ("256x128", dict(mode=2)), ("128 nostore", dict(mode=2, debug=1)), ("128 noepi", dict(mode=2, debug=2)), ("auto", dict(mode=-1))]
+                ("256x128", dict(mode=2)), ("128 nostore", dict(mode=2, debug=1)), ("128 noepi", dict(mode=2, debug=2)), ("128 nopre", dict(mode=2, debug=4)),
+                ("auto", dict(mode=-1))]
     shapes = [(8232, 3072, 1024, bf, "qkv"), (8232, 4096, 1024, bf, "fc1"), (8232, 1024, 4096, torch.float32, "fc2"),
               (8232, 1024, 1024, torch.float32, "proj"), (8192, 3072, 1024, bf, "qkv8192"), (8192, 4096, 1024, bf, "fc1_8192"),
               (4096, 4096, 4096, bf, "4096^3"), (8192, 8192, 8192, bf, "8192^3"), (8232, 2304, 768, bf, "qkv_b"), (8232, 3072, 768, bf, "fc1_b"),
