@@ -78,10 +78,13 @@ __device__ __forceinline__ float other_half_max(float x) {
   return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
 }
 
-template <int DH>
-__global__ __launch_bounds__(256, DH == 64 ? 4 : 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+template <int DH, bool ABL>
+__global__ __launch_bounds__(256, DH == 64 ? (ABL ? 3 : 4) : 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int H, int N,
-                                                       int Npad) {
+                                                       int Npad, int dbg_arg, unsigned long long* __restrict__ probe) {
+  // ABL: timing ablations (tools/attn_ablate.py, du_set_option key 4): pieces of the tile program switched off by dbg bits; the product
+  // kernel is the ABL = false instantiation, where every `dbg &` test folds away
+  const int dbg = ABL ? dbg_arg : 0;
   constexpr int KT = 64;                     // keys per tile
   constexpr int ROWB = DH * 2;               // bytes per K / V row (128 / 256): unpadded LDS images
   constexpr int NKK = DH / 16;               // k-steps of the S^T product
@@ -91,7 +94,13 @@ __global__ __launch_bounds__(256, DH == 64 ? 4 : 2) void attn_fwd_kernel(const b
   constexpr int RPP = 1024 / ROWB;           // rows per 1-KB DMA piece (8 / 4)
   constexpr int CPR = ROWB / 16;             // 16-byte chunks per row (8 / 16)
   constexpr int PIECES = TILE_B / 1024;      // DMA pieces per operand tile (8 / 16), dealt to the 4 waves: piece = wave + 4 i
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_B];
+  // K / V ring.  Two buffers (one tile of prefetch).  A three-buffer ring (two tiles in flight, 3 workgroups / CU) was measured in round 3:
+  // 58.5 us against 56.0 us at the dinounet_l shape -- the tile period is not memory latency (tools/attn_ablate.py: the K / V tiles sit in
+  // L2 / Infinity Cache; an EMPTY tile loop still costs half the kernel), and the third buffer costs a workgroup of occupancy.
+  constexpr int NBUF = 2;
+  constexpr int AHEAD = NBUF - 1;            // tiles requested beyond the one being multiplied
+  constexpr int DMA_PER_TILE = 2 * (PIECES / 4);   // LDS-DMA instructions per wave and tile (K + V)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * BUF_B];
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   typedef __attribute__((address_space(3))) s16x4 lds_v4;
@@ -111,6 +120,19 @@ __global__ __launch_bounds__(256, DH == 64 ? 4 : 2) void attn_fwd_kernel(const b
   }
   const int q0 = (qt * 4 + wave) * 32;
   const bool active = q0 < N;        // wave-uniform: the last query tile of N = 1029 keeps only one wave busy
+  // ABL bit 64: wave 0 of workgroup (1, 0) stamps s_memtime at the segment boundaries of every tile and leaves the per-segment cycle sums
+  // in probe[0..7] (du_debug_attn_probe); each stamp drains the LDS / scalar queues, so the tile runs ~10 % slower than unprobed
+  const bool probing = ABL && (dbg_arg & 64) && probe && blockIdx.x == 1 && blockIdx.y == 0 && wave == 0;
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+  auto stamp = [&](int j) {
+    if constexpr (ABL) {
+      if (probing) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (j >= 0) seg[j] += t - t_prev;
+        t_prev = t;
+      }
+    }
+  };
   const bf16_t* Qb = Q + (long)bh * Npad * DH;
 
   // ---- K / V descriptors (N rows: later rows of the Npad-row arrays are never read) and this lane's DMA source offsets ----
@@ -188,13 +210,31 @@ __global__ __launch_bounds__(256, DH == 64 ? 4 : 2) void attn_fwd_kernel(const b
   };
 
   const int ntiles = (N + KT - 1) / KT;
+  // counted wait: everything but the youngest `tiles` tiles' DMA has landed (vector memory returns in order)
+  auto wait_all_but = [&](int tiles) {
+    if (tiles <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (DMA_PER_TILE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  };
+  static_assert(AHEAD <= 2 && (DMA_PER_TILE == 4 || DMA_PER_TILE == 8), "wait_all_but() knows one tile of 4 or 8 pieces in flight");
   dma_tile(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (AHEAD > 1 && ntiles > 1) dma_tile(1, 1);
+  wait_all_but(AHEAD > 1 && ntiles > 1 ? 1 : 0);
+  // The compiler cannot see the wait above (nor the one that ends every tile), so its own wait-count bookkeeping still has the four Q
+  // fragment loads "in flight" at the loop head and guarded the S^T MFMAs of EVERY tile with s_waitcnt vmcnt(3) ... vmcnt(0) -- which the
+  // hardware applies to what is really outstanding there: the LDS-DMA of the NEXT tile, issued a few instructions earlier.  Every tile
+  // waited for its successor's loads to land before its 7th MFMA (the prefetch overlapped nothing; ~2 us per tile and wave, found in the
+  // ISA in round 3).  Re-defining the fragments here makes the compiler settle its vmcnt debt before the loop.
+#pragma unroll
+  for (int kk = 0; kk < NKK; kk++) asm volatile("" : "+v"(qf[kk]));
   __syncthreads();
+  int cur = 0, fill = AHEAD % NBUF;                      // ring slots: the tile being multiplied, the one requested now
   for (int kt = 0; kt < ntiles; kt++) {
     const bool more = kt + 1 < ntiles;
-    if (more) dma_tile((kt + 1) & 1, kt + 1);            // lands while this tile is multiplied
-    const unsigned char* Ks = smem + (kt & 1) * BUF_B;
+    stamp(-1);
+    if (kt + AHEAD < ntiles && !(dbg & 32)) dma_tile(fill, kt + AHEAD);
+    stamp(0);                                            // 0: DMA issue // into the slot read last in tile kt - 1 (everyone is past that tile's barrier)
+    const unsigned char* Ks = smem + cur * BUF_B;
     const unsigned char* Vs = Ks + TILE_B;
     if (active) {
       // ---- S^T - m = K Q^T - m for the two 32-key blocks: all K fragments first, then the two accumulation chains alternating ----
@@ -208,7 +248,8 @@ __global__ __launch_bounds__(256, DH == 64 ? 4 : 2) void attn_fwd_kernel(const b
       bf16x8 kf[2][2];                                   // two k-steps of both key blocks in flight
 #pragma unroll
       for (int kb = 0; kb < 2; kb++) { kf[kb][0] = kfrag(kb, 0); kf[kb][1] = kfrag(kb, 1); }
-      __builtin_amdgcn_s_setprio(1);
+      if (dbg & 8) { s[0] = cinit; s[1] = cinit; } else {
+      if (!(dbg & 128)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < NKK; kk++) {
 #pragma unroll
@@ -217,7 +258,10 @@ __global__ __launch_bounds__(256, DH == 64 ? 4 : 2) void attn_fwd_kernel(const b
           if (kk + 2 < NKK) kf[kb][kk & 1] = kfrag(kb, kk + 2);
         }
       }
-      __builtin_amdgcn_s_setprio(0);
+      if (!(dbg & 128)) __builtin_amdgcn_s_setprio(0);
+      }
+      if (probing) { asm volatile("" :: "v"(s[0][0]), "v"(s[1][0])); }
+      stamp(1);                                          // 1: K fragment reads + S^T MFMAs (results landed)
       // first V fragments: in flight under the softmax
       bf16x8 vf[2][NDB];
 #pragma unroll
@@ -233,14 +277,16 @@ __global__ __launch_bounds__(256, DH == 64 ? 4 : 2) void attn_fwd_kernel(const b
           }
       }
       float mx = s[0][0];
+      if (!(dbg & 2)) {
 #pragma unroll
       for (int kb = 0; kb < 2; kb++)
 #pragma unroll
         for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
       mx = other_half_max(mx);                           // tile maximum relative to the running maximum
+      }
       // deferred rescale: keep the old running max while the tile's max exceeds it by <= 8 (P <= 2^8, exact in the fp32
       // accumulators, bf16 P keeps its relative precision); the branch is wave-uniform
-      if (kt == 0 || !__all(mx <= 8.0f)) {
+      if (!(dbg & 2) && (kt == 0 || !__all(mx <= 8.0f))) {
         const float dm = kt == 0 ? mx : fmaxf(mx, 0.f);  // new max - old max (the first tile adopts its maximum whatever its sign)
         const float alpha = __builtin_amdgcn_exp2f(-dm);
         m_run += dm;
@@ -254,15 +300,22 @@ __global__ __launch_bounds__(256, DH == 64 ? 4 : 2) void attn_fwd_kernel(const b
 #pragma unroll
           for (int r = 0; r < 16; r++) s[kb][r] -= dm;
       }
+      stamp(2);                                          // 2: mask, running maximum, (rare) rescale
 #pragma unroll
       for (int kb = 0; kb < 2; kb++)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const float p0 = __builtin_amdgcn_exp2f(s[kb][r]), p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+          float p0 = s[kb][r], p1 = s[kb][r + 1];
+          if (!(dbg & 1)) {
+            p0 = __builtin_amdgcn_exp2f(p0); p1 = __builtin_amdgcn_exp2f(p1);
+            if constexpr (ABL) asm volatile("" : "+v"(p0), "+v"(p1));     // keeps the ablation's branch a branch (no speculated exp + select)
+          }
           s[kb][r] = p0; s[kb][r + 1] = p1;
           l0 += p0; l1 += p1;
         }
 
+      if (probing) { asm volatile("" :: "v"(s[0][15]), "v"(s[1][15]), "v"(l0), "v"(l1)); }
+      stamp(3);                                          // 3: exp2 + row sums
       // ---- O^T += V^T P^T: B fragment of step (kb, st) = accumulator registers 8st..8st+7 of s[kb] (keys kb*32 + 16st + 4half +
       //      {0..3, 8..11}); the V fragments of the next step are fetched while this step's MFMAs run ----
 #pragma unroll
@@ -275,16 +328,32 @@ __global__ __launch_bounds__(256, DH == 64 ? 4 : 2) void attn_fwd_kernel(const b
         bf16x8 pf;
 #pragma unroll
         for (int e = 0; e < 8; e++) pf[e] = (bf16_t)s[kb][8 * st + e];
-        __builtin_amdgcn_s_setprio(1);
+        if (!(dbg & 4)) {
+        if (!(dbg & 128)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int d = 0; d < NDB; d++) acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[step & 1][d], pf, acc_o[d], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (!(dbg & 128)) __builtin_amdgcn_s_setprio(0);
+        }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the next tile has landed; the barrier = everyone's
+    // this wave's share of the NEXT tile has landed (the barrier = everyone's); the tile after it may stay in flight
+    if (probing) { asm volatile("" :: "v"(acc_o[0][0]), "v"(acc_o[NDB - 1][15])); }
+    stamp(4);                                            // 4: P conversion, V fragment reads, PV MFMAs (results landed)
+    if (!(dbg & 16)) {
+    wait_all_but(AHEAD > 1 && kt + 2 < ntiles ? 1 : 0);
     __syncthreads();
+    }
+    stamp(5);                                            // 5: end-of-tile DMA wait + barrier
+    cur = cur + 1 == NBUF ? 0 : cur + 1;
+    fill = fill + 1 == NBUF ? 0 : fill + 1;
   }
 
+  if constexpr (ABL) {
+    if (probing && lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) probe[j] = seg[j];
+    }
+  }
   // ---- finalize: O[q][dv] = O^T[dv][q] / l ----
   const float l_part = l0 + l1;
   const float l = l_part + __shfl_xor(l_part, 32, 64);
@@ -385,7 +454,7 @@ __global__ __launch_bounds__(256) void qkv_rope_split_rows_kernel(const T* __res
   }
 }
 
-int g_attn_w = 0;        // unused knob kept for du_set_option key 4 (workgroups are 4 waves: 3-wave workgroups measured slower)
+int g_attn_w = 0;        // du_set_option key 4: ablation bits of attn_fwd_kernel<64, true> (tools/attn_ablate.py); 0 = the product kernel
 
 extern "C" int du_qkv_rope_split_rows(int dtype, const void* qkv_rows, void* q, void* k, void* v, const float* sin_t, const float* cos_t,
                                       int B, int N, int Npad, int H, int Dh, int prefix, float qscale, int64_t m_begin, int m_count,
@@ -407,6 +476,19 @@ extern "C" int du_qkv_rope_split_rows(int dtype, const void* qkv_rows, void* q, 
   return du_check_launch();
 }
 
+// device scratch of the ablation kernel's cycle probe (allocated on first use, never in the product path)
+static unsigned long long* g_attn_probe = nullptr;
+static unsigned long long* attn_probe_buffer() {
+  if (!g_attn_probe && hipMalloc((void**)&g_attn_probe, 8 * sizeof(unsigned long long)) != hipSuccess) g_attn_probe = nullptr;
+  return g_attn_probe;
+}
+// Debug aid (tools/attn_ablate.py): copy the 8 per-segment cycle sums the last probed launch (du_set_option(4, bits | 64)) left behind.
+extern "C" int du_debug_attn_probe(uint64_t* host8) {
+  if (!host8) return DU_ERR_BAD_ARG;
+  if (!g_attn_probe) return DU_ERR_UNSUPPORTED;
+  return hipMemcpy(host8, g_attn_probe, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? DU_OK : DU_ERR_LAUNCH;
+}
+
 extern "C" int du_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int N, int Npad, int Dh,
                                 void* stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -414,9 +496,10 @@ extern "C" int du_attention_fwd(const void* q, const void* k, const void* v, voi
   if ((long)N * Dh * 2 > 0x7fffffffL) return DU_ERR_UNSUPPORTED;
   dim3 grid((N + 127) / 128, B * H), block(256);
   if (Dh == 64)
-    hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad);
+    if (g_attn_w) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, g_attn_w, attn_probe_buffer());
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, 0, nullptr);
   else if (Dh == 128)
-    hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad);
+    hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, 0, nullptr);
   else return DU_ERR_UNSUPPORTED;
   return du_check_launch();
 }

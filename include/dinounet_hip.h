@@ -411,10 +411,12 @@ int du_device_ok(void); /* 1 if the current device is gfx950 */
 /* Kernel-selection knobs for measurement tools (within-process A/B runs, tools/gemm_p8_bench.py); results never depend on them.
    key 0: 256 x 256 multi-phase NT GEMM (gemm_p8.hip): -1 heuristic (default), 0 never, 1 wherever legal;
    key 1: its pinned issue order on (1, default) / off (0);  key 2: its tile band height (default 4);
-   key 3: epilogue ablations of those kernels (timing only);  key 4: attention waves per workgroup (0 = per shape, 3, 4);
+   key 3: epilogue ablations of those kernels (timing only);  key 4: attention tile-program ablation bits (0 = the product kernel; tools/attn_ablate.py);
    key 5: weight gradients (contraction-major operands, split-K) on the multi-phase kernel: 1 where it pays (default), 2 wherever legal,
           0 never (the 128 x 128 kernel). */
 int du_set_option(int key, int value);
+/* tuning aid: the 8 per-segment cycle sums of the last probed attention launch (du_set_option(4, bits | 64), tools/attn_ablate.py) */
+int du_debug_attn_probe(uint64_t* host8);
 
 /* ---- sliding-window inference: predicted_logits[sl] += prediction * gaussian; n_predictions[sl] += gaussian
    (dinounet/inference/predict_from_raw_data.py:607-608) for a batch of nb windows, then predicted_logits /= n_predictions (:610).

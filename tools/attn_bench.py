@@ -45,7 +45,7 @@ def main():
             same &= bool(torch.equal(out, o0))
         del s, ref
         res = {}
-        for w in (0, 3, 4):
+        for w in (0,):
             L.du_set_option(4, w)
             run(q, k, v, out, B, H, N, Npad, Dh)
             if w:
@@ -68,7 +68,7 @@ def main():
         fl = 4.0 * B * H * N * N * Dh
         good = err < 2e-2 and same
         ok &= good
-        print(f"{name:>18} B{B} H{H} N{N} Dh{Dh}: {t:8.1f} us  {fl / t / 1e6:7.1f} TF/s ({fl / t / 1e6 / 2500 * 100:4.1f} % of 2.5 PF)  [W3 {res[3]:.1f} W4 {res[4]:.1f} us]  "
+        print(f"{name:>18} B{B} H{H} N{N} Dh{Dh}: {t:8.1f} us  {fl / t / 1e6:7.1f} TF/s ({fl / t / 1e6 / 2500 * 100:4.1f} % of 2.5 PF)  "
               f"rel err {err:.2e} deterministic {same} -> {'OK' if good else 'FAIL'}", flush=True)
     print("CHECK", "PASSED" if ok else "FAILED")
     sys.exit(0 if ok else 1)
