@@ -65,23 +65,60 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
   // every install.  The loads are raw buffer loads of ONE image (descriptor rebuilt per chunk from wave-uniform values): a pixel outside
   // the image -- or a chunk past the end of this workgroup's work -- gets an out-of-range offset and reads zeros, no branch per load.
   uint4 hregA[HV], hregB[HV], wreg[WV];
-  const unsigned img_bytes = (unsigned)P.H * (unsigned)P.W;     // x bytes-per-pixel below
-  auto halo_load = [&](uint4 (&hreg)[HV], int tile, int ch, bool live) {
-    const int tx0 = (tile % P.tilesX) * TW;
-    const int t2 = tile / P.tilesX;
-    const int ty0 = (t2 % P.tilesY) * TH, b = live ? t2 / P.tilesY : 0;
+  // Addressing diet (round 3: the kernel is instruction-issue bound -- ~620 instructions per wave and tile around 18-72 MFMAs; a SIMD
+  // issues about one instruction per 4-5 cycles whatever its kind, tools/attn_ablate.py).  Per halo slot of this thread only constants:
+  // rel = (dy - 1) * W + (dx - 1) pixels from the tile origin, the byte offset of its channel vector, and three bit masks (slot does not
+  // exist / sits in the halo's left column / right column).  Rows above and below the image fall outside the per-image buffer descriptor
+  // by themselves (negative or >= H * W offsets); the left / right columns wrap into the neighbouring row, so they are killed through
+  // the masks when the tile touches that border: bit 31 of the offset = out of range.
+  int rel_pix[HV];
+  const unsigned cv_bytes = (unsigned)(tid % CV) * 16u;   // 256 % CV == 0: the same channel vector in every slot
+  unsigned masks = 0;                                   // bits 0-7 dead slots, 8-15 left column, 16-23 right column
+#pragma unroll
+  for (int i = 0; i < HV; i++) {
+    const int v = tid + i * 256;
+    const int pix = v / CV;
+    rel_pix[i] = (pix / HXW - 1) * P.W + (pix % HXW - 1);
+    if (v >= HW_ * CV) masks |= 1u << i;
+    else if (pix % HXW == 0) masks |= 0x100u << i;
+    else if (pix % HXW == HXW - 1) masks |= 0x10000u << i;
+  }
+  static_assert(HV <= 8 && 256 % CV == 0, "slot masks are 8 bits wide");
+  struct TileAt { int tile, tx, ty, b; };               // a tile of this workgroup's sequence and its (x, y, image) coordinates
+  int step_x, step_y, step_b;                           // gridDim.x tiles further on, in those coordinates
+  {
+    const int g = (int)gridDim.x, per = P.tilesX * P.tilesY;
+    step_b = g / per; step_y = (g % per) / P.tilesX; step_x = g % P.tilesX;
+  }
+  auto tile_at = [&](int tile) {
+    TileAt t; t.tile = tile; t.tx = tile % P.tilesX;
+    const int q = tile / P.tilesX;
+    t.ty = q % P.tilesY; t.b = q / P.tilesY;
+    return t;
+  };
+  auto tile_next = [&](TileAt& t) {                     // + gridDim.x tiles without a division
+    t.tile += (int)gridDim.x;
+    t.tx += step_x; if (t.tx >= P.tilesX) { t.tx -= P.tilesX; t.ty++; }
+    t.ty += step_y; if (t.ty >= P.tilesY) { t.ty -= P.tilesY; t.b++; }
+    t.b += step_b;
+  };
+  auto halo_load = [&](uint4 (&hreg)[HV], const TileAt& t, int ch) {
+    const bool live = t.tile < P.ntiles;
+    const int tx0 = t.tx * TW, ty0 = t.ty * TH;
     const int c0 = ch * CK;
     const bf16_t* src = P.x; long ld = P.ldx; int cofs = c0;
     if (c0 >= P.C1) { src = P.x2; ld = P.ldx2; cofs = c0 - P.C1; }
     const unsigned pixb = (unsigned)ld * 2u;
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)b * P.H * P.W * ld), 0, (int)(img_bytes * pixb), 0x00020000);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)(live ? t.b : 0) * P.H * P.W * ld), 0,
+                                                      (int)((unsigned)P.H * (unsigned)P.W * pixb), 0x00020000);
+    const unsigned base = (unsigned)(ty0 * P.W + tx0) * pixb + (unsigned)cofs * 2u;      // wave-uniform
+    const unsigned sel = 0xffu | (tx0 == 0 ? 0xff00u : 0u) | (tx0 + TW == P.W ? 0xff0000u : 0u);       // wave-uniform
+    unsigned kill = masks & sel;
+    kill = (kill | (kill >> 8) | (kill >> 16) | (live ? 0u : 0xffu)) & 0xffu;
 #pragma unroll
     for (int i = 0; i < HV; i++) {
-      const int v = tid + i * 256;
-      const int pix = v / CV, cv = v % CV;
-      const int gy = ty0 + pix / HXW - 1, gx = tx0 + pix % HXW - 1;
-      const bool ok = live && v < HW_ * CV && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
-      const unsigned off = ok ? ((unsigned)(gy * P.W + gx) * pixb + (unsigned)(cofs + cv * 8) * 2u) : 0x80000000u;
+      unsigned off = (unsigned)__mul24(rel_pix[i], (int)pixb) + cv_bytes + base;
+      off |= (kill << (31 - i)) & 0x80000000u;
       hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
   };
@@ -116,46 +153,48 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
     }
   };
 
-  int tile = blockIdx.x;
-  if (tile >= P.ntiles) return;
-  // this lane's bias values, read ONCE: a load in the epilogue queues behind the halo prefetches (vector memory returns in order) and made
-  // every tile wait for the chunks it had just requested
-  float bias_r[TN];
-#pragma unroll
-  for (int j = 0; j < TN; j++) bias_r[j] = P.bias ? P.bias[j * 32 + (lane & 31)] : 0.f;
-  // chunk sequence of this (persistent) workgroup: (tile, 0..nch-1), (tile + grid, 0..nch-1), ...
-  auto advance = [&](int& t, int& c) { if (++c == nch) { c = 0; t += (int)gridDim.x; } };
-  w_load(0);
-  halo_load(hregA, tile, 0, true);
+  if ((int)blockIdx.x >= P.ntiles) return;
+  // the bias, read from memory ONCE (a load in the epilogue queues behind the halo prefetches: vector memory returns in order) and kept in
+  // LDS; it starts the accumulators, so the epilogue adds nothing
+  float* bias_s;
   {
-    int t2 = tile, c2 = 0;
-    advance(t2, c2);
-    halo_load(hregB, t2, c2, t2 < P.ntiles);
+    constexpr size_t MAIN_B = (size_t)(W_EL + H_EL) * 2, STG_B = (size_t)128 * STG_LD * 4 + (size_t)4 * COUT * 2 * 4;
+    bias_s = (float*)(smem_raw + (nch == 1 ? MAIN_B + STG_B : (MAIN_B > STG_B ? MAIN_B : STG_B)));
+    if (tid < COUT) bias_s[tid] = P.bias ? P.bias[tid] : 0.f;          // visible after the first install barrier
   }
+  // chunk sequence of this (persistent) workgroup: (tile, 0..nch-1), (tile + grid, 0..nch-1), ...; `cur` = the tile being multiplied,
+  // (`pre`, pre_ch) = the chunk the next halo request is for (two chunks ahead)
+  TileAt cur = tile_at((int)blockIdx.x), pre = cur;
+  int pre_ch = 0;
+  auto pre_advance = [&]() { if (++pre_ch == nch) { pre_ch = 0; tile_next(pre); } };
+  w_load(0);
+  halo_load(hregA, pre, pre_ch); pre_advance();
+  halo_load(hregB, pre, pre_ch); pre_advance();
   bool w_pending = true;
   int ch = 0;
   f32x16 acc[TN];
   // one chunk: install it from `hreg`, refill `hreg` with the chunk after the next one, multiply; the tile's epilogue after its last chunk.
   // Returns false when this workgroup has no further chunk.
   auto step = [&](uint4 (&hreg)[HV]) -> bool {
-    if (ch == 0) {
-#pragma unroll
-      for (int j = 0; j < TN; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
-    }
     {
       halo_store(hreg);
       if (w_pending) w_store();
       __syncthreads();
+      if (ch == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          const float bv = bias_s[j * 32 + (lane & 31)];
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[j][r] = bv;
+        }
+      }
       {
-        int t1 = tile, c1 = ch;
-        advance(t1, c1);                               // next chunk: its weights (one chunk ahead: they come from L2)
-        int t2 = t1, c2 = c1;
-        advance(t2, c2);                               // the chunk after it: its halo
-        if (t1 < P.ntiles && nch > 1) w_load(c1);      // before the halo: the next install waits for the weights only
+        // next chunk: its weights (one chunk ahead: they come from L2), before the halo: the next install waits for the weights only
+        const int c1 = ch + 1 == nch ? 0 : ch + 1;
+        const bool next_live = ch + 1 < nch || cur.tile + (int)gridDim.x < P.ntiles;
+        if (next_live && nch > 1) w_load(c1);
         w_pending = nch > 1;
-        halo_load(hreg, t2, c2, t2 < P.ntiles);
+        halo_load(hreg, pre, pre_ch); pre_advance();    // the chunk after it: its halo
       }
       // ---- 9 taps x CK/16 k-steps ----
 #pragma unroll
@@ -180,16 +219,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
     // accumulator register r of lane l: output pixel (wave*32 + (r&3) + 8*(r>>2) + 4*(l>>5)), channel j*32 + (l&31)
 #pragma unroll
     for (int j = 0; j < TN; j++) {
-      const float bv = bias_r[j];
 #pragma unroll
       for (int r = 0; r < 16; r++)
-        stg[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * STG_LD + j * 32 + (lane & 31)] = acc[j][r] + bv;
+        stg[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * STG_LD + j * 32 + (lane & 31)] = acc[j][r];
     }
     __syncthreads();
     {
-      const int tx0 = (tile % P.tilesX) * TW;
-      const int t2 = tile / P.tilesX;
-      const int ty0 = (t2 % P.tilesY) * TH, b = t2 / P.tilesY;
+      const int tile = cur.tile, tx0 = cur.tx * TW, ty0 = cur.ty * TH, b = cur.b;
       constexpr int C8 = COUT / 8;                     // 16-byte channel vectors per output pixel (4 / 8 / 16)
       // thread = (pixel, channel vector); 256 % C8 == 0, so a thread keeps the same channel vector for all its pixels and can
       // accumulate that vector's statistics (of the bf16-rounded values the norm layer will read) in registers on the way
@@ -237,8 +273,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
     }
     __syncthreads();
     ch = 0;
-    tile += gridDim.x;
-    return tile < P.ntiles;
+    tile_next(cur);
+    return cur.tile < P.ntiles;
   };
   for (;;) {
     if (!step(hregA)) break;
@@ -253,7 +289,7 @@ int launch(const HaloParams& P, hipStream_t st) {
   const int nch = P.Cin / CK;
   const size_t main_bytes = (size_t)(9 * COUT * LD + (TH + 2) * HROW) * 2;
   const size_t stg_bytes = (size_t)128 * (COUT + 4) * 4 + (size_t)4 * COUT * 2 * 4;   // fp32 tile + statistics scratch [4][COUT][2]
-  const size_t lds = nch == 1 ? main_bytes + stg_bytes : (main_bytes > stg_bytes ? main_bytes : stg_bytes);
+  const size_t lds = (nch == 1 ? main_bytes + stg_bytes : (main_bytes > stg_bytes ? main_bytes : stg_bytes)) + (size_t)COUT * 4;   // + bias
   if (lds > 160 * 1024) return DU_ERR_UNSUPPORTED;
   // the halo loads address one image through a 32-bit buffer descriptor whose out-of-range sentinel is offset 2^31
   if ((long)P.H * P.W * (P.ldx > P.ldx2 ? P.ldx : P.ldx2) * 2 >= (1L << 31)) return DU_ERR_UNSUPPORTED;
