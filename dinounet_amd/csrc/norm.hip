@@ -306,7 +306,9 @@ __global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__
 }
 
 // backward pass 1: per-(g,c) sums of dz = dy * act'(z) and dz * xhat over this workgroup's pixels -> partial (or atomics)
-template <typename T>
+// U pixels of this thread are requested together (2 U 16-byte loads in flight per thread): with 2 workgroups per CU the kernel is
+// latency x concurrency bound, not bandwidth bound (U = 2: 2.6 TB/s over the decoder's layers in the dinounet_l step)
+template <typename T, int U>
 __global__ __launch_bounds__(256) void norm_act_bwd_stats_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                                  long lddy, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const float* __restrict__ w,
@@ -332,11 +334,8 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stats_kernel(const T* __rest
       float mu[V], rs[V], wc[V], bc[V];
 #pragma unroll
       for (int j = 0; j < V; j++) { mu[j] = mean[(long)g * C + c0 + j]; rs[j] = rstd[(long)g * C + c0 + j]; wc[j] = w[c0 + j]; bc[j] = b[c0 + j]; }
-#pragma unroll 2
-      for (long p = p0 + tp; p < p1; p += np) {
-        const long pix = (long)g * P + p;
-        Vec16<T> tx = as_vec<T>(*(const uint4*)(x + pix * ldx + c0));
-        Vec16<T> tg = as_vec<T>(*(const uint4*)(dy + pix * lddy + c0));
+      auto one = [&](const uint4& rx, const uint4& rg) {
+        Vec16<T> tx = as_vec<T>(rx), tg = as_vec<T>(rg);
 #pragma unroll
         for (int j = 0; j < V; j++) {
           const float xh = (to_f32(tx.v[j]) - mu[j]) * rs[j];
@@ -344,6 +343,22 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stats_kernel(const T* __rest
           a[j] += dz;
           bb[j] += dz * xh;
         }
+      };
+      long p = p0 + tp;
+      for (; p + (long)(U - 1) * np < p1; p += (long)U * np) {
+        uint4 rx[U], rg[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const long pix = (long)g * P + p + (long)u * np;
+          rx[u] = *(const uint4*)(x + pix * ldx + c0);
+          rg[u] = *(const uint4*)(dy + pix * lddy + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) one(rx[u], rg[u]);
+      }
+      for (; p < p1; p += np) {
+        const long pix = (long)g * P + p;
+        one(*(const uint4*)(x + pix * ldx + c0), *(const uint4*)(dy + pix * lddy + c0));
       }
     }
     lane_reduce<V>(a, bb, cvb, np, tp, tcv, red, cv < cv_total, [&](int j, float sa, float sb) {
@@ -394,6 +409,17 @@ __global__ __launch_bounds__(256) void norm_act_bwd_dx_kernel(const T* __restric
     // 2 x 2 independent 16-byte loads in flight per thread
     const long step = (long)gridDim.x * np;
     long p = (long)blockIdx.x * np + tp;
+    for (; p + 3 * step < P; p += 4 * step) {          // 8 loads in flight per thread (2 workgroups per CU: latency x concurrency bound)
+      uint4 rx[4], rg[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const long pu = (long)g * P + p + u * step;
+        rx[u] = *(const uint4*)(x + pu * ldx + c0);
+        rg[u] = *(const uint4*)(dy + pu * lddy + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) one(rx[u], rg[u], (long)g * P + p + u * step);
+    }
     for (; p + step < P; p += 2 * step) {
       const long pa = (long)g * P + p, pb = pa + step;
       const uint4 xa = *(const uint4*)(x + pa * ldx + c0), xb = *(const uint4*)(x + pb * ldx + c0);
@@ -749,8 +775,11 @@ extern "C" int du_norm_act_bwd_stats(int dtype, const void* x, int64_t ldx, cons
   dim3 grid((unsigned)(G * strips)), block(256);
   if (dtype != DU_BF16 && dtype != DU_F32) return DU_ERR_BAD_ARG;
   return strip_launch(bsums, ws, ws_elems, G, strips, C, st, [&](float* part) {
-    if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_bwd_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, part);
-    else hipLaunchKernelGGL(norm_act_bwd_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, part);
+    static const int deep = getenv("DU_NORM_BWD_UNROLL") ? atoi(getenv("DU_NORM_BWD_UNROLL")) : 4;     // A-B aid: 2 = the round-2 loop
+    if (dtype == DU_BF16) {
+      if (deep >= 4) hipLaunchKernelGGL((norm_act_bwd_stats_kernel<bf16_t, 4>), grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, part);
+      else hipLaunchKernelGGL((norm_act_bwd_stats_kernel<bf16_t, 2>), grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, part);
+    } else hipLaunchKernelGGL((norm_act_bwd_stats_kernel<float, 2>), grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, part);
   });
 }
 
@@ -811,8 +840,11 @@ extern "C" int du_norm_act_bwd_stats_grads(int dtype, const void* x, int64_t ldx
   const long strips = (P + STRIP - 1) / STRIP;
   if (!ws || ws_elems < (long)G * strips * C * 2) return DU_ERR_BAD_ARG;
   dim3 grid((unsigned)(G * strips)), block(256);
-  if (dtype == DU_BF16) hipLaunchKernelGGL(norm_act_bwd_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, ws);
-  else hipLaunchKernelGGL(norm_act_bwd_stats_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, ws);
+  static const int deep = getenv("DU_NORM_BWD_UNROLL") ? atoi(getenv("DU_NORM_BWD_UNROLL")) : 4;     // A-B aid: 2 = the round-2 loop
+  if (dtype == DU_BF16) {
+    if (deep >= 4) hipLaunchKernelGGL((norm_act_bwd_stats_kernel<bf16_t, 4>), grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, ws);
+    else hipLaunchKernelGGL((norm_act_bwd_stats_kernel<bf16_t, 2>), grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, ws);
+  } else hipLaunchKernelGGL((norm_act_bwd_stats_kernel<float, 2>), grid, block, 0, st, (const float*)x, ldx, (const float*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, ws);
   if ((long)C * 2 >= 512) hipLaunchKernelGGL(finalize_grads_kernel<32>, dim3((unsigned)((C * 2 + 31) / 32)), dim3(256), 0, st, (const float*)ws, bsums, G, (int)strips, C * 2, dw, db);
   else hipLaunchKernelGGL(finalize_grads_kernel<4>, dim3((unsigned)((C * 2 + 3) / 4)), dim3(256), 0, st, (const float*)ws, bsums, G, (int)strips, C * 2, dw, db);
   return du_check_launch();

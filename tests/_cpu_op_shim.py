@@ -195,7 +195,69 @@ def qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, workspace):
     return attention(mm(h, w, bias=bias), sin, cos, B, N, H, Dh, prefix, workspace)
 
 
-_NAMES = ["mm", "linear", "linear_cat", "conv1x1_cat", "fapm_project", "conv1x1", "conv2d", "conv2d_stats", "conv_transpose2x2", "norm_act", "layer_norm", "layer_norm_res", "layernorm_raw", "msda_prep", "msda",
+def mm_swiglu(x, w12, b12=None):
+    """silu(x w1^T + b1) * (x w2^T + b2) from the INTERLEAVED projection (rows w1_0, w2_0, w1_1, w2_1, ...), ops.mm_swiglu"""
+    u = x.float() @ w12.float().t()
+    if b12 is not None:
+        u = u + b12.float()
+    return (F.silu(u[:, 0::2]) * u[:, 1::2]).to(x.dtype)
+
+
+def sample_gather(x, idx):
+    return x[idx].clone()
+
+
+def sample_scatter_(x, src, idx):
+    x[idx] = src
+    return x
+
+
+class _ShimSyncBN(torch.autograd.Function):
+    """Training-mode SyncBatchNorm + activation of ONE NHWC tensor with the statistics summed over `group` (ops._SyncBNMulti's contract:
+    global statistics and dx, LOCAL weight / bias gradients -- DDP averages those), running statistics updated with the unbiased variance."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, rm, rv, mom, act, group):
+        import torch.distributed as dist
+        C = x.shape[-1]
+        xf = x.float().reshape(-1, C)
+        st = torch.cat([xf.sum(0), (xf * xf).sum(0), torch.tensor([float(xf.shape[0])])])
+        dist.all_reduce(st, group=group)
+        n = float(st[-1])
+        mean = st[:C] / n
+        var = (st[C:2 * C] / n - mean * mean).clamp_min(0)
+        rstd = (var + eps).rsqrt()
+        if rm is not None:
+            rm.mul_(1 - mom).add_(mom * mean)
+            rv.mul_(1 - mom).add_(mom * var * (n / max(n - 1.0, 1.0)))
+        xh = (xf - mean) * rstd
+        z = xh * w.float() + b.float()
+        ctx.save_for_backward(xh, z, w.float(), rstd)
+        ctx.conf = (act, group, n, x.shape, x.dtype)
+        return _act(z, act).reshape(x.shape).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        xh, z, w, rstd = ctx.saved_tensors
+        act, group, n, shape, dt = ctx.conf
+        C = shape[-1]
+        with torch.enable_grad():
+            zz = z.detach().requires_grad_(True)
+            (dz,) = torch.autograd.grad(_act(zz, act), zz, dy.float().reshape(-1, C))
+        s = torch.cat([dz.sum(0), (dz * xh).sum(0)])
+        dw, db = s[C:].clone(), s[:C].clone()                 # local sums
+        dist.all_reduce(s, group=group)
+        dx = w * rstd * (dz - s[:C] / n - xh * (s[C:] / n))
+        return dx.reshape(shape).to(dt), dw, db, None, None, None, None, None, None
+
+
+def sync_bn_multi(xs, bns, act, group):
+    return [_ShimSyncBN.apply(x, bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1,
+                              act, group) for x, bn in zip(xs, bns)]
+
+
+_NAMES = ["mm_swiglu", "sample_gather", "sample_scatter_", "sync_bn_multi", "mm", "linear", "linear_cat", "conv1x1_cat", "fapm_project", "conv1x1", "conv2d", "conv2d_stats", "conv_transpose2x2", "norm_act", "layer_norm", "layer_norm_res", "layernorm_raw", "msda_prep", "msda",
           "dwconv3x3", "dwconv_tokens", "maxpool3x3s2", "bilinear_add", "bilinear_resize", "squeeze_excite", "nchw_to_nhwc", "nhwc_to_nchw_f32", "patchify16", "cast",
           "attention", "qkv_attention"]
 

@@ -86,3 +86,82 @@ def test_bucketed_allreduce_and_ddp_dice_world2():
     mean_loss = sum(r[2] for r in res) / world
     assert abs(mean_loss - float(l)) < 1e-5
     assert torch.allclose(res[0][3], gref, atol=1e-6)
+
+
+# ---- the CPU stand-ins of the ops a multi-rank adapter / a 7B-style train-mode backbone reach (tests/_cpu_op_shim.py): the SyncBatchNorm
+#      contract over two gloo ranks, the SwiGLU gate from the interleaved projection, the DropPath sample gather / scatter ----
+def _syncbn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _cpu_op_shim as shim
+    from dinounet_amd import ops
+    from dinounet_amd._lib import ACT_RELU
+    g = torch.Generator().manual_seed(5)
+    X = [torch.randn(4, 6, 5, 8, generator=g), torch.randn(4, 3, 3, 16, generator=g)]
+    DY = [torch.randn(4, 6, 5, 8, generator=g), torch.randn(4, 3, 3, 16, generator=g)]
+    torch.manual_seed(7)
+    bns = [nn.BatchNorm2d(8), nn.BatchNorm2d(16)]
+    for bn in bns:
+        nn.init.normal_(bn.weight, 1.0, 0.2); nn.init.normal_(bn.bias, 0.0, 0.2)
+    xs = [x[rank * 2:(rank + 1) * 2].clone().requires_grad_(True) for x in X]
+    with shim.patched_ops():
+        ys = ops.sync_bn_multi(xs, bns, ACT_RELU, None)
+    torch.autograd.backward(ys, [d[rank * 2:(rank + 1) * 2] for d in DY])
+    q.put((rank, [y.detach() for y in ys], [x.grad for x in xs], [bn.weight.grad for bn in bns], [bn.bias.grad for bn in bns],
+           [bn.running_mean.clone() for bn in bns], [bn.running_var.clone() for bn in bns]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_syncbn_stand_in_matches_full_batch_batchnorm_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    g = torch.Generator().manual_seed(5)
+    X = [torch.randn(4, 6, 5, 8, generator=g), torch.randn(4, 3, 3, 16, generator=g)]
+    DY = [torch.randn(4, 6, 5, 8, generator=g), torch.randn(4, 3, 3, 16, generator=g)]
+    torch.manual_seed(7)
+    bns = [nn.BatchNorm2d(8), nn.BatchNorm2d(16)]
+    for bn in bns:
+        nn.init.normal_(bn.weight, 1.0, 0.2); nn.init.normal_(bn.bias, 0.0, 0.2)
+    for j in range(2):
+        x = X[j].clone().requires_grad_(True)
+        y = torch.relu(bns[j](x.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)          # full batch, NCHW module on the NHWC tensor
+        y.backward(DY[j])
+        yy = torch.cat([res[0][1][j], res[1][1][j]], 0)
+        dx = torch.cat([res[0][2][j], res[1][2][j]], 0)
+        assert torch.allclose(yy, y.detach(), atol=1e-5)
+        assert torch.allclose(dx, x.grad, atol=1e-5)
+        assert torch.allclose(res[0][3][j] + res[1][3][j], bns[j].weight.grad, atol=1e-4)    # local sums add up to the full-batch gradient
+        assert torch.allclose(res[0][4][j] + res[1][4][j], bns[j].bias.grad, atol=1e-4)
+        for r in range(2):
+            assert torch.allclose(res[r][5][j], bns[j].running_mean, atol=1e-6)
+            assert torch.allclose(res[r][6][j], bns[j].running_var, atol=1e-6)
+
+
+def test_swiglu_and_sample_copy_stand_ins():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _cpu_op_shim as shim
+    from dinounet_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x, w1, w2 = torch.randn(7, 12, generator=g), torch.randn(10, 12, generator=g), torch.randn(10, 12, generator=g)
+    b1, b2 = torch.randn(10, generator=g), torch.randn(10, generator=g)
+    w12 = torch.stack([w1, w2], 1).reshape(20, 12)
+    b12 = torch.stack([b1, b2], 1).reshape(20)
+    with shim.patched_ops():
+        h = ops.mm_swiglu(x, w12, b12)
+        t = torch.arange(24.0).view(4, 6)
+        idx = torch.tensor([2, 0])
+        sub = ops.sample_gather(t, idx)
+        ops.sample_scatter_(t, sub * 10, idx)
+    assert torch.allclose(h, torch.nn.functional.silu(x @ w1.t() + b1) * (x @ w2.t() + b2), atol=1e-5)
+    assert torch.equal(sub, torch.arange(24.0).view(4, 6)[[2, 0]])
+    assert torch.equal(t[2], torch.arange(12.0, 18.0) * 10) and torch.equal(t[1], torch.arange(6.0, 12.0))

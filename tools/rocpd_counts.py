@@ -12,13 +12,26 @@ import sqlite3
 import sys
 
 
-def steady_period(names, lo=100, hi=4000):
+def steady_period(names, lo=100, hi=4000, max_tail=600):
+    """(period p, tail o): the dispatches [n - o - k p, n - o) are k replayed steps (equal multisets of kernel names per window of p); the
+    last o dispatches are whatever ran after the last replay.  Multisets are compared through sums of per-name random 64-bit values
+    (prefix sums: O(1) per window)."""
+    import random
+    rnd = random.Random(1234)
+    val = {}
+    pre = [0]
+    for nm in names:
+        if nm not in val:
+            val[nm] = rnd.getrandbits(61)
+        pre.append(pre[-1] + val[nm])
     n = len(names)
-    for p in range(lo, min(hi, n // 3) + 1):
-        a = collections.Counter(names[n - p:])
-        if a == collections.Counter(names[n - 2 * p:n - p]) and a == collections.Counter(names[n - 3 * p:n - 2 * p]):
-            return p
-    return 0
+    for p in range(lo, min(hi, n // 4) + 1):
+        for o in range(0, min(max_tail, n - 4 * p) + 1):
+            e = n - o
+            w = pre[e] - pre[e - p]
+            if w == pre[e - p] - pre[e - 2 * p] == pre[e - 2 * p] - pre[e - 3 * p]:
+                return p, o
+    return 0, 0
 
 
 def main():
@@ -26,15 +39,17 @@ def main():
     steps = int(sys.argv[2])
     rows = c.execute("select name, start, end from kernels order by start").fetchall()
     names = [r[0] for r in rows]
-    p = steady_period(names)
+    p, tail = steady_period(names)
     if p:
-        ref = collections.Counter(names[len(names) - p:])
+        e = len(names) - tail
+        ref = collections.Counter(names[e - p:e])
         k = 1
-        while (k + 1) * p <= len(names) and collections.Counter(names[len(names) - (k + 1) * p:len(names) - k * p]) == ref:
+        while (k + 1) * p <= e and collections.Counter(names[e - (k + 1) * p:e - k * p]) == ref:
             k += 1
-        rows = rows[len(rows) - k * p:]
-        print(f"# steady state: {p} dispatches per replayed step (period found over the last {k} steps of the trace; "
-              f"{len(names)} dispatches in the whole trace = {len(names) / steps:.0f} per step with the warm-up's one-time work charged to every step)")
+        rows = rows[e - k * p:e]
+        print(f"# steady state: {p} dispatches per replayed step (period found over the last {k} steps of the trace, {tail} dispatches after "
+              f"them; {len(names)} dispatches in the whole trace = {len(names) / steps:.0f} per step with the warm-up's one-time work charged to "
+              f"every step)")
         steps = k
     else:
         print(f"# no steady period found: {len(names)} dispatches / {steps} steps = {len(names) / steps:.0f} per step (warm-up included)")
