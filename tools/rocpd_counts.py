@@ -6,32 +6,33 @@ The trace of `bench.py` holds the eager warm-up steps (first-use work: weight pa
 steps; dividing everything by the step count charges the one-time work to every step.  So the steady state is found from the trace
 itself: the smallest window length p whose last three windows of p dispatches hold the same multiset of kernel names is one replayed
 step; counts and times are then taken over the trailing run of such windows only.  Falls back to total / <steps> when no period is found.
-usage: python tools/rocpd_counts.py <results.db> <steps in the trace>"""
+usage: python tools/rocpd_counts.py <results.db> <steps in the trace> [--by-time]"""
 import collections
 import sqlite3
 import sys
 
 
-def steady_period(names, lo=100, hi=4000, max_tail=600):
-    """(period p, tail o): the dispatches [n - o - k p, n - o) are k replayed steps (equal multisets of kernel names per window of p); the
-    last o dispatches are whatever ran after the last replay.  Multisets are compared through sums of per-name random 64-bit values
-    (prefix sums: O(1) per window)."""
-    import random
-    rnd = random.Random(1234)
-    val = {}
-    pre = [0]
-    for nm in names:
-        if nm not in val:
-            val[nm] = rnd.getrandbits(61)
-        pre.append(pre[-1] + val[nm])
-    n = len(names)
-    for p in range(lo, min(hi, n // 4) + 1):
-        for o in range(0, min(max_tail, n - 4 * p) + 1):
-            e = n - o
-            w = pre[e] - pre[e - p]
-            if w == pre[e - p] - pre[e - 2 * p] == pre[e - 2 * p] - pre[e - 3 * p]:
-                return p, o
-    return 0, 0
+def steady_period(names):
+    """(period p, tail o): the dispatches [n - o - k p, n - o) are k replayed steps.  The period is the spacing of the kernels that run
+    ONCE per step (the optimizer's kernel, the loss kernels ...): for every kernel name with at least six launches whose last five
+    spacings are equal that spacing is a vote, the most frequent vote wins, and the windows end right after the last launch of one of
+    the voters.  (Comparing multisets of consecutive windows alone is not enough: a network of 24 identical blocks has windows shorter
+    than a step, by whole blocks, that agree several times in a row.)"""
+    pos = collections.defaultdict(list)
+    for i, nm in enumerate(names):
+        pos[nm].append(i)
+    votes = collections.Counter()
+    last = {}
+    for nm, ps in pos.items():
+        if len(ps) >= 6:
+            d = [ps[-j] - ps[-j - 1] for j in range(1, 6)]
+            if min(d) == max(d) and d[0] >= 100:
+                votes[d[0]] += 1
+                last[d[0]] = max(last.get(d[0], 0), ps[-1])
+    if not votes:
+        return 0, 0
+    p = votes.most_common(1)[0][0]
+    return p, len(names) - (last[p] + 1)
 
 
 def main():
@@ -59,8 +60,9 @@ def main():
         a[0] += 1
         a[1] += e - s
     tot_ns = sum(v[1] for v in agg.values())
-    print(f"# kernel time {tot_ns / steps / 1e6:.3f} ms per step; kernels sorted by launch count")
-    for n, (k_, ns) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
+    by_time = "--by-time" in sys.argv
+    print(f"# kernel time {tot_ns / steps / 1e6:.3f} ms per step; kernels sorted by {'time' if by_time else 'launch count'}")
+    for n, (k_, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1 if by_time else 0])[:70]:
         print(f"{k_ / steps:7.1f}/step {ns / k_ / 1e3:8.2f} us avg {ns / steps / 1e6:7.3f} ms/step  {n[:110]}")
 
 
