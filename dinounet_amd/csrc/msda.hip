@@ -388,7 +388,46 @@ __global__ __launch_bounds__(256) void msda_gv_finalize_kernel(const float* __re
 // (any offset pattern stays correct).  A 64-column double-buffered variant (one barrier per step) measured slower: the per-step
 // scatter + barrier cost, not the barrier count, paces the loop.
 // ------------------------------------------------------------------------------------------------------
+// Round 3: most K steps touch nothing.  A workgroup owns 512 consecutive plane pixels (8 rows of the 64 x 64 level) but walked ALL
+// Lq / 32 query blocks -- scatter arithmetic + a 16-wave barrier each -- although a query samples around its own reference point: ~33 of
+// the 168 blocks of the dinounet_l adapter reach a given 8-row tile.  msda_gv_rows_kernel records, per (batch, head, 32-query block), the
+// first and last plane row any of its 128 samples can touch (exact bilinear support, empty = 0xffff / 0); the product kernel builds the
+// ordered list of the blocks whose rows meet its tile and walks only those.  Skipping is decided on exact bounds, so results are
+// unchanged for any offsets (a model with far-reaching offsets simply skips less).
+__global__ __launch_bounds__(256) void msda_gv_rows_kernel(const int64_t* __restrict__ shapes, const float* __restrict__ loc,
+                                                           unsigned* __restrict__ rows, int N, int M, int Lq, int nblk) {
+  // workgroup = one (batch, 32-query block), all heads: a query's locations of all heads and points are one contiguous M * 32-byte run,
+  // so thread (query, head) reads its 4 points as two 16-byte loads next to its neighbours'; per-head min / max through LDS atomics
+  __shared__ int lo_s[64], hi_s[64];
+  const int Hs = (int)shapes[0], Ws = (int)shapes[1];
+  const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  for (int i = threadIdx.x; i < M; i += 256) { lo_s[i] = 0xffff; hi_s[i] = -1; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * M; i += 256) {
+    const int m = i % M, q = blk * 32 + i / M;
+    if (q >= Lq) break;
+    const float4* lp = (const float4*)(loc + (((long)b * Lq + q) * M + m) * 8);
+    const float4 l0 = lp[0], l1 = lp[1];
+    const float xs[4] = {l0.x, l0.z, l1.x, l1.z}, ys[4] = {l0.y, l0.w, l1.y, l1.w};
+    int lo = 0xffff, hi = -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float h = ys[k] * Hs - 0.5f, w = xs[k] * Ws - 0.5f;
+      if (h > -1.f && w > -1.f && h < (float)Hs && w < (float)Ws) {
+        const int h0 = (int)floorf(h);
+        lo = min(lo, h0 < 0 ? 0 : h0); hi = max(hi, h0 + 1 > Hs - 1 ? Hs - 1 : h0 + 1);
+      }
+    }
+    if (hi >= 0) { atomicMin(&lo_s[m], lo); atomicMax(&hi_s[m], hi); }
+  }
+  __syncthreads();
+  for (int m = threadIdx.x; m < M; m += 256)
+    rows[((long)b * M + m) * nblk + blk] = hi_s[m] < 0 ? 0xffffu : ((unsigned)lo_s[m] | ((unsigned)hi_s[m] << 16));
+}
+
 constexpr int GV_PT = 512;        // plane pixels per workgroup
+template <int N_> struct GvSlot { static constexpr int value = N_; };
+constexpr int GV_MAXBLK = 1024;   // query blocks per chunk the skip list holds (more: every block is walked)
 constexpr int GV_KQ = 32;         // queries per K step
 constexpr int GV_WLD = 128 + 8;   // W row pitch (bf16): 272 B, conflict-free ds_read_b128 fragments
 constexpr int GV_GLD = 128 + 8;
@@ -396,9 +435,12 @@ constexpr int GV_GLD = 128 + 8;
 __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __restrict__ gout, const int64_t* __restrict__ shapes,
                                                             const float* __restrict__ loc, const float* __restrict__ attn,
                                                             float* __restrict__ gvalue, int N, int S, int M, int D, int Lq,
-                                                            int q_per_chunk, int tiles, long chunk_stride, int out_bf16) {
+                                                            int q_per_chunk, int tiles, long chunk_stride, int out_bf16,
+                                                            const unsigned* __restrict__ rows, int nblk_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ unsigned step_mask[3];
+  __shared__ unsigned short need[GV_MAXBLK];
+  __shared__ int wave_cnt[16];
   bf16_t* Wl = (bf16_t*)smem_raw;                       // [GV_PT][GV_WLD]
   bf16_t* Gt = Wl + GV_PT * GV_WLD;                     // [32 channels][GV_GLD]   (G^T: k contiguous)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -419,40 +461,70 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
   const int q1 = min(Lq, q0 + q_per_chunk);
   for (int i = tid; i < (GV_PT * GV_WLD + 32 * GV_GLD) / 8; i += 1024) ((uint4*)Wl)[i] = make_uint4(0, 0, 0, 0);
   if (tid < 3) step_mask[tid] = 0u;
-  __syncthreads();
-
-  f32x16 acc;
+  // ---- ordered list of the query blocks of this chunk whose rows meet this tile (thread t = block t of the chunk) ----
+  const int nblk = (q1 - q0 + GV_KQ - 1) / GV_KQ;
+  const bool listed = rows != nullptr && nblk <= GV_MAXBLK;
+  int nneed = nblk;
+  if (listed) {
+    bool want = false;
+    if (tid < nblk) {
+      const unsigned r = rows[((long)b * M + m) * nblk_all + q0 / GV_KQ + tid];
+      const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
+      // pixels the block can touch: [lo * Ws, hi * Ws + Ws - 1]; this tile: [pix0, pix0 + GV_PT - 1]
+      want = lo != 0xffff && lo * Ws <= pix0 + GV_PT - 1 && hi * Ws + Ws - 1 >= pix0;
+    }
+    const unsigned long long bal = __ballot(want);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int base = 0, total = 0;
 #pragma unroll
-  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    for (int w2 = 0; w2 < 16; w2++) { const int c2 = wave_cnt[w2]; if (w2 < wave) base += c2; total += c2; }
+    if (want) need[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+    nneed = total;
+  }
+  __syncthreads();
+  auto block_q = [&](int i) { return q0 + (listed ? (int)need[i] : i) * GV_KQ; };
+
+  f32x16 acc, acc2;          // even / odd k-steps: two chains of 4 dependent MFMAs instead of one of 8 (only the 2-3 touched waves work in
+                             // a step, so the chain latency is the step's MFMA phase)
+#pragma unroll
+  for (int r = 0; r < 16; r++) { acc[r] = 0.f; acc2[r] = 0.f; }
   // scatter role (threads 0..511): column col = (query ql, point p), one bilinear corner each
   const int col = tid >> 2, corner = tid & 3;
   const int ql_s = col >> 2, p_s = col & 3;
   // G role (all threads): query ql_g, channel c_g
   const int ql_g = tid >> 5, c_g = tid & 31;
   int my_off = -1;
-  // the per-step operands (sampling location, attention weight, grad_out element) are fetched one step ahead: the loads of step s+1 are in
-  // flight while step s is scattered and multiplied, so their HBM/L2 latency is off the critical path of the barrier-paced loop
-  float lx_n = 0.f, ly_n = 0.f, a_n = 0.f; bf16_t g_n = (bf16_t)0.f;
-  auto fetch = [&](int qs) {
-    lx_n = -4.f; ly_n = -4.f; a_n = 0.f; g_n = (bf16_t)0.f;
-    if (tid < 512) {
-      const int q = qs + ql_s;
-      if (q < q1) {
-        const long pr = ((long)b * Lq + q) * M + m;
-        const float2 l2 = *(const float2*)(loc + (pr * 4 + p_s) * 2);
-        lx_n = l2.x; ly_n = l2.y;
-        a_n = attn[pr * 4 + p_s];
-      }
-    }
-    const int qg = qs + ql_g;
-    if (qg < q1 && c_g < D) g_n = gout[(((long)b * Lq + qg) * M + m) * D + c_g];
+  // the per-step operands (sampling location, attention weight, grad_out element) are fetched THREE steps ahead into a ring of three
+  // register sets (round 3: a step is ~1 us, about one L2 / HBM latency -- with one step of prefetch every step began by waiting for its
+  // own operands).  The step body exists three times, one per set, so set indices are static and the compiler's vmcnt stays counted.
+  float lx_r[3] = {0.f, 0.f, 0.f}, ly_r[3] = {0.f, 0.f, 0.f}, a_r[3] = {0.f, 0.f, 0.f};
+  bf16_t g_r[3] = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+  // every thread issues the same three loads in every fetch (clamped addresses; validity is applied when the values are used): with
+  // loads under divergent or wave-dependent conditions the number of younger loads differs by path and the compiler falls back to
+  // s_waitcnt vmcnt(0) in front of every use -- which drains the ring
+  auto fetch = [&](auto slot, int qs) {
+    constexpr int SL = decltype(slot)::value;
+    const int q = min(qs + ql_s, Lq - 1);
+    const long pr = ((long)b * Lq + q) * M + m;
+    const float2 l2 = *(const float2*)(loc + (pr * 4 + p_s) * 2);
+    lx_r[SL] = l2.x; ly_r[SL] = l2.y;
+    a_r[SL] = attn[pr * 4 + p_s];
+    const int qg = min(qs + ql_g, Lq - 1);
+    g_r[SL] = gout[(((long)b * Lq + qg) * M + m) * D + min(c_g, D - 1)];
   };
-  fetch(q0);
-  int par = 0;     // step index mod 3: three masks rotate so that a mask is cleared a full step before its next writers
-  for (int qs = q0; qs < q1; qs += GV_KQ, par = (par == 2 ? 0 : par + 1)) {
-    const float lx = lx_n, ly = ly_n, a = a_n;
-    const bf16_t gval = g_n;
-    if (qs + GV_KQ < q1) fetch(qs + GV_KQ);
+  auto block_q_or_end = [&](int i) { return i < nneed ? block_q(i) : q1; };
+  fetch(GvSlot<0>{}, block_q_or_end(0));
+  fetch(GvSlot<1>{}, block_q_or_end(1));
+  fetch(GvSlot<2>{}, block_q_or_end(2));
+  // one K step on register set / step mask SL (= step % 3: three masks rotate so that a mask is cleared a full step before its next writers)
+  auto do_step = [&](auto slot, int step) {
+    constexpr int par = decltype(slot)::value;
+    const int qs = block_q(step);
+    const bool ok_s = qs + ql_s < q1, ok_g = qs + ql_g < q1 && c_g < D;
+    const float lx = ok_s ? lx_r[par] : -4.f, ly = ok_s ? ly_r[par] : -4.f, a = ok_s ? a_r[par] : 0.f;
+    const bf16_t gval = ok_g ? g_r[par] : (bf16_t)0.f;
+    fetch(slot, block_q_or_end(step + 3));
     if (tid < 512) {                                   // waves 0..7 (wave-uniform)
       float wv = 0.f; int woff = -1; unsigned blk = 0u;
       const float h = ly * Hs - 0.5f, w = lx * Ws - 0.5f;
@@ -496,12 +568,27 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
         for (int kk = 0; kk < 8; kk++) {
           bf16x8 fa = *(const bf16x8*)(Wl + (wave * 32 + (lane & 31)) * GV_WLD + kk * 16 + (lane >> 5) * 8);
           bf16x8 fb = *(const bf16x8*)(Gt + (lane & 31) * GV_GLD + kk * 16 + (lane >> 5) * 8);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+          if (kk & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc2, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
         }
       }
       __syncthreads();                                 // W / G^T are rewritten by the next step (nobody read them if nothing was touched)
     }
+  };
+  // whole triples unconditionally (a conditional copy inside the loop makes the number of loads younger than a set path-dependent and
+  // the compiler's waits collapse towards vmcnt(0)); the last one or two steps peeled
+  int step = 0;
+  for (; step + 3 <= nneed; step += 3) {
+    do_step(GvSlot<0>{}, step);
+    do_step(GvSlot<1>{}, step + 1);
+    do_step(GvSlot<2>{}, step + 2);
   }
+  if (step < nneed) {
+    do_step(GvSlot<0>{}, step);
+    if (step + 1 < nneed) do_step(GvSlot<1>{}, step + 1);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] += acc2[r];
   // lane: channel (lane & 31), pixels (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32-pixel block
   const int c = lane & 31;
   if (c < D) {
@@ -821,8 +908,15 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
           if (hipFuncSetAttribute((const void*)msda_gv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return DU_ERR_LAUNCH;
           attr_set = true;
         }
+        // rows table of the query blocks (behind the chunk partials in the workspace); without room for it every block is walked
+        const int nblk_all = (Lq + GV_KQ - 1) / GV_KQ;
+        const long tab_off = nchunk > 1 ? (long)nchunk * plane_all : 0, tab_n = (long)N * M * nblk_all;
+        static const bool no_skip = getenv("DU_MSDA_GV_NO_SKIP") != nullptr;      // debugging / A-B aid
+        unsigned* rows = (!no_skip && M <= 64 && ws && ws_elems >= tab_off + tab_n) ? (unsigned*)(ws + tab_off) : nullptr;
+        if (rows)
+          hipLaunchKernelGGL(msda_gv_rows_kernel, dim3((unsigned)(N * nblk_all)), dim3(256), 0, st, shapes, loc, rows, N, M, Lq, nblk_all);
         hipLaunchKernelGGL(msda_gv_mfma_kernel, dim3(nchunk, N * M * tiles), dim3(1024), lds_bytes, st, (const bf16_t*)gout, shapes, loc, attn,
-                           dstp, N, S, M, D, Lq, qpc, tiles, cstride, (gv_bf16 && nchunk == 1) ? 1 : 0);
+                           dstp, N, S, M, D, Lq, qpc, tiles, cstride, (gv_bf16 && nchunk == 1) ? 1 : 0, (const unsigned*)rows, nblk_all);
         if (nchunk > 1) {
           const long n4 = plane_all / 4;
           long g = (n4 + 255) / 256; if (g > 4096) g = 4096;
@@ -881,15 +975,17 @@ extern "C" int64_t du_msda_bwd_ws_elems(int N, int S, int M, int D, int L, int L
   const int cpt = D % 4 == 0 ? 4 : 1;
   int LPP = next_pow2((D + cpt - 1) / cpt);
   if (LPP > 64) LPP = 64;
-  if ((size_t)S * D * sizeof(float) > 144 * 1024 || L * P > 8) return 0;
-  int nchunk, qpc;
-  lds_chunking(N, M, Lq, LPP, &nchunk, &qpc);
+  // rows table of msda_gv_rows_kernel (MFMA grad_value path: bf16, single level, 4 points, D <= 32), behind the chunk partials
+  const int64_t tab = (L == 1 && P == 4 && D <= 32) ? (int64_t)N * M * ((Lq + GV_KQ - 1) / GV_KQ) : 0;
+  if (L * P > 8) return tab;
+  int nchunk = 1, qpc;
+  if ((size_t)S * D * sizeof(float) <= 144 * 1024) lds_chunking(N, M, Lq, LPP, &nchunk, &qpc);
   // MFMA grad_value path (bf16, single level, 4 points): query chunks so that ~256 workgroups exist
   const int tiles = (S + GV_PT - 1) / GV_PT;
   int nc2 = (int)((256 + (long)N * M * tiles - 1) / ((long)N * M * tiles));
   if (nc2 > 16) nc2 = 16;
   if (nc2 > nchunk) nchunk = nc2;
-  return nchunk > 1 ? (int64_t)nchunk * N * S * M * D : 0;
+  return (nchunk > 1 ? (int64_t)nchunk * N * S * M * D : 0) + tab;
 }
 
 extern "C" int du_msda_backward(int dtype, const void* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
