@@ -791,6 +791,36 @@ def test_msda_bf16_mfma_grad_value_odd_planes(N, Hs, Ws, Lq, Dh):
     assert rel(gv, gvr) < 2e-2 and rel(ga, gar) < 2e-2 and rel(gl, glr) < 1e-1
 
 
+@pytest.mark.parametrize("N,Hs,Ws,Lq,Dh,spread", [(2, 32, 32, 2048, 32, 0.04), (1, 40, 28, 900, 32, 0.10), (2, 64, 64, 1100, 16, 0.02)])
+def test_msda_bf16_grad_value_skips_only_blocks_that_cannot_reach_a_tile(N, Hs, Ws, Lq, Dh, spread):
+    """Round 3: the grad_value kernel walks only the 32-query blocks whose samples can reach its 512-pixel tile (msda_gv_rows_kernel).
+    Localised sampling as in the adapter (a query samples around its own reference point, raster order) makes most blocks skippable;
+    some queries are sent far outside the plane (blocks with NO valid sample), some far from their reference point (blocks reaching
+    several tiles).  Results must match the oracle as with any other locations."""
+    from dinounet_amd import ops
+    from oracle import dinounet_oracle as O
+    d = dev()
+    dt = torch.bfloat16
+    S, M, P = Hs * Ws, 16, 4
+    g = torch.Generator().manual_seed(21)
+    v = q(gen(N, S, M, Dh, seed=22), dt)
+    ref_y = ((torch.arange(Lq) * Hs * Ws // Lq) // Ws).float().add(0.5) / Hs          # raster-ordered reference points
+    ref_x = ((torch.arange(Lq) * Hs * Ws // Lq) % Ws).float().add(0.5) / Ws
+    loc = torch.stack([ref_x, ref_y], -1).view(1, Lq, 1, 1, 1, 2) + (torch.rand(N, Lq, M, 1, P, 2, generator=g) - 0.5) * 2 * spread
+    loc[:, 64:128] = 3.0                                                               # two whole blocks outside the plane
+    loc[:, 300:305] = torch.rand(N, 5, M, 1, P, 2, generator=g)                        # a few queries that sample anywhere
+    a = torch.softmax(gen(N, Lq, M, 1, P, seed=23), -1)
+    go = q(gen(N, Lq, M * Dh, seed=24), dt)
+    gvr, glr, gar = O.msda_backward(v, [(Hs, Ws)], loc, a, go)
+    shapes, lsi = torch.tensor([[Hs, Ws]], device=d), torch.zeros(1, dtype=torch.long, device=d)
+    vg, lg, ag = v.to(d, dt).requires_grad_(True), loc.to(d).requires_grad_(True), a.to(d).requires_grad_(True)
+    out = ops.msda(vg, shapes, lsi, lg, ag)
+    gv, gl, ga = torch.autograd.grad(out, (vg, lg, ag), go.to(d, dt))
+    assert rel(gv, gvr) < 2e-2 and rel(ga, gar) < 2e-2 and rel(gl, glr) < 1e-1
+    # every plane pixel no sample reaches keeps an exactly zero gradient (a skipped block must not leave stale products behind)
+    assert bool((gv.float().cpu()[gvr == 0] == 0).all())
+
+
 def test_msda_prep_fwd_bwd():
     from dinounet_amd import ops
     d = dev()
