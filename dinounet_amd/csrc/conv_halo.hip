@@ -250,22 +250,30 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloParams P) {
         *(uint4*)(P.y + (((long)b * P.H + oy) * P.W + ox) * P.ldy + c8 * 8) = as_u4(o);
       }
       if (P.stats_part) {
-        float* red = stg + 128 * STG_LD;               // [4 waves][COUT][2]
-#pragma unroll
-        for (int e = 0; e < 8; e++)
-          for (int o2 = C8; o2 < 64; o2 <<= 1) { s1[e] += __shfl_xor(s1[e], o2, 64); s2[e] += __shfl_xor(s2[e], o2, 64); }
-        if (lane < C8) {
+        // lanes that share a channel vector sit C8 apart: inside the 16-lane rows they are combined by DPP row shifts (full-rate VALU,
+        // out-of-row sources read 0), the 16 row results of the workgroup through LDS.  (The xor-shuffle tree this replaces was 48-64
+        // ds_bpermute + as many adds and waits per tile -- a tenth of the tile program, §6.38 -- and the reason the 32-channel layers
+        // took their statistics from a separate pass over the tensor.)
+        if constexpr (C8 <= 8) {
 #pragma unroll
           for (int e = 0; e < 8; e++) {
-            red[((wave * COUT) + lane * 8 + e) * 2] = s1[e];
-            red[((wave * COUT) + lane * 8 + e) * 2 + 1] = s2[e];
+            if constexpr (C8 == 4) { s1[e] += DU_DPP_F32(s1[e], 0x114); s2[e] += DU_DPP_F32(s2[e], 0x114); }      // row_shr:4
+            s1[e] += DU_DPP_F32(s1[e], 0x118); s2[e] += DU_DPP_F32(s2[e], 0x118);                                   // row_shr:8
           }
+        }
+        __syncthreads();                               // every thread has read its part of the staged tile: reuse it
+        float* part = stg;                             // [16 = wave * 4 + row][COUT][2]
+        if ((lane & 15) >= 16 - C8) {
+          const int slot = wave * 4 + (lane >> 4);
+#pragma unroll
+          for (int e = 0; e < 8; e += 2)
+            *(float4*)(part + ((slot * COUT) + c8 * 8 + e) * 2) = make_float4(s1[e], s2[e], s1[e + 1], s2[e + 1]);
         }
         __syncthreads();
         if (tid < COUT) {
           float t1 = 0.f, t2s = 0.f;
 #pragma unroll
-          for (int q2 = 0; q2 < 4; q2++) { t1 += red[(q2 * COUT + tid) * 2]; t2s += red[(q2 * COUT + tid) * 2 + 1]; }
+          for (int q2 = 0; q2 < 16; q2++) { t1 += part[(q2 * COUT + tid) * 2]; t2s += part[(q2 * COUT + tid) * 2 + 1]; }
           P.stats_part[((long)tile * COUT + tid) * 2] = t1;
           P.stats_part[((long)tile * COUT + tid) * 2 + 1] = t2s;
         }

@@ -922,6 +922,11 @@ def conv_wgrad(x, dy, KH, KW, stride, pad, x2=None, with_db=False):
     return out, colsum(dy.view(-1, dy.shape[-1]))
 
 
+# statistics of 32-channel outputs from the convolution's own epilogue too (round 3: the epilogue reduction is DPP row shifts now, cheap
+# enough that the separate statistics pass over the 134 MB tensors of the 512^2 stages costs more); DINOUNET_CONV_STATS32=0: A-B aid
+_STATS32 = os.environ.get("DINOUNET_CONV_STATS32", "1") != "0"
+
+
 class _Conv2d(torch.autograd.Function):
     """Conv2d on NHWC, optional second input = fused channel concat (dinounet_training.py:614).  With want_stats the forward also
     returns the per-tile partial channel statistics of the output (emitted by the LDS-tiled kernel's epilogue) so the following
@@ -938,7 +943,7 @@ class _Conv2d(torch.autograd.Function):
         if KH == 3 and KW == 3 and stride == 1 and pad == 1:
             # the epilogue statistics pay off from 64 output channels up (measured: +35 us on the 32-channel 512^2 layers, where the
             # separate statistics pass costs ~30 us; -10 us on the 64/128-channel ones)
-            r = conv3x3_halo(x, wp, _f32(bias), x2, want_stats and w.shape[0] >= 64)
+            r = conv3x3_halo(x, wp, _f32(bias), x2, want_stats and (w.shape[0] >= 64 or _STATS32))
         if r is not None:
             y, part = r
         else:

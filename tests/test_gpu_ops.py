@@ -1027,13 +1027,7 @@ def test_conv3x3_halo_kernel_fwd_bwd_stats(B, H, W, C1, C2, Cout):
     x2g = x2.to(d, dt).requires_grad_(True) if C2 else None
     wg, bg = w.to(d).requires_grad_(True), bias.to(d).requires_grad_(True)
     y, part = ops.conv2d_stats(xg, wg, bg, 1, 1, x2g)
-    if Cout < 64:
-        assert part is None
-        from dinounet_amd import ops as _o
-        r_ = _o.conv3x3_halo(xg.detach(), _o.pack_conv_weight(wg.detach(), dt), bg.detach(), None if x2g is None else x2g.detach(), True)
-        assert r_ is not None
-        part = r_[1]
-    assert part is not None, "shape should be served by the halo kernel"
+    assert part is not None, "shape should be served by the halo kernel, statistics included (32-channel outputs too since round 3)"
     y.backward(go.to(d, dt))
     tol = TOL[dt]
     assert rel(y, yr) < tol
