@@ -1413,7 +1413,144 @@ __global__ __launch_bounds__(256) void film_bwd_kernel(const T* __restrict__ dz,
     *(uint4*)(dz2 + row * 2 * R + R + c0) = as_u4(os);
   }
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Segmentation head: the U-Net's last layer, a 1 x 1 convolution from 32 channels to K <= 4 classes on the full-resolution feature map
+// (seg_layers[-1], dinounet_training.py:603-629 / nnU-Net UNetDecoder), logits in fp32 NCHW for the loss.  As a GEMM (M = 2 M pixels,
+// N = K padded to 8, contraction 32) + an NHWC -> NCHW pass it ran at 1.3 TB/s (99 + ~25 us), its data / weight gradients as two more
+// products (73 + 85 us) behind a pad-and-transpose of dlogits.  It is a stream: one thread per pixel.
+//   forward : logits[b][k][p] = bias[k] + sum_c x[b][p][c] * bf16(w[k][c])          reads x once, writes K planes
+//   backward: dx[b][p][c] = sum_k dl[b][k][p] * bf16(w[k][c]);  dw[k][c] = sum_p dl * x;  db[k] = sum_p dl        ONE pass over x
+// (weights rounded to the activation dtype as autocast does; dlogits stay fp32).  Weight-gradient partials per workgroup -> du_strip_finalize.
+// ------------------------------------------------------------------------------------------------------
+constexpr int SEG_C = 32;
+template <int K>
+__global__ __launch_bounds__(256) void seg_head_fwd_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, long HW, long total) {
+  __shared__ float ws[K * SEG_C + K];
+  for (int i = threadIdx.x; i < K * SEG_C; i += 256) ws[i] = (float)(bf16_t)w[i];
+  if (threadIdx.x < K) ws[K * SEG_C + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
+    uint4 r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) r[j] = *(const uint4*)(x + p * ldx + j * 8);
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) acc[k] = ws[K * SEG_C + k];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const Vec16<bf16_t> v = as_vec<bf16_t>(r[j]);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float xv = (float)v.v[e];
+#pragma unroll
+        for (int k = 0; k < K; k++) acc[k] = fmaf(xv, ws[k * SEG_C + j * 8 + e], acc[k]);
+      }
+    }
+    const long b = p / HW, q = p - b * HW;
+#pragma unroll
+    for (int k = 0; k < K; k++) out[(b * K + k) * HW + q] = acc[k];
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void seg_head_bwd_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                           const float* __restrict__ dl, bf16_t* __restrict__ dx, long lddx,
+                                                           float* __restrict__ part, long HW, long total) {
+  constexpr int NW = K * SEG_C + K, NWP = (NW + 1) & ~1;          // partial rows padded to an even length (du_strip_finalize sums pairs)
+  __shared__ float ws[K * SEG_C];
+  __shared__ float red[4][NWP];
+  for (int i = threadIdx.x; i < K * SEG_C; i += 256) ws[i] = (float)(bf16_t)w[i];
+  __syncthreads();
+  float gw[K][SEG_C], gb[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    gb[k] = 0.f;
+#pragma unroll
+    for (int c = 0; c < SEG_C; c++) gw[k][c] = 0.f;
+  }
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
+    const long b = p / HW, q = p - b * HW;
+    float g[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { g[k] = dl[(b * K + k) * HW + q]; gb[k] += g[k]; }
+    uint4 r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) r[j] = *(const uint4*)(x + p * ldx + j * 8);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const Vec16<bf16_t> v = as_vec<bf16_t>(r[j]);
+      Vec16<bf16_t> o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float xv = (float)v.v[e];
+        float d = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          d = fmaf(g[k], ws[k * SEG_C + j * 8 + e], d);
+          gw[k][j * 8 + e] = fmaf(g[k], xv, gw[k][j * 8 + e]);
+        }
+        o.v[e] = (bf16_t)d;
+      }
+      if (dx) *(uint4*)(dx + p * lddx + j * 8) = as_u4(o);
+    }
+  }
+  // workgroup partial of (dw, db): wave sums, then the 4 waves through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+#pragma unroll
+    for (int c = 0; c < SEG_C; c++) {
+      const float t = wave_sum(gw[k][c]);
+      if (lane == 0) red[wave][k * SEG_C + c] = t;
+    }
+    const float tb = wave_sum(gb[k]);
+    if (lane == 0) red[wave][K * SEG_C + k] = tb;
+  }
+  if (NWP != NW && threadIdx.x < 4) red[threadIdx.x][NW] = 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < NWP; i += 256) part[(long)blockIdx.x * NWP + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
 }  // namespace
+
+// x (B, HW, 32) bf16 NHWC with pixel stride ldx; w (K, 32) fp32, bias (K) fp32 or null; out (B, K, HW) fp32.  K in 1..4.
+extern "C" int du_seg_head_fwd(const void* x, int64_t ldx, const float* w, const float* bias, float* out, int B, int64_t HW, int C, int K,
+                               void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!x || !w || !out || B <= 0 || HW <= 0) return DU_ERR_BAD_ARG;
+  if (C != SEG_C || K < 1 || K > 4 || ldx % 8 || (((uintptr_t)x) & 15)) return DU_ERR_UNSUPPORTED;
+  const long total = (long)B * HW;
+  long g = (total + 255) / 256; if (g > 256 * 16) g = 256 * 16;
+#define SEG_FWD(K_) hipLaunchKernelGGL((seg_head_fwd_kernel<K_>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)x, (long)ldx, w, bias, out, (long)HW, total)
+  switch (K) { case 1: SEG_FWD(1); break; case 2: SEG_FWD(2); break; case 3: SEG_FWD(3); break; default: SEG_FWD(4); break; }
+#undef SEG_FWD
+  return du_check_launch();
+}
+// number of fp32 partial rows du_seg_head_bwd writes (each K * 32 + K floats rounded up to even): the caller's scratch must hold that many
+extern "C" int du_seg_head_bwd_blocks(int B, int64_t HW) {
+  const long total = (long)B * HW;
+  long g = (total + 255) / 256; if (g > 1024) g = 1024;
+  return (int)g;
+}
+// dl (B, K, HW) fp32; dx (B, HW, 32) bf16 with pixel stride lddx (nullable: weight / bias gradients only); part: du_seg_head_bwd_blocks x
+// (K * 33 rounded up to even) fp32 scratch; dwb (K * 33 rounded up to even) fp32 OVERWRITTEN: dw (K, 32) then db (K).
+extern "C" int du_seg_head_bwd(const void* x, int64_t ldx, const float* w, const float* dl, void* dx, int64_t lddx, float* part, float* dwb,
+                               int B, int64_t HW, int C, int K, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!x || !w || !dl || !part || !dwb || B <= 0 || HW <= 0) return DU_ERR_BAD_ARG;
+  if (C != SEG_C || K < 1 || K > 4 || ldx % 8 || (dx && lddx % 8) || ((((uintptr_t)x) | ((uintptr_t)dx)) & 15)) return DU_ERR_UNSUPPORTED;
+  const long total = (long)B * HW;
+  const int g = du_seg_head_bwd_blocks(B, HW);
+#define SEG_BWD(K_) hipLaunchKernelGGL((seg_head_bwd_kernel<K_>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)x, (long)ldx, w, dl, (bf16_t*)dx, (long)lddx, part, (long)HW, total)
+  switch (K) { case 1: SEG_BWD(1); break; case 2: SEG_BWD(2); break; case 3: SEG_BWD(3); break; default: SEG_BWD(4); break; }
+#undef SEG_BWD
+  int rc = du_check_launch();
+  if (rc != DU_OK) return rc;
+  const int n = (K * SEG_C + K + 1) & ~1;
+  return du_strip_finalize(part, dwb, 1, g, n / 2, stream);
+}
+
 
 extern "C" int du_film_fwd(int dtype, const void* gb, const void* z2, void* z, int64_t rows, int R, void* stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -324,6 +324,10 @@ class UNetDecoder(nn.Module):
                 # the K-class head runs as a GEMM with its output columns zero-padded to a multiple of 8 (16-byte rows for the
                 # vectorised dgrad/wgrad loads); the logits are the first K columns, in fp32
                 K = sl.weight.shape[0]
+                if ops.seg_head_ok(x, K):                   # 32 channels -> <= 4 classes: one streaming pass, NCHW fp32 logits directly
+                    segs.append(ops.seg_head(x, sl.weight, sl.bias))
+                    lres = x
+                    continue
                 Kp = (K + 7) // 8 * 8
                 w8 = torch.nn.functional.pad(sl.weight.flatten(1), (0, 0, 0, Kp - K))
                 b8 = torch.nn.functional.pad(sl.bias, (0, Kp - K))

@@ -2014,6 +2014,61 @@ def nhwc_to_nchw_f32(x):
     return _ToNCHW.apply(x)
 
 
+class _SegHead(torch.autograd.Function):
+    """The decoder's last 1x1 convolution (32 channels -> K <= 4 classes, seg_layers[-1]: dinounet_training.py:603-629) as ONE streaming
+    pass: bf16 NHWC features -> fp32 NCHW logits; backward = ONE pass over the features for dx, dw and db (du_seg_head_*)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        B, H, W, Cc, ld = _nhwc(x)
+        K = w.shape[0]
+        wf = _f32(w).reshape(K, Cc).contiguous()
+        out = torch.empty((B, K, H, W), dtype=torch.float32, device=x.device)
+        e0 = PROFILE.start() if PROFILE is not None else None
+        _lib.check(_lib.lib().du_seg_head_fwd(_p(x), ld, _p(wf), _p(_f32(b)) if b is not None else None, _p(out), B, H * W, Cc, K, _st()),
+                   "du_seg_head_fwd")
+        if PROFILE is not None:
+            PROFILE.stop("seg_head_fwd_kernel<bf16>", e0, 2.0 * B * H * W * Cc * K, 2.0 * B * H * W * Cc + 4.0 * B * H * W * K)
+        ctx.save_for_backward(x, wf)
+        ctx.meta = (w.shape, b is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dl):
+        x, wf = ctx.saved_tensors
+        w_shape, has_b = ctx.meta
+        B, H, W, Cc, ld = _nhwc(x)
+        K = wf.shape[0]
+        dl = dl.float().contiguous()
+        L = _lib.lib()
+        n = (K * Cc + K + 1) // 2 * 2
+        part = torch.empty((int(L.du_seg_head_bwd_blocks(B, H * W)), n), dtype=torch.float32, device=x.device)
+        dwb = torch.empty(n, dtype=torch.float32, device=x.device)
+        dx = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device) if ctx.needs_input_grad[0] else None
+        e0 = PROFILE.start() if PROFILE is not None else None
+        _lib.check(L.du_seg_head_bwd(_p(x), ld, _p(wf), _p(dl), _p(dx), Cc, _p(part), _p(dwb), B, H * W, Cc, K, _st()), "du_seg_head_bwd")
+        if PROFILE is not None:
+            PROFILE.stop("seg_head_bwd_kernel<bf16>", e0, 4.0 * B * H * W * Cc * K, 4.0 * B * H * W * Cc + 4.0 * B * H * W * K)
+        dw = dwb[:K * Cc].view(w_shape) if ctx.needs_input_grad[1] else None
+        db = dwb[K * Cc:K * Cc + K] if (has_b and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+_SEG_HEAD = os.environ.get("DINOUNET_SEG_HEAD", "1") != "0"          # A-B aid: 0 = the padded GEMM + layout passes of round 2
+
+
+def seg_head_ok(x, K):
+    """True when seg_head() serves this head: bf16 NHWC features with 32 channels (16-byte aligned pixels), 1..4 classes, on the GPU."""
+    return (_SEG_HEAD and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] == 32 and 1 <= K <= 4
+            and x.stride(3) == 1 and x.stride(2) % 8 == 0 and x.stride(1) == x.shape[2] * x.stride(2) and x.stride(0) == x.shape[1] * x.stride(1)
+            and x.data_ptr() % 16 == 0)
+
+
+def seg_head(x, w, b):
+    """logits (B, K, H, W) fp32 = 1x1 conv of x (B, H, W, 32) bf16 with w (K, 32, 1, 1), b (K)."""
+    return _SegHead.apply(x, w, b)
+
+
 def patchify16(x, dt):
     _req(x)
     x = x.float().contiguous()

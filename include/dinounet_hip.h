@@ -405,6 +405,16 @@ int du_aug_blur(const float* x, float* y, const float* sigma, int planes, int H,
 /* SimulateLowResolutionTransform: nearest-neighbour down to round(size * zoom[p]), cubic back up; zoom outside (0, 1) copies */
 int du_aug_lowres(const float* x, float* y, const float* zoom, int planes, int H, int W, void* stream);
 
+/* Segmentation head (the decoder's last 1x1 convolution, 32 channels -> K <= 4 classes; dinounet_training.py:603-629, nnU-Net UNetDecoder
+   seg_layers): one streaming pass instead of a padded GEMM + layout passes.  bf16 activations, weights rounded to bf16 as autocast does.
+   du_seg_head_fwd: x (B, HW, 32) NHWC bf16 (pixel stride ldx), w (K, 32) fp32, bias (K) fp32 or null -> out (B, K, HW) fp32 (NCHW logits).
+   du_seg_head_bwd: dl (B, K, HW) fp32 -> dx (B, HW, 32) bf16 (nullable), dwb = [dw (K, 32), db (K)] fp32 (K * 33 floats rounded up to an
+   even count, OVERWRITTEN); part = du_seg_head_bwd_blocks(B, HW) rows of that length, scratch.  DU_ERR_UNSUPPORTED for other C / K. */
+int du_seg_head_fwd(const void* x, int64_t ldx, const float* w, const float* bias, float* out, int B, int64_t HW, int C, int K, void* stream);
+int du_seg_head_bwd_blocks(int B, int64_t HW);
+int du_seg_head_bwd(const void* x, int64_t ldx, const float* w, const float* dl, void* dx, int64_t lddx, float* part, float* dwb, int B,
+                    int64_t HW, int C, int K, void* stream);
+
 /* library self-description */
 const char* du_version(void);
 int du_device_ok(void); /* 1 if the current device is gfx950 */

@@ -1003,6 +1003,38 @@ def test_vit_qkv_rope_in_gemm_epilogue(B, H, N, D):
     assert rel(out_u, ref) < 3e-2
 
 
+@pytest.mark.parametrize("B,H,W,K,ld", [(2, 24, 40, 2, 32), (1, 17, 13, 1, 32), (3, 8, 16, 3, 32), (2, 33, 9, 4, 32), (2, 16, 16, 2, 64)])
+def test_seg_head_streaming_kernels_match_conv1x1(B, H, W, K, ld):
+    """The decoder's last layer (32 channels -> K classes, dinounet_training.py:603-629) as one streaming pass: fp32 NCHW logits, and dx /
+    dw / db from ONE backward pass, vs torch's conv2d on the same bf16 features with the weights rounded to bf16 (autocast).  Pixel counts
+    that are no multiple of the workgroup size, 1..4 classes, features that are the first 32 channels of a wider tensor (ld = 64)."""
+    from dinounet_amd import ops
+    d = dev()
+    dt = torch.bfloat16
+    xfull = q(gen(B, H, W, ld, seed=41), dt)
+    w, b = gen(K, 32, 1, 1, seed=42, scale=0.3), gen(K, seed=43, scale=0.3)
+    go = gen(B, K, H, W, seed=44)
+    xr = xfull[..., :32].float().clone().requires_grad_(True)
+    wr, br = q(w, dt).clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr.permute(0, 3, 1, 2), wr, br)
+    yr.backward(go)
+    xg_full = xfull.to(d, dt)
+    xg = xg_full[..., :32].detach().requires_grad_(True) if ld == 32 else xg_full[..., :32]
+    if ld != 32:
+        xg_full.requires_grad_(True)
+        xg = xg_full[..., :32]
+    assert ops.seg_head_ok(xg, K)
+    wg, bg = w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    y = ops.seg_head(xg, wg, bg)
+    assert y.shape == (B, K, H, W) and y.dtype == torch.float32
+    assert rel(y, yr) < 1e-5
+    y.backward(go.to(d))
+    gx = xg.grad if ld == 32 else xg_full.grad[..., :32]
+    assert rel(gx, xr.grad) < TOL[dt]                      # dx is stored in bf16
+    assert rel(wg.grad, wr.grad) < 1e-4 and rel(bg.grad, br.grad) < 1e-5
+    assert not ops.seg_head_ok(xg.float(), K) and not ops.seg_head_ok(xg, 5)
+
+
 @pytest.mark.parametrize("B,H,W,C1,C2,Cout", [(2, 16, 32, 64, 0, 32), (1, 24, 16, 32, 32, 32), (2, 8, 16, 64, 64, 64), (1, 16, 16, 128, 128, 128),
                                               (1, 32, 48, 32, 0, 64), (3, 8, 16, 128, 0, 64)])
 def test_conv3x3_halo_kernel_fwd_bwd_stats(B, H, W, C1, C2, Cout):
