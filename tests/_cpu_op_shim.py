@@ -86,11 +86,29 @@ def conv_transpose2x2(x, w, bias=None, residual=None):
     return y if residual is None else y + residual
 
 
+class _ContigGrad(torch.autograd.Function):
+    """Identity whose backward hands on a CONTIGUOUS gradient.  torch 2.10's CPU instance_norm backward returns wrong weight / bias / input
+    gradients for batch size 1 when the incoming gradient is channels-last strided (as it is behind `_nhwc`: a permuted view) -- found in
+    round 3 when one-slice-per-rank runs disagreed with the full batch; batch >= 2 takes another path and is right."""
+
+    @staticmethod
+    def forward(ctx, y):
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.contiguous()
+
+
 def norm_act(x, w, b, kind, act=ACT_NONE, eps=1e-5, training=True, running_mean=None, running_var=None, momentum=0.1, group=None,
              stats_part=None):
+    if kind != "in" and training and group is not None:
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size(group) > 1:            # SyncBatchNorm semantics (ops._NormAct with a group)
+            return _ShimSyncBN.apply(x, w, b, eps, running_mean, running_var, momentum, act, group)
     xc = _nchw(x).float()
     if kind == "in":
-        y = F.instance_norm(xc, None, None, w, b, True, 0.0, eps)
+        y = _ContigGrad.apply(F.instance_norm(xc, None, None, w, b, True, 0.0, eps))
     elif training:
         y = F.batch_norm(xc, running_mean, running_var, w, b, True, momentum, eps)
     else:
@@ -221,11 +239,13 @@ class _ShimSyncBN(torch.autograd.Function):
         import torch.distributed as dist
         C = x.shape[-1]
         xf = x.float().reshape(-1, C)
-        st = torch.cat([xf.sum(0), (xf * xf).sum(0), torch.tensor([float(xf.shape[0])])])
+        xd = xf.double()                                   # sums in fp64: E[x^2] - E[x]^2 in fp32 costs ~1e-6 of the variance, which the
+        st = torch.cat([xd.sum(0), (xd * xd).sum(0), torch.tensor([float(xf.shape[0])], dtype=torch.float64)])   # gradients amplify
         dist.all_reduce(st, group=group)
         n = float(st[-1])
-        mean = st[:C] / n
-        var = (st[C:2 * C] / n - mean * mean).clamp_min(0)
+        mean64 = st[:C] / n
+        var = (st[C:2 * C] / n - mean64 * mean64).clamp_min(0).float()
+        mean = mean64.float()
         rstd = (var + eps).rsqrt()
         if rm is not None:
             rm.mul_(1 - mom).add_(mom * mean)

@@ -165,3 +165,86 @@ def test_swiglu_and_sample_copy_stand_ins():
     assert torch.allclose(h, torch.nn.functional.silu(x @ w1.t() + b1) * (x @ w2.t() + b2), atol=1e-5)
     assert torch.equal(sub, torch.arange(24.0).view(4, 6)[[2, 0]])
     assert torch.equal(t[2], torch.arange(12.0, 18.0) * 10) and torch.equal(t[1], torch.arange(6.0, 12.0))
+
+
+# ---- two ranks through the whole product wiring: DinoUNet (dinounet_s) in train mode, one slice per rank, SyncBatchNorm statistics of the
+#      SPM stem (one collective per norm) and of the four output norms (ONE packed collective, ops.sync_bn_multi) over gloo.  Every rank's
+#      logits must equal the reference's full-batch logits of its slice (tests/golden/dinounet_s_64_train.npz: torch BatchNorm over both
+#      slices), the averaged gradients the full-batch gradients, the running statistics the full-batch ones.
+_WATCH = ("spm.stem.0.weight", "spm.stem.1.weight", "spm.stem.1.bias", "spm.conv4.0.weight", "dinov3_adapter.norm1.weight", "dinov3_adapter.norm4.bias",
+          "dinov3_adapter.up.weight", "decoder.stages.0.convs.0.conv.weight")
+
+
+def _adapter_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DINOUNET_ALLOW_RANDOM_BACKBONE="1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import json
+    import _cpu_op_shim as shim
+    from oracle import weights
+    from oracle.refshim import PLANS_2D
+    from dinounet_amd.network_architecture import DinoUNet
+    from dinounet_amd.dinov3.adapter import DropPath
+    torch.set_num_threads(2)
+    keys = json.load(open(os.path.join(here, "golden", "state_dict_dinounet_s.json")))["keys"]
+    net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name="dinounet_s", precision="fp32")
+    net.load_state_dict(weights.make_state_dict([(k, tuple(s)) for k, s, _ in keys], seed=0), strict=True)
+    net.train()
+    for m in net.modules():
+        if isinstance(m, DropPath):
+            m.drop_prob = 0.0
+    net.encoder.dinov3_adapter.backbone.rope_embed.rescale_coords = None
+    x = weights.make_input(2, 3, 64, 64, seed=1)
+    if world > 1:
+        x = x[rank:rank + 1]
+    with shim.patched_ops():
+        y = net.decoder(net.encoder(x))
+        (y * y).mean().backward()
+    named = dict(net.named_parameters())
+    # numpy arrays travel through the queue by value (a tensor is handed over as a shared-memory handle its producer must outlive)
+    grads = {k: named[k].grad.numpy().copy() for k in named if k.endswith(_WATCH) and named[k].grad is not None}
+    bufs = {k: v.numpy().copy() for k, v in net.named_buffers()
+            if ("running_mean" in k or "running_var" in k) and ("spm.stem.1" in k or "norm2" in k)}
+    q.put((rank, y.detach().numpy().copy(), grads, bufs))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_dinounet_two_ranks_syncbn_through_the_adapter_matches_full_batch():
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_adapter_worker, args=(r, 2, port, q)) for r in range(2)]
+    ref = ctx.Process(target=_adapter_worker, args=(0, 1, _free_port(), q))          # the full batch in ONE process, same code path
+    [p.start() for p in procs + [ref]]
+    got = [q.get(timeout=900) for _ in range(3)]
+    [p.join(timeout=120) for p in procs + [ref]]
+    assert all(p.exitcode == 0 for p in procs + [ref])
+    got = [(r, torch.from_numpy(y), {k: torch.from_numpy(v) for k, v in gr.items()}, {k: torch.from_numpy(v) for k, v in bf.items()})
+           for r, y, gr, bf in got]
+    full = [g for g in got if g[1].shape[0] == 2][0]
+    ranks = sorted([g for g in got if g[1].shape[0] == 1], key=lambda t: t[0])
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dinounet_s_64_train.npz"))
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert rel(full[1], torch.from_numpy(gold["logits"])) < 2e-5                     # the single-process run is the reference's
+    for r in range(2):
+        assert rel(ranks[r][1][0], full[1][r]) < 2e-5, r                            # each rank's slice, with the OTHER rank's statistics
+    assert len(full[2]) >= 6
+    # Gradient tolerance: this network amplifies input rounding ~200x into its gradients (3e-6 relative noise on the decoder's inputs moves
+    # the decoder's weight gradients by 6e-4; the two setups' features differ by 3e-6: batch statistics summed in another order), so the
+    # averaged gradients are held to 1e-2 of the tensor's maximum and 2e-3 in norm -- a wiring error (a missing cross-rank term, the local
+    # instead of the global count) shows up at 0.1-1.
+    bad = {}
+    for k, g in full[2].items():
+        avg = (ranks[0][2][k] + ranks[1][2][k]) / 2                                 # DDP's average of the per-rank mean losses
+        if rel(avg, g) >= 1e-2 or abs(float(avg.norm()) / float(g.norm()) - 1.0) >= 2e-3:
+            bad[k] = (rel(avg, g), float(g.norm()), float(avg.norm()))
+    assert not bad, bad
+    for k, v in full[3].items():
+        for r in range(2):
+            assert torch.allclose(ranks[r][3][k], v, rtol=1e-4, atol=1e-6), (k, r)
