@@ -520,3 +520,27 @@ def test_bench_roofline_reads_pmc_summaries_only_for_matching_kernel_sources(mon
     bench.pmc_traffic(roof)
     bench.pmc_cycles(roof)
     assert "traffic" not in roof and "digest mismatch" in roof["traffic_note"] and "pmc_cycles" not in roof
+
+
+def test_launch_count_tool_finds_the_replayed_step_not_a_sub_period(tmp_path):
+    """tools/rocpd_counts.py: the kernel trace of bench.py holds eager warm-up steps with one-time work beside the replayed steps, and a
+    network of identical blocks has windows SHORTER than a step whose kernel multisets agree several times in a row (round 3: 823 and 845
+    were found before the true 867).  The period must come from the once-per-step kernels."""
+    import sqlite3
+    import subprocess
+    import sys
+    block = ["ln", "qkv", "rope", "attn", "proj", "ln", "fc1", "fc2", "tail_a", "tail_b"]
+    step = ["prep"] + block * 24 + [f"dec{i % 7}" for i in range(60)] + ["loss", "sgd"]
+    names = []
+    for w in range(3):                                     # warm-up: the step + first-use work
+        names += step + [f"init{w}_{i}" for i in range(40 + 13 * w)]
+    names += step * 10 + ["readback"]
+    db = tmp_path / "trace.db"
+    c = sqlite3.connect(db)
+    c.execute("create table kernels(name text, start int, end int)")
+    c.executemany("insert into kernels values(?,?,?)", [(n, 1000 * i, 1000 * i + 700) for i, n in enumerate(names)])
+    c.commit(); c.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rocpd_counts.py"), str(db), "13"], capture_output=True, text=True, check=True).stdout
+    assert f"steady state: {len(step)} dispatches per replayed step" in out.splitlines()[0], out[:300]
+    assert "  24.0/step" in out and "   1.0/step" in out
