@@ -17,6 +17,9 @@ EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 # step, all tests green).  The build reads hipcc's resource-usage remarks and fails on ScratchSize > 0 there.
 NO_SCRATCH = ("gemm_bf16.hip", "gemm_glds.hip", "gemm_p8.hip", "gemm_skinny.hip", "conv_halo.hip", "attention.hip")
 REMARK = "-Rpass-analysis=kernel-resource-usage"
+# timing-ablation instantiations of the attention kernel (last template argument != 0; tools/attn_ablate.py) may spill: they never run in the product
+import re as _re
+_ABLATION = _re.compile(r"attn_fwd_w64_kernelILi\d+ELi\d+ELb\dELi\d+ELi[1-9]\d*ELi\d+EEE")
 
 
 def _digest():
@@ -57,7 +60,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             for ln in out.decode().splitlines():
                 if "Function Name:" in ln:
                     name = ln.split("Function Name:")[1].split("[")[0].strip()
-                elif "ScratchSize [bytes/lane]:" in ln and int(ln.split("ScratchSize [bytes/lane]:")[1].split("[")[0]) > 0:
+                elif "ScratchSize [bytes/lane]:" in ln and int(ln.split("ScratchSize [bytes/lane]:")[1].split("[")[0]) > 0 and not _ABLATION.search(name or ""):
                     spills.append(f"{name} ({ln.split('ScratchSize [bytes/lane]:')[1].split('[')[0].strip()} B/lane)")
             if spills:
                 raise RuntimeError(f"{s}: kernels spill to scratch: " + "; ".join(spills[:6]))

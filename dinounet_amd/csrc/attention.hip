@@ -73,9 +73,15 @@ __global__ __launch_bounds__(256) void qkv_rope_split_kernel(const T* __restrict
 //     are fetched while step i multiplies; the row maximum crosses the wave halves with v_permlane32_swap (no LDS round trip).
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float other_half_max(float x) {
-  const unsigned u = __builtin_bit_cast(unsigned, x);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0]: lower half's value in every lane, r[1]: upper half's
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  // max of the two wave halves' values, in every lane.  v_permlane32_swap exchanges the upper half of its first operand with the lower half
+  // of its second: fed (x, copy of x), the first register then holds the lower half's value in every lane, the second the upper half's.
+  // In inline asm on purpose: through __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2) folds fmaxf(r[0], r[1]) to r[0] (also with an
+  // opaque copy as second operand) -- the running maximum of rounds 2 / 3 silently came from the keys of the LOWER half-lanes only.  Found
+  // in round 4 by the spiked-key test (a large score on an upper-half key overflowed the probabilities to inf / NaN); on unspiked data the
+  // two halves' maxima are close, so nothing showed.  The s_nop covers the VALU-write -> v_permlane read hazard (2 wait states).
+  float a = x, b;
+  asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
+  return fmaxf(a, b);
 }
 
 template <int DH, bool ABL>
@@ -374,6 +380,402 @@ __global__ __launch_bounds__(256, DH == 64 ? (ABL ? 3 : 4) : 2) void attn_fwd_ke
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// flash attention forward, round 4: 64 queries per wave (two 32-query blocks sharing every K / V fragment), two waves per SIMD
+//
+// Why: the 4-waves-per-SIMD kernel above spends ~340 instruction issues around 16 MFMAs per 64-key tile and a SIMD issues
+// about one instruction per 4-5 cycles whatever it is; its ceiling at d_head 64 is 0.38 of the matrix pipe.  What this kernel removes:
+//   * the running row maximum.  The scores of the FIRST tile a wave multiplies set the reference m of every query (a proper row maximum,
+//     so the largest probability of a row is >= 1 for good: the row sum cannot underflow); every later tile is exponentiated against that
+//     m without looking at its own maximum -- P = 2^(s - m) may exceed 1 by any factor fp32 holds (P enters the PV product as bf16, the row
+//     sum and O accumulate in fp32: precision is relative, only the RANGE matters).  A tile whose lane-partial row sum exceeds 2^60 (or is
+//     not finite) takes a cold path that multiplies its scores again straight from global memory, adopts the true maximum and rescales O
+//     and l (tests force it with spiked keys and with the threshold turned down to zero).  32 v_max + a lane exchange + a vote per 32
+//     scores and the max -> exp dependency are gone: per 32-query block and tile 32 v_exp + 32 v_add + 16 v_cvt_pk stay around 16 MFMAs;
+//   * half of the K / V fragment reads, DMA issues, waits, barriers and loop overhead per MFMA: both query blocks share them;
+//   * masks and -m bookkeeping in the loop: the ragged tile (keys >= N) is multiplied FIRST (softmax does not care about key order), in the
+//     prologue that computes the masked maximum anyway; in the loop m rides in as the C operand of the first S^T MFMA of a chain.
+// (The one-wave-per-SIMD / 512-register form of this kernel was compiled first: hipcc parks MFMA operands in the accumulator half of the
+// register file and copies them back and forth -- 600 v_accvgpr_read / _write per tile -- so the kernel stays inside 256 VGPRs and two
+// workgroups share a CU; the partner wave of a SIMD fills the matrix pipe while this one exponentiates.)
+// K / V tiles arrive by LDS-DMA into a three-slot ring (two tiles of flight), one barrier per tile.
+// NQB = 1 (d_head 128: O alone is 128 registers for two blocks): 32 queries per wave, the same program.
+// ------------------------------------------------------------------------------------------------------
+template <int DH, int NQB, bool PROBE = false, int OCC = 2, int ABL = 0, int PRIO = 0>
+__global__ __launch_bounds__(256, OCC) void attn_fwd_w64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int H, int N,
+                                                                int Npad, float thresh, unsigned long long* __restrict__ probe) {
+  constexpr int KT = 64;                     // keys per tile
+  constexpr int QW = 32 * NQB;               // queries per wave
+  constexpr int ROWB = DH * 2;               // bytes per K / V row
+  constexpr int NKK = DH / 16;               // k-steps of the S^T product
+  constexpr int NDB = DH / 32;               // 32-wide dv blocks of O^T
+  constexpr int TILE_B = KT * ROWB;          // 8 / 16 KB per operand tile
+  constexpr int SLOT_B = 2 * TILE_B;         // K image then V image
+  constexpr int RPP = 1024 / ROWB;           // rows per 1-KB DMA piece
+  constexpr int CPR = ROWB / 16;             // 16-byte chunks per row
+  constexpr int PIECES = TILE_B / 1024;      // DMA pieces per operand tile, dealt to the 4 waves
+  constexpr int DPO = PIECES / 4;            // LDS-DMA instructions per wave and operand tile
+  constexpr int NSLOT = DH == 64 ? (OCC > 3 ? 2 : 3) : 2;    // 48 / 64 KB per workgroup, two workgroups per CU (OCC 4: 32 KB each)
+  constexpr int AHEAD = NSLOT - 1;           // tiles requested beyond the one being multiplied
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * SLOT_B];
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4 lds_v4;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  unsigned long long t_entry = 0;
+  if constexpr (PROBE) t_entry = __builtin_amdgcn_s_memtime();
+  if constexpr (PRIO == 1 || PRIO == 2) {
+    // static, DISTINCT priorities for the waves that share a SIMD (they belong to different workgroups: wave slot = HW_ID[3:0])
+    const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));
+    const unsigned pr = PRIO == 1 ? (slot & 3) : 3 - (slot & 3);
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, ql = lane & 31;
+  int bh = blockIdx.y, qt = blockIdx.x;
+  if ((gridDim.y & 7) == 0) {                // all query tiles of a head on one XCD (its K / V stay in that L2)
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, idx = lin >> 3;
+    bh = (idx / (int)gridDim.x) * 8 + xcd;
+    qt = idx % (int)gridDim.x;
+  }
+  const int q0 = (qt * 4 + wave) * QW;
+  const bool active = q0 < N;                // wave-uniform
+  const bf16_t* Qb = Q + (long)bh * Npad * DH;
+  const bf16_t* Kb = K + (long)bh * Npad * DH;
+
+  auto make_srd = [&](const bf16_t* base) __attribute__((always_inline)) -> u32x4 {
+    const unsigned long long a = (unsigned long long)(const void*)base;
+    u32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    d[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    d[2] = __builtin_amdgcn_readfirstlane((unsigned)(N * ROWB));             // rows >= N read as zeros
+    d[3] = 0x00020000u;
+    return d;
+  };
+  const u32x4 rk = make_srd(Kb), rv = make_srd(V + (long)bh * Npad * DH);
+  unsigned vk_off, vv_off;                   // the LDS images and their source-side swizzles are those of attn_fwd_kernel
+  {
+    const int rip = lane / CPR, pc = lane % CPR;
+    const int swk = DH == 64 ? ((((wave & 1) << 2) | (rip >> 1)) & 7) : ((wave * 4 + rip) & 15);
+    const int swv = DH == 64 ? (((rip >> 1) & 1) << 2) : ((rip & 3) << 2);
+    vk_off = (unsigned)(rip * ROWB + ((pc ^ swk) << 4));
+    vv_off = (unsigned)(rip * ROWB + ((pc ^ swv) << 4));
+  }
+  auto dma16 = [&](const u32x4& srd, unsigned voff, unsigned soff, unsigned lds_addr) __attribute__((always_inline)) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
+  };
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int ntiles = (N + KT - 1) / KT;
+  // order of multiplication: step 0 = the ragged last tile, step i = tile i - 1; steps past the end name a tile beyond N (the DMA returns
+  // zeros through the descriptor's bounds check and nobody reads them: every step issues the same number of pieces, so the counted waits
+  // hold for any N)
+  auto tile_of = [&](int i) __attribute__((always_inline)) -> int { return i == 0 ? ntiles - 1 : (i < ntiles ? i - 1 : ntiles); };
+  auto dma_step = [&](int i, int slot) __attribute__((always_inline)) {
+    const int tile = tile_of(i);
+#pragma unroll
+    for (int j = 0; j < DPO; j++) {
+      const int piece = wave + 4 * j;
+      const unsigned soff = (unsigned)((tile * KT + piece * RPP) * ROWB);
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * SLOT_B + piece * 1024);
+      dma16(rk, vk_off, soff, dst);
+      dma16(rv, vv_off, soff, dst + TILE_B);
+    }
+  };
+
+  // Q fragments (B operand): lane (q, half) holds Q[q][kk*16 + half*8 .. +8]
+  bf16x8 qf[NQB][NKK];
+#pragma unroll
+  for (int qb = 0; qb < NQB; qb++) {
+    int qr = q0 + qb * 32 + ql; if (qr > N - 1) qr = N - 1;
+#pragma unroll
+    for (int kk = 0; kk < NKK; kk++) qf[qb][kk] = *(const bf16x8*)(Qb + (long)qr * DH + kk * 16 + half * 8);
+  }
+#pragma unroll
+  for (int a = 0; a < AHEAD; a++) dma_step(a, a);
+#pragma unroll
+  for (int qb = 0; qb < NQB; qb++)
+#pragma unroll
+    for (int kk = 0; kk < NKK; kk++) asm volatile("" : "+v"(qf[qb][kk]));      // the compiler settles its own vmcnt debt (the Q loads) here
+
+  f32x16 acc_o[NQB][NDB], s[NQB][2], cinit[NQB];
+  bf16x8 pf[NQB][4];                         // P^T of the current tile: B fragments of the four PV steps, per query block
+  float m[NQB], l[NQB];
+#pragma unroll
+  for (int qb = 0; qb < NQB; qb++) {
+    l[qb] = 0.f; m[qb] = 0.f;
+#pragma unroll
+    for (int d = 0; d < NDB; d++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc_o[qb][d][r] = 0.f;
+  }
+
+  // fragment addresses
+  const int ksw = DH == 64 ? ((ql >> 1) & 7) : (ql & 15);
+  const int krow = ql * ROWB;
+  const int g = lane >> 4, p16 = lane & 15;
+  const int vf_sel = DH == 64 ? ((p16 >> 3) & 1) : ((p16 >> 2) & 3);
+  const int vlane = (4 * (g >> 1) + (p16 >> 2)) * ROWB + 32 * (g & 1) + 8 * (p16 & 3);
+  auto kfrag = [&](const unsigned char* Ks, int kb, int kk) __attribute__((always_inline)) -> bf16x8 {
+    return *(const bf16x8*)(Ks + kb * 32 * ROWB + krow + (((kk * 2 + half) ^ ksw) << 4));
+  };
+  auto vfrag = [&](const unsigned char* Vs, int step, int d) __attribute__((always_inline)) -> bf16x8 {
+    const unsigned char* vp = Vs + vlane + (16 * step) * ROWB + ((d ^ vf_sel) << 6);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)vp);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(vp + 8 * ROWB));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  // S^T - m of every query block against the K image at Ks: each K fragment is read once and multiplied into all blocks
+  // ABL (tools/attn_ablate.py: timing only, results are garbage): 1 no exp2, 2 no S^T MFMAs, 4 no PV MFMAs, 8 no K / V fragment reads,
+  // 16 no DMA and no wait for it, 32 no barrier, 64 no row sums, 128 no bf16 packing
+  auto qk = [&](const unsigned char* Ks, const f32x16 (&cin)[NQB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < NKK; kk++)
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        bf16x8 a;
+        if constexpr (ABL & 8) { a = qf[0][(kk + kb) % NKK]; asm volatile("" : "+v"(a)); } else a = kfrag(Ks, kb, kk);
+#pragma unroll
+        for (int qb = 0; qb < NQB; qb++) {
+          if constexpr (ABL & 2) { if (kk == 0) s[qb][kb] = cin[qb]; asm volatile("" : "+v"(s[qb][kb]) : "v"(a)); }
+          else s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[qb][kk], kk == 0 ? cin[qb] : s[qb][kb], 0, 0, 0);
+        }
+      }
+  };
+  auto pv = [&](const unsigned char* Vs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int step = 0; step < 4; step++)
+#pragma unroll
+      for (int d = 0; d < NDB; d++) {
+        bf16x8 a;
+        if constexpr (ABL & 8) { a = qf[0][(step + d) % NKK]; asm volatile("" : "+v"(a)); } else a = vfrag(Vs, step, d);
+#pragma unroll
+        for (int qb = 0; qb < NQB; qb++) {
+          if constexpr (ABL & 4) asm volatile("" : "+v"(acc_o[qb][d]) : "v"(a), "v"(pf[qb][step]));
+          else acc_o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[qb][step], acc_o[qb][d], 0, 0, 0);
+        }
+      }
+  };
+  auto pv_qb = [&](int qb, const unsigned char* Vs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int step = 0; step < 4; step++)
+#pragma unroll
+      for (int d = 0; d < NDB; d++) {
+        bf16x8 a;
+        if constexpr (ABL & 8) { a = qf[0][(step + d) % NKK]; asm volatile("" : "+v"(a)); } else a = vfrag(Vs, step, d);
+        if constexpr (ABL & 4) asm volatile("" : "+v"(acc_o[qb][d]) : "v"(a), "v"(pf[qb][step]));
+        else acc_o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[qb][step], acc_o[qb][d], 0, 0, 0);
+      }
+  };
+  // P = 2^S (S already carries -m), packed for the PV steps; returns this lane's partial row sum of the tile
+  auto expo = [&](int qb) __attribute__((always_inline)) -> float {
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        float p0, p1;
+        if constexpr (ABL & 1) { p0 = s[qb][kb][r]; p1 = s[qb][kb][r + 1]; }
+        else { p0 = __builtin_amdgcn_exp2f(s[qb][kb][r]); p1 = __builtin_amdgcn_exp2f(s[qb][kb][r + 1]); }
+        if constexpr (!(ABL & 64)) { t0 += p0; t1 += p1; }
+        if constexpr (ABL & 128) {
+          if ((r & 3) == 0) { unsigned u = __builtin_bit_cast(unsigned, p0); asm volatile("" : "+v"(u) : "v"(p1));
+                              bf16x2 t2 = __builtin_bit_cast(bf16x2, u); pf[qb][kb * 2 + (r >> 3)][r & 7] = t2[0]; pf[qb][kb * 2 + (r >> 3)][(r & 7) + 1] = t2[1]; }
+          else { unsigned u = __builtin_bit_cast(unsigned, p1); asm volatile("" : "+v"(u) : "v"(p0));
+                 bf16x2 t2 = __builtin_bit_cast(bf16x2, u); pf[qb][kb * 2 + (r >> 3)][r & 7] = t2[0]; pf[qb][kb * 2 + (r >> 3)][(r & 7) + 1] = t2[1]; }
+        } else {
+          pf[qb][kb * 2 + (r >> 3)][r & 7] = (bf16_t)p0;
+          pf[qb][kb * 2 + (r >> 3)][(r & 7) + 1] = (bf16_t)p1;
+        }
+      }
+    return t0 + t1;
+  };
+  // the cold path: tile `tile` of query block qb overflowed against the reference m: scores again (K fragments straight from global
+  // memory), true maximum, rescale of what the block has accumulated
+  auto rescue = [&](int qb, int tile) __attribute__((always_inline)) {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; r++) z[r] = 0.f;
+    f32x16 rs[2];
+#pragma unroll
+    for (int kk = 0; kk < NKK; kk++)
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        const bf16x8 a = *(const bf16x8*)(Kb + (long)(tile * KT + kb * 32 + ql) * DH + kk * 16 + half * 8);
+        rs[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[qb][kk], kk == 0 ? z : rs[kb], 0, 0, 0);
+      }
+    float mx = rs[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, rs[kb][r]);
+    mx = other_half_max(mx);
+    const float mn = fmaxf(m[qb], mx);
+    const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
+    m[qb] = mn;
+    l[qb] *= alpha;
+#pragma unroll
+    for (int d = 0; d < NDB; d++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc_o[qb][d][r] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cinit[qb][r] = -mn;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[qb][kb][r] = rs[kb][r] - mn;
+  };
+
+  // ---- step 0: the ragged tile with its masked row maximum ----
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"((AHEAD - 1) * 2 * DPO) : "memory");      // step 0 landed (this wave's share; the barrier = everyone's)
+  __builtin_amdgcn_s_barrier();
+  dma_step(AHEAD, AHEAD % NSLOT);
+  if (active) {
+    f32x16 z[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; qb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) z[qb][r] = 0.f;
+    const int t0 = ntiles - 1;
+    qk(smem, z);
+#pragma unroll
+    for (int qb = 0; qb < NQB; qb++) {
+      float mx = -3e38f;
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int key = t0 * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= N) s[qb][kb][r] = -3e38f;
+          mx = fmaxf(mx, s[qb][kb][r]);
+        }
+      mx = other_half_max(mx);
+      m[qb] = mx;
+#pragma unroll
+      for (int r = 0; r < 16; r++) cinit[qb][r] = -mx;
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[qb][kb][r] -= mx;
+      l[qb] = expo(qb);
+    }
+    pv(smem + TILE_B);
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"((AHEAD - 1) * 2 * DPO) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- steps 1 .. ntiles - 1: full tiles, no masks, no maxima ----
+  // PROBE (tools/attn_ablate.py, du_set_option(4, 64)): wave 0 of workgroup (1, 0) stamps s_memtime at the segment boundaries of every step
+  // and leaves the per-segment cycle sums in probe[0..7]; each stamp drains the wave's queues, so the probed wave runs slower than unprobed
+  const bool probing = PROBE && probe && blockIdx.x == 1 && blockIdx.y == 0 && wave == 0;
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+  unsigned long long t_begin = 0;
+  if constexpr (PROBE) t_begin = __builtin_amdgcn_s_memtime();
+  auto stamp = [&](int j) __attribute__((always_inline)) {
+    if constexpr (PROBE) {
+      if (probing) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (j >= 0) seg[j] += t - t_prev;
+        t_prev = t;
+      }
+    }
+  };
+  int cur = 1 % NSLOT, fill = (1 + AHEAD) % NSLOT;
+  for (int i = 1; i < ntiles; i++) {
+    stamp(-1);
+    if constexpr (!(ABL & 16)) dma_step(i + AHEAD, fill);               // into the slot read in step i - 1: everyone is past that step's barrier
+    stamp(0);
+    if (active) {
+      const unsigned char* Ks = smem + cur * SLOT_B;
+      qk(Ks, cinit);
+      if constexpr (PROBE) { if (probing) { asm volatile("" :: "v"(s[0][0][0]), "v"(s[NQB - 1][1][15])); } }
+      stamp(1);
+      float lt[NQB];
+      if constexpr (NQB == 2 && PRIO == 3) {
+        // the second block's exponentials ride beside the first block's PV MFMAs (the first block's rode beside the second block's S^T chain)
+        lt[0] = expo(0);
+        if (__builtin_expect(!__all(lt[0] < thresh), 0)) { rescue(0, i - 1); lt[0] = expo(0); }
+        l[0] += lt[0];
+        pv_qb(0, Ks + TILE_B);
+        lt[1] = expo(1);
+        if (__builtin_expect(!__all(lt[1] < thresh), 0)) { rescue(1, i - 1); lt[1] = expo(1); }
+        l[1] += lt[1];
+        pv_qb(1, Ks + TILE_B);
+      } else {
+#pragma unroll
+      for (int qb = 0; qb < NQB; qb++) lt[qb] = expo(qb);
+#pragma unroll
+      for (int qb = 0; qb < NQB; qb++) {
+        if (__builtin_expect(!__all(lt[qb] < thresh), 0)) {
+          rescue(qb, i - 1);
+          lt[qb] = expo(qb);
+        }
+        l[qb] += lt[qb];
+      }
+      if constexpr (PROBE) { if (probing) { asm volatile("" :: "v"(pf[0][0]), "v"(pf[NQB - 1][3]), "v"(l[0])); } }
+      stamp(2);
+      pv(Ks + TILE_B);
+      }
+      if constexpr (PROBE) { if (probing) { asm volatile("" :: "v"(acc_o[0][0][0]), "v"(acc_o[NQB - 1][NDB - 1][15])); } }
+      stamp(3);
+    }
+    if constexpr (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((AHEAD - 1) * 2 * DPO) : "memory");    // step i + 1 has landed; later requests stay in flight
+    stamp(4);
+    if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+    stamp(5);
+    cur = cur + 1 == NSLOT ? 0 : cur + 1;
+    fill = fill + 1 == NSLOT ? 0 : fill + 1;
+  }
+
+  if constexpr (PROBE) {
+    if (probing && lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) probe[j] = seg[j];
+    }
+    // census: when and where every workgroup's loop ran (HW_ID: wave slot, SIMD, CU, SE; XCC_ID): entries of 4 words behind the 8 sums
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (probe && wave == 0 && lane == 0 && wg < 1024) {
+      probe[8 + 8 * wg] = t_begin;
+      probe[8 + 8 * wg + 1] = __builtin_amdgcn_s_memtime();
+      probe[8 + 8 * wg + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));        // HW_REG_HW_ID, 32 bits
+      probe[8 + 8 * wg + 3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));         // HW_REG_XCC_ID, 4 bits
+      probe[8 + 8 * wg + 4] = t_entry;
+    }
+  }
+  // ---- finalize: O[q][dv] = O^T[dv][q] / l ----
+  if (!active) return;
+  const int b = bh / H, h = bh % H;
+#pragma unroll
+  for (int qb = 0; qb < NQB; qb++) {
+    const float lsum = l[qb] + __shfl_xor(l[qb], 32, 64);
+    const float inv = 1.f / lsum;
+    const int q = q0 + qb * 32 + ql;
+    if (q < N) {
+      bf16_t* op = O + ((long)b * N + q) * ((long)H * DH) + (long)h * DH;
+#pragma unroll
+      for (int d = 0; d < NDB; d++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+          bf16x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) o4[e] = (bf16_t)(acc_o[qb][d][g4 * 4 + e] * inv);
+          *(bf16x4*)(op + d * 32 + 8 * g4 + 4 * half) = o4;
+        }
+    }
+  }
+  if constexpr (PROBE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (probe && wave == 0 && lane == 0 && wg < 1024) probe[8 + 8 * wg + 5] = __builtin_amdgcn_s_memtime();
+  }
+}
+
 // row softmax, fp32, in place; pad columns [cols, ld) are zeroed (parity-mode attention: scores materialised)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, long rows, int cols, long ld) {
   const int lane = threadIdx.x & 63;
@@ -454,6 +856,9 @@ __global__ __launch_bounds__(256) void qkv_rope_split_rows_kernel(const T* __res
   }
 }
 
+int g_attn_impl = 0;     // du_set_option key 6: 0 = attn_fwd_w64_kernel (one wave per SIMD, 64 queries per wave), 1 = attn_fwd_kernel (round 2/3)
+int g_attn_var = 0;      // du_set_option key 8: experimental variants of the w64 kernel (tools only)
+int g_attn_thresh_log2 = 60;   // du_set_option key 7: log2 of the row-sum threshold of the w64 kernel's cold rescale path (<= -1000: every tile takes it)
 int g_attn_w = 0;        // du_set_option key 4: ablation bits of attn_fwd_kernel<64, true> (tools/attn_ablate.py); 0 = the product kernel
 
 extern "C" int du_qkv_rope_split_rows(int dtype, const void* qkv_rows, void* q, void* k, void* v, const float* sin_t, const float* cos_t,
@@ -479,14 +884,32 @@ extern "C" int du_qkv_rope_split_rows(int dtype, const void* qkv_rows, void* q, 
 // device scratch of the ablation kernel's cycle probe (allocated on first use, never in the product path)
 static unsigned long long* g_attn_probe = nullptr;
 static unsigned long long* attn_probe_buffer() {
-  if (!g_attn_probe && hipMalloc((void**)&g_attn_probe, 8 * sizeof(unsigned long long)) != hipSuccess) g_attn_probe = nullptr;
+  if (!g_attn_probe && hipMalloc((void**)&g_attn_probe, (8 + 8 * 1024) * sizeof(unsigned long long)) != hipSuccess) g_attn_probe = nullptr;
   return g_attn_probe;
 }
 // Debug aid (tools/attn_ablate.py): copy the 8 per-segment cycle sums the last probed launch (du_set_option(4, bits | 64)) left behind.
+// the census the probed w64 kernel leaves behind: 8 words per workgroup (loop begin, loop end in s_memtime ticks; HW_ID; XCC_ID; kernel entry; after the
+// output stores have been acknowledged; 2 spare), first n workgroups
+extern "C" int du_debug_attn_census(uint64_t* host, int n) {
+  if (!host || n < 1 || n > 1024) return DU_ERR_BAD_ARG;
+  if (!g_attn_probe) return DU_ERR_UNSUPPORTED;
+  return hipMemcpy(host, g_attn_probe + 8, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? DU_OK : DU_ERR_LAUNCH;
+}
 extern "C" int du_debug_attn_probe(uint64_t* host8) {
   if (!host8) return DU_ERR_BAD_ARG;
   if (!g_attn_probe) return DU_ERR_UNSUPPORTED;
   return hipMemcpy(host8, g_attn_probe, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? DU_OK : DU_ERR_LAUNCH;
+}
+
+// Debug aid: blocks per CU the runtime's occupancy query admits for the attention kernels (which: 0 = w64 d_head 64, 1 = w64 d_head 128,
+// 2 = the round-3 kernel d_head 64)
+extern "C" int du_debug_attn_occupancy(int which) {
+  int n = -1;
+  hipError_t e;
+  if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_w64_kernel<64, 2>, 256, 0);
+  else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_w64_kernel<128, 1>, 256, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<64, false>, 256, 0);
+  return e == hipSuccess ? n : -1;
 }
 
 extern "C" int du_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int N, int Npad, int Dh,
@@ -494,6 +917,26 @@ extern "C" int du_attention_fwd(const void* q, const void* k, const void* v, voi
   hipStream_t st = (hipStream_t)stream;
   if (!q || !k || !v || !out || B <= 0 || H <= 0 || N <= 0 || Npad < N) return DU_ERR_BAD_ARG;
   if ((long)N * Dh * 2 > 0x7fffffffL) return DU_ERR_UNSUPPORTED;
+  if (g_attn_impl == 0 && (g_attn_w & ~64) == 0 && (Dh == 64 || Dh == 128)) {
+    // 64 (d_head 128: 32) queries per wave, two workgroups per CU (attn_fwd_w64_kernel); threshold of the cold rescale path: 2^60 unless a
+    // test turned it down
+    const float thresh = g_attn_thresh_log2 <= -1000 ? 0.f : ldexpf(1.f, g_attn_thresh_log2);
+    if (Dh == 64 && (g_attn_w & 64)) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2, true>), dim3((N + 255) / 256, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, attn_probe_buffer());
+#define DU_ABL2(bits) else if (Dh == 64 && g_attn_var == 1000 + (bits)) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2, false, 2, (bits)>), dim3((N + 255) / 256, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
+#define DU_ABL1(bits) else if (Dh == 64 && g_attn_var == 2000 + (bits)) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 1, false, 4, (bits)>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
+    DU_ABL2(1) DU_ABL2(2) DU_ABL2(4) DU_ABL2(6) DU_ABL2(193) DU_ABL2(8) DU_ABL2(48) DU_ABL2(56) DU_ABL2(199) DU_ABL2(255) DU_ABL2(249)
+    DU_ABL1(1) DU_ABL1(2) DU_ABL1(4) DU_ABL1(6) DU_ABL1(193) DU_ABL1(8) DU_ABL1(48) DU_ABL1(56) DU_ABL1(199) DU_ABL1(255) DU_ABL1(249)
+    else if (Dh == 64 && g_attn_var == 7) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2, false, 2, 0, 3>), dim3((N + 255) / 256, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
+    else if (Dh == 64 && g_attn_var == 3) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2, false, 2, 0, 1>), dim3((N + 255) / 256, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
+    else if (Dh == 64 && g_attn_var == 4) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 1, false, 4, 0, 1>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
+    else if (Dh == 64 && g_attn_var == 5) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 1, false, 4, 0, 2>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
+    else if (Dh == 64 && g_attn_var == 6) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 1, false, 3, 0, 1>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
+    else if (Dh == 64 && g_attn_var == 1) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 1, false, 3>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
+    else if (Dh == 64 && g_attn_var == 2) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 1, false, 4>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
+    else if (Dh == 64) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2>), dim3((N + 255) / 256, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
+    else hipLaunchKernelGGL((attn_fwd_w64_kernel<128, 1>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
+    return du_check_launch();
+  }
   dim3 grid((N + 127) / 128, B * H), block(256);
   if (Dh == 64)
     if (g_attn_w) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, g_attn_w, attn_probe_buffer());

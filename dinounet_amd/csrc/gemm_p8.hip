@@ -1248,10 +1248,14 @@ int launch_p8_tn(const du_gemm_args& a, int splits, hipStream_t st) {
 
 // debugging / A-B knobs (within-process variant switching for tools/gemm_p8_bench.py); not part of the hot-path contract
 extern int g_attn_w;      // attention.hip
+extern int g_attn_impl, g_attn_thresh_log2, g_attn_var;
 
 extern "C" int du_set_option(int key, int value) {
   switch (key) {
     case 4: g_attn_w = value; return DU_OK;
+    case 6: g_attn_impl = value; return DU_OK;
+    case 7: g_attn_thresh_log2 = value; return DU_OK;
+    case 8: g_attn_var = value; return DU_OK;
     case 0: g_p8_mode = value; return DU_OK;
     case 1: g_p8_sched = value; return DU_OK;
     case 2: g_p8_group = value; return DU_OK;

@@ -427,6 +427,12 @@ int du_device_ok(void); /* 1 if the current device is gfx950 */
 int du_set_option(int key, int value);
 /* tuning aid: the 8 per-segment cycle sums of the last probed attention launch (du_set_option(4, bits | 64), tools/attn_ablate.py) */
 int du_debug_attn_probe(uint64_t* host8);
+/* tuning aid: workgroups per CU the runtime's occupancy query admits for an attention kernel (0: 64 queries per wave, d_head 64;
+   1: d_head 128; 2: the round-3 kernel) */
+int du_debug_attn_occupancy(int which);
+/* tuning aid: 8 words (loop begin tick, loop end tick, HW_ID, XCC_ID, kernel entry tick, exit tick, 2 spare) of the first n (<= 1024) workgroups
+   of the last probed launch of the 64-queries-per-wave kernel */
+int du_debug_attn_census(uint64_t* host, int n);
 
 /* ---- sliding-window inference: predicted_logits[sl] += prediction * gaussian; n_predictions[sl] += gaussian
    (dinounet/inference/predict_from_raw_data.py:607-608) for a batch of nb windows, then predicted_logits /= n_predictions (:610).
