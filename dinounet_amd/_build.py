@@ -17,9 +17,9 @@ EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 # step, all tests green).  The build reads hipcc's resource-usage remarks and fails on ScratchSize > 0 there.
 NO_SCRATCH = ("gemm_bf16.hip", "gemm_glds.hip", "gemm_p8.hip", "gemm_skinny.hip", "conv_halo.hip", "attention.hip")
 REMARK = "-Rpass-analysis=kernel-resource-usage"
-# timing-ablation instantiations of the attention kernel (last template argument != 0; tools/attn_ablate.py) may spill: they never run in the product
+# timing-ablation and cycle-probe instantiations of the attention kernel (tools/attn_ablate.py) may spill: they never run in the product
 import re as _re
-_ABLATION = _re.compile(r"attn_fwd_w64_kernelILi\d+ELi\d+ELb\dELi\d+ELi[1-9]\d*ELi\d+EEE")
+_ABLATION = _re.compile(r"attn_fwd_w64_kernelILi\d+ELi\d+ELb\dELi\d+ELi[1-9]\d*ELi\d+ELb\dEEE|attn_fwd_w64_kernelILi\d+ELi\d+ELb1E|attn_fwd_w64_kernelILi\d+ELi\d+ELb\dELi\d+ELi\d+ELi\d+ELb1EEE|attn_fwd_pipe_kernelILb\dELi[1-9]\d*EEE")
 
 
 def _digest():

@@ -9,6 +9,7 @@
 // moves between lanes or through LDS.  The contraction order over keys is permuted accordingly on the V^T side
 // (two 8-byte LDS reads per fragment).  Row max needs one cross-half exchange per tile; the row sum is kept as
 // a per-lane partial and combined once at the end; the O rescale factor is lane-local.
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -439,9 +440,21 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_w64_kernel(const bf16_t* __
   int bh = blockIdx.y, qt = blockIdx.x;
   if ((gridDim.y & 7) == 0) {                // all query tiles of a head on one XCD (its K / V stay in that L2)
     const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, idx = lin >> 3;
-    bh = (idx / (int)gridDim.x) * 8 + xcd;
-    qt = idx % (int)gridDim.x;
+    const int gx = gridDim.x, hpx = gridDim.y >> 3;          // query tiles per head, heads per XCD
+    if (gx > 1 && N % (4 * QW) != 0 && N % (4 * QW) <= 2 * QW) {
+      // the LAST query tile of a head is nearly empty (N = 1029: 5 queries, one wave busy for the whole key walk): dispatched behind the
+      // full tiles it ran alone at the end (+ 16 us at the dinounet_l shape); dispatched FIRST it shares a CU with a full workgroup and the
+      // slot it frees takes a late full one
+      if (idx < hpx) { bh = idx * 8 + xcd; qt = gx - 1; }
+      else { const int j = idx - hpx; bh = (j / (gx - 1)) * 8 + xcd; qt = j % (gx - 1); }
+    } else {
+      bh = (idx / gx) * 8 + xcd;
+      qt = idx % gx;
+    }
   }
+  // (Splitting the keys of a nearly empty last query tile over its four waves -- every wave its own reference maximum, partial (m, l, O)
+  //  combined through LDS -- was built and measured in round 4: the second instantiation of the tile walk cost the common one its last
+  //  registers (spilled Q fragments, + 8 us on the dinounet_l shape).  Dispatching those workgroups first, above, is what stayed.)
   const int q0 = (qt * 4 + wave) * QW;
   const bool active = q0 < N;                // wave-uniform
   const bf16_t* Qb = Q + (long)bh * Npad * DH;
@@ -509,6 +522,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_w64_kernel(const bf16_t* __
 #pragma unroll
   for (int qb = 0; qb < NQB; qb++) {
     l[qb] = 0.f; m[qb] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cinit[qb][r] = 0.f;
 #pragma unroll
     for (int d = 0; d < NDB; d++)
 #pragma unroll
@@ -632,18 +647,10 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_w64_kernel(const bf16_t* __
       for (int r = 0; r < 16; r++) s[qb][kb][r] = rs[kb][r] - mn;
   };
 
-  // ---- step 0: the ragged tile with its masked row maximum ----
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"((AHEAD - 1) * 2 * DPO) : "memory");      // step 0 landed (this wave's share; the barrier = everyone's)
-  __builtin_amdgcn_s_barrier();
-  dma_step(AHEAD, AHEAD % NSLOT);
-  if (active) {
-    f32x16 z[NQB];
-#pragma unroll
-    for (int qb = 0; qb < NQB; qb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) z[qb][r] = 0.f;
+  // the first step of a wave: scores against a zero reference, (step 0: keys >= N masked,) row maximum -> m, P, PV
+  auto first_step = [&](const unsigned char* Ks, bool ragged) __attribute__((always_inline)) {
     const int t0 = ntiles - 1;
-    qk(smem, z);
+    qk(Ks, cinit);                           // (cinit is still zero: the C operand costs no extra registers)
 #pragma unroll
     for (int qb = 0; qb < NQB; qb++) {
       float mx = -3e38f;
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_w64_kernel(const bf16_t* __
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int key = t0 * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (key >= N) s[qb][kb][r] = -3e38f;
+          if (ragged && key >= N) s[qb][kb][r] = -3e38f;
           mx = fmaxf(mx, s[qb][kb][r]);
         }
       mx = other_half_max(mx);
@@ -665,18 +672,13 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_w64_kernel(const bf16_t* __
         for (int r = 0; r < 16; r++) s[qb][kb][r] -= mx;
       l[qb] = expo(qb);
     }
-    pv(smem + TILE_B);
-  }
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"((AHEAD - 1) * 2 * DPO) : "memory");
-  __builtin_amdgcn_s_barrier();
-
-  // ---- steps 1 .. ntiles - 1: full tiles, no masks, no maxima ----
+    pv(Ks + TILE_B);
+  };
   // PROBE (tools/attn_ablate.py, du_set_option(4, 64)): wave 0 of workgroup (1, 0) stamps s_memtime at the segment boundaries of every step
   // and leaves the per-segment cycle sums in probe[0..7]; each stamp drains the wave's queues, so the probed wave runs slower than unprobed
   const bool probing = PROBE && probe && blockIdx.x == 1 && blockIdx.y == 0 && wave == 0;
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
   unsigned long long t_begin = 0;
-  if constexpr (PROBE) t_begin = __builtin_amdgcn_s_memtime();
   auto stamp = [&](int j) __attribute__((always_inline)) {
     if constexpr (PROBE) {
       if (probing) {
@@ -686,28 +688,23 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_w64_kernel(const bf16_t* __
       }
     }
   };
-  int cur = 1 % NSLOT, fill = (1 + AHEAD) % NSLOT;
-  for (int i = 1; i < ntiles; i++) {
-    stamp(-1);
-    if constexpr (!(ABL & 16)) dma_step(i + AHEAD, fill);               // into the slot read in step i - 1: everyone is past that step's barrier
-    stamp(0);
-    if (active) {
-      const unsigned char* Ks = smem + cur * SLOT_B;
-      qk(Ks, cinit);
-      if constexpr (PROBE) { if (probing) { asm volatile("" :: "v"(s[0][0][0]), "v"(s[NQB - 1][1][15])); } }
-      stamp(1);
-      float lt[NQB];
-      if constexpr (NQB == 2 && PRIO == 3) {
-        // the second block's exponentials ride beside the first block's PV MFMAs (the first block's rode beside the second block's S^T chain)
-        lt[0] = expo(0);
-        if (__builtin_expect(!__all(lt[0] < thresh), 0)) { rescue(0, i - 1); lt[0] = expo(0); }
-        l[0] += lt[0];
-        pv_qb(0, Ks + TILE_B);
-        lt[1] = expo(1);
-        if (__builtin_expect(!__all(lt[1] < thresh), 0)) { rescue(1, i - 1); lt[1] = expo(1); }
-        l[1] += lt[1];
-        pv_qb(1, Ks + TILE_B);
-      } else {
+  // one step after a wave's first: full tile, no masks, no maxima
+  auto later_step = [&](const unsigned char* Ks, int i) __attribute__((always_inline)) {
+    qk(Ks, cinit);
+    if constexpr (PROBE) { if (probing) { asm volatile("" :: "v"(s[0][0][0]), "v"(s[NQB - 1][1][15])); } }
+    stamp(1);
+    float lt[NQB];
+    if constexpr (NQB == 2 && PRIO == 3) {
+      // the second block's exponentials ride beside the first block's PV MFMAs (the first block's rode beside the second block's S^T chain)
+      lt[0] = expo(0);
+      if (__builtin_expect(!__all(lt[0] < thresh), 0)) { rescue(0, i - 1); lt[0] = expo(0); }
+      l[0] += lt[0];
+      pv_qb(0, Ks + TILE_B);
+      lt[1] = expo(1);
+      if (__builtin_expect(!__all(lt[1] < thresh), 0)) { rescue(1, i - 1); lt[1] = expo(1); }
+      l[1] += lt[1];
+      pv_qb(1, Ks + TILE_B);
+    } else {
 #pragma unroll
       for (int qb = 0; qb < NQB; qb++) lt[qb] = expo(qb);
 #pragma unroll
@@ -721,16 +718,33 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_w64_kernel(const bf16_t* __
       if constexpr (PROBE) { if (probing) { asm volatile("" :: "v"(pf[0][0]), "v"(pf[NQB - 1][3]), "v"(l[0])); } }
       stamp(2);
       pv(Ks + TILE_B);
-      }
-      if constexpr (PROBE) { if (probing) { asm volatile("" :: "v"(acc_o[0][0][0]), "v"(acc_o[NQB - 1][NDB - 1][15])); } }
-      stamp(3);
     }
-    if constexpr (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((AHEAD - 1) * 2 * DPO) : "memory");    // step i + 1 has landed; later requests stay in flight
-    stamp(4);
-    if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
-    stamp(5);
-    cur = cur + 1 == NSLOT ? 0 : cur + 1;
-    fill = fill + 1 == NSLOT ? 0 : fill + 1;
+    if constexpr (PROBE) { if (probing) { asm volatile("" :: "v"(acc_o[0][0][0]), "v"(acc_o[NQB - 1][NDB - 1][15])); } }
+    stamp(3);
+  };
+  {
+    // ---- step 0: the ragged tile with its masked row maximum ----
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((AHEAD - 1) * 2 * DPO) : "memory");      // step 0 landed (this wave's share; the barrier = everyone's)
+    __builtin_amdgcn_s_barrier();
+    dma_step(AHEAD, AHEAD % NSLOT);
+    if (active) first_step(smem, true);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((AHEAD - 1) * 2 * DPO) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (PROBE) t_begin = __builtin_amdgcn_s_memtime();
+    // ---- steps 1 .. ntiles - 1 ----
+    int cur = 1 % NSLOT, fill = (1 + AHEAD) % NSLOT;
+    for (int i = 1; i < ntiles; i++) {
+      stamp(-1);
+      if constexpr (!(ABL & 16)) dma_step(i + AHEAD, fill);               // into the slot read in step i - 1: everyone is past that step's barrier
+      stamp(0);
+      if (active) later_step(smem + cur * SLOT_B, i);
+      if constexpr (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((AHEAD - 1) * 2 * DPO) : "memory");    // step i + 1 has landed; later requests stay in flight
+      stamp(4);
+      if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+      stamp(5);
+      cur = cur + 1 == NSLOT ? 0 : cur + 1;
+      fill = fill + 1 == NSLOT ? 0 : fill + 1;
+    }
   }
 
   if constexpr (PROBE) {
@@ -773,6 +787,378 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_w64_kernel(const bf16_t* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     if (probe && wave == 0 && lane == 0 && wg < 1024) probe[8 + 8 * wg + 5] = __builtin_amdgcn_s_memtime();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// the same algorithm as attn_fwd_w64_kernel (d_head 64, 64 queries per wave, no running maximum), software-pipelined INSIDE the wave
+//
+// What round 4's measurements said (tools/scratch/mix_bench.hip, the ablation table of tools/attn_ablate.py):
+//   * v_mfma_f32_32x32x16_bf16 followed by 2 v_exp + 2 v_add + 1 v_cvt_pk IN THE SAME WAVE runs at 37.8 cycles per MFMA (5 plain VALU ops:
+//     33.5) -- the vector ALU work hides under the matrix pipe when it is interleaved at that grain;
+//   * the same work in PHASES (a run of MFMAs, then a run of VALU) does not overlap across the waves of a SIMD: the ablation of the phased
+//     kernel is additive (MFMAs alone 14.5 us, softmax VALU alone 11.5 us, together 29 us), whatever the occupancy (2, 3, 4 waves).
+// So every MFMA group needs an INDEPENDENT VALU chain beside it.  The two query blocks A, B of a wave alternate (' = the previous step):
+//     G1:  S_A = K Q_A - m_A  (8 MFMA)   beside   P_B'[keys 32..63] = 2^S_B'        check B'
+//     G2:  O_B += V' P_B'     (8 MFMA)   beside   P_A[keys 0..31]   = 2^S_A
+//     G3:  S_B = K Q_B - m_B  (8 MFMA)   beside   P_A[keys 32..63]  = 2^S_A         check A
+//     G4:  O_A += V P_A       (8 MFMA)   beside   P_B[keys 0..31]   = 2^S_B
+// S is single-buffered (a block's scores are consumed before its next S^T chain starts), B trails A by half a step.  K / V arrive by LDS-DMA
+// into two three-slot rings (V of the previous step is still read in G2), one barrier per step.
+// ------------------------------------------------------------------------------------------------------
+template <int N_> struct AIC { static constexpr int value = N_; };
+template <bool PROBE = false, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                 const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int H, int N,
+                                                                 int Npad, float thresh, unsigned long long* __restrict__ probe) {
+  constexpr int DH = 64, KT = 64, ROWB = 128, NKK = 4, NDB = 2, TILE_B = KT * ROWB, RPP = 8, CPR = 8, DPO = 2, NSLOT = 3;
+  constexpr int KSLOT = 2;                   // K of step i is read in step i only: two slots (V: also in G2 of step i + 1: three)
+  constexpr int QOFF = (KSLOT + NSLOT) * TILE_B;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[QOFF + 4 * TILE_B];      // K ring, V ring, Q image of every wave (64 rows each)
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4 lds_v4;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, ql = lane & 31;
+  int bh = blockIdx.y, qt = blockIdx.x;
+  if ((gridDim.y & 7) == 0) {                // all query tiles of a head on one XCD (its K / V stay in that L2)
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, idx = lin >> 3;
+    bh = (idx / (int)gridDim.x) * 8 + xcd;
+    qt = idx % (int)gridDim.x;
+  }
+  const int q0 = (qt * 4 + wave) * 64;
+  const bool active = q0 < N;                // wave-uniform
+  const bf16_t* Qb = Q + (long)bh * Npad * DH;
+  const bf16_t* Kb = K + (long)bh * Npad * DH;
+
+  auto make_srd = [&](const bf16_t* base) __attribute__((always_inline)) -> u32x4 {
+    const unsigned long long a = (unsigned long long)(const void*)base;
+    u32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    d[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    d[2] = __builtin_amdgcn_readfirstlane((unsigned)(N * ROWB));             // rows >= N read as zeros
+    d[3] = 0x00020000u;
+    return d;
+  };
+  const u32x4 rk = make_srd(Kb), rv = make_srd(V + (long)bh * Npad * DH);
+  unsigned vk_off, vv_off;                   // LDS images and source-side swizzles of attn_fwd_kernel
+  {
+    const int rip = lane / CPR, pc = lane % CPR;
+    const int swk = (((wave & 1) << 2) | (rip >> 1)) & 7;
+    const int swv = ((rip >> 1) & 1) << 2;
+    vk_off = (unsigned)(rip * ROWB + ((pc ^ swk) << 4));
+    vv_off = (unsigned)(rip * ROWB + ((pc ^ swv) << 4));
+  }
+  auto dma16 = [&](const u32x4& srd, unsigned voff, unsigned soff, unsigned lds_addr) __attribute__((always_inline)) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr) : "memory");
+  };
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int ntiles = (N + KT - 1) / KT;
+  // step 0 = the ragged last tile, step i = tile i - 1; steps past the end name a tile beyond N (zeros through the bounds check, never read)
+  auto tile_of = [&](int i) __attribute__((always_inline)) -> int { return i == 0 ? ntiles - 1 : (i < ntiles ? i - 1 : ntiles); };
+  auto dma_op = [&](const u32x4& srd, unsigned voff, int slot_base, int step) __attribute__((always_inline)) {
+    const int tile = tile_of(step);
+#pragma unroll
+    for (int j = 0; j < DPO; j++) {
+      const int piece = wave + 4 * j;
+      const unsigned soff = (unsigned)((tile * KT + piece * RPP) * ROWB);
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot_base + piece * 1024);
+      dma16(srd, voff, soff, dst);
+    }
+  };
+  auto dma_k = [&](int step) __attribute__((always_inline)) { dma_op(rk, vk_off, (step % KSLOT) * TILE_B, step); };
+  auto dma_v = [&](int step) __attribute__((always_inline)) { dma_op(rv, vv_off, (KSLOT + step % NSLOT) * TILE_B, step); };
+  auto kslot = [&](int step) __attribute__((always_inline)) -> const unsigned char* { return smem + (step % KSLOT) * TILE_B; };
+  auto vslot = [&](int step) __attribute__((always_inline)) -> const unsigned char* { return smem + (KSLOT + step % NSLOT) * TILE_B; };
+
+  // this wave's 64 query rows: an LDS image like a K tile's (rows past N read as zeros; they are never stored), 8 pieces of 8 rows; the B
+  // fragments of the S^T chains are read from it (in registers they cost 32 VGPRs the pipelined loop does not have)
+  const unsigned char* Qs = smem + QOFF + wave * TILE_B;
+  {
+    const u32x4 rq = make_srd(Qb);
+    const int rip = lane / CPR, pc = lane % CPR;
+#pragma unroll
+    for (int piece = 0; piece < 8; piece++) {
+      const int swq = (((piece & 1) << 2) | (rip >> 1)) & 7;
+      const unsigned voff = (unsigned)(rip * ROWB + ((pc ^ swq) << 4));
+      const unsigned soff = (unsigned)((q0 + piece * RPP) * ROWB);
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + QOFF + wave * TILE_B + piece * 1024);
+      dma16(rq, voff, soff, dst);
+    }
+  }
+  dma_k(0); dma_v(0); dma_k(1); dma_v(1);
+
+  f32x16 acc_o[2][NDB], s[2][2], cinit[2];
+  bf16x8 pf[2][4];
+  float m[2], l[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; qb++) {
+    l[qb] = 0.f; m[qb] = 0.f;
+#pragma unroll
+    for (int d = 0; d < NDB; d++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc_o[qb][d][r] = 0.f;
+  }
+  const int ksw = (ql >> 1) & 7;
+  const int krow = ql * ROWB;
+  const int g = lane >> 4, p16 = lane & 15;
+  const int vf_sel = (p16 >> 3) & 1;
+  const int vlane = (4 * (g >> 1) + (p16 >> 2)) * ROWB + 32 * (g & 1) + 8 * (p16 & 3);
+  auto kfrag = [&](const unsigned char* Ks, int kb, int kk) __attribute__((always_inline)) -> bf16x8 {
+    return *(const bf16x8*)(Ks + kb * 32 * ROWB + krow + (((kk * 2 + half) ^ ksw) << 4));
+  };
+  auto vfrag = [&](const unsigned char* Vs, int step, int d) __attribute__((always_inline)) -> bf16x8 {
+    const unsigned char* vp = Vs + vlane + (16 * step) * ROWB + ((d ^ vf_sel) << 6);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)vp);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(vp + 8 * ROWB));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  auto qfrag = [&](int qb, int kk) __attribute__((always_inline)) -> bf16x8 { return kfrag(Qs, qb, kk); };
+  auto qk = [&](int qb, const unsigned char* Ks, const f32x16& cin) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < NKK; kk++) {
+      const bf16x8 b = qfrag(qb, kk);
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+        s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(Ks, kb, kk), b, kk == 0 ? cin : s[qb][kb], 0, 0, 0);
+    }
+  };
+  auto pv = [&](int qb, const unsigned char* Vs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int step = 0; step < 4; step++)
+#pragma unroll
+      for (int d = 0; d < NDB; d++)
+        acc_o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(Vs, step, d), pf[qb][step], acc_o[qb][d], 0, 0, 0);
+  };
+  // P = 2^S of one 32-key block, packed for its two PV steps; returns this lane's partial row sum
+  auto expo = [&](int qb, int kb) __attribute__((always_inline)) -> float {
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = __builtin_amdgcn_exp2f(s[qb][kb][r]), p1 = __builtin_amdgcn_exp2f(s[qb][kb][r + 1]);
+      t0 += p0; t1 += p1;
+      pf[qb][kb * 2 + (r >> 3)][r & 7] = (bf16_t)p0;
+      pf[qb][kb * 2 + (r >> 3)][(r & 7) + 1] = (bf16_t)p1;
+    }
+    return t0 + t1;
+  };
+  // ---- the pipelined step as 32 pinned slots: slot n = MFMA n + the two exponentials of pair n + the sums / packing of pair n - 1 + the
+  //      LDS reads of the fragments MFMA n + 2 needs; nothing moves across a slot boundary (sched_barrier) ----
+  //   MFMA n:  0..7  S_A chain (kk = n >> 1, kb = n & 1)      8..15 O_B += V' P_B' (step = (n - 8) >> 1, d = n & 1)
+  //           16..23 S_B chain                                24..31 O_A += V P_A
+  //   pair n: chain n >> 3 = 0: (B, keys 32..63) of the previous step, 1: (A, 0..31), 2: (A, 32..63), 3: (B, 0..31); scores 2 (n & 7), + 1
+  bf16x8 kfr[3], qfr[2], vfr[3];            // rotating fragment registers (compile-time indices)
+  float pp0 = 0.f, pp1 = 0.f;               // the pair whose sums / packing are pending
+  float ta0 = 0.f, ta1 = 0.f, tb0 = 0.f, tb1 = 0.f;      // partial row sums of the step in progress (block A, block B)
+  auto chain_qb = [](int c) constexpr { return (c == 1 || c == 2) ? 0 : 1; };
+  auto chain_kb = [](int c) constexpr { return (c == 0 || c == 2) ? 1 : 0; };
+  auto pair_exp = [&](auto nc) __attribute__((always_inline)) {
+    constexpr int n = decltype(nc)::value, c = (n >> 3) & 3, jj = n & 7, qb = (c == 1 || c == 2) ? 0 : 1, kb = (c == 0 || c == 2) ? 1 : 0;
+    if constexpr (ABL & 1) { pp0 = s[qb][kb][2 * jj]; pp1 = s[qb][kb][2 * jj + 1]; }
+    else {
+      pp0 = __builtin_amdgcn_exp2f(s[qb][kb][2 * jj]);
+      pp1 = __builtin_amdgcn_exp2f(s[qb][kb][2 * jj + 1]);
+    }
+  };
+  auto pair_finish = [&](auto nc) __attribute__((always_inline)) {        // sums and packing of pair n (its exponentials are in pp0 / pp1)
+    constexpr int n = decltype(nc)::value, c = (n >> 3) & 3, jj = n & 7, qb = (c == 1 || c == 2) ? 0 : 1, kb = (c == 0 || c == 2) ? 1 : 0;
+    // (the empty asm statements pin the sums and the packed pair to THIS slot: left alone, the SLP vectoriser pairs the adds of different
+    //  slots into v_pk_add_f32 and the conversions sink to the end of the region -- runs of VALU that no MFMA covers)
+    if constexpr (!(ABL & 64)) {
+      if constexpr (qb == 0) { ta0 += pp0; ta1 += pp1; asm volatile("" : "+v"(ta0), "+v"(ta1)); }
+      else { tb0 += pp0; tb1 += pp1; asm volatile("" : "+v"(tb0), "+v"(tb1)); }
+    }
+    bf16x2 t2;
+    unsigned u;
+    if constexpr (ABL & 128) { u = __builtin_bit_cast(unsigned, pp0) ^ __builtin_bit_cast(unsigned, pp1); }
+    else {
+      t2[0] = (bf16_t)pp0; t2[1] = (bf16_t)pp1;
+      u = __builtin_bit_cast(unsigned, t2);
+      asm volatile("" : "+v"(u));
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w = __builtin_bit_cast(u32x4, pf[qb][kb * 2 + (jj >> 2)]);
+    w[jj & 3] = u;
+    pf[qb][kb * 2 + (jj >> 2)] = __builtin_bit_cast(bf16x8, w);
+  };
+  // fragment loads of MFMA n (issued two slots ahead): S^T chains: K (kb, kk) into kfr[n % 3] and, for even n, Q (qb, kk) into qfr[kk & 1];
+  // PV: V (step, d) into vfr[n % 3]
+  auto frag_load = [&](auto nc, const unsigned char* Ks, const unsigned char* Vp, const unsigned char* Vc) __attribute__((always_inline)) {
+    constexpr int n = decltype(nc)::value & 31, grp = n >> 3, jj = n & 7;
+    if constexpr (ABL & 8) { } else
+    if constexpr (grp == 0 || grp == 2) {
+      constexpr int kk = jj >> 1, kb = jj & 1, qb = grp == 0 ? 0 : 1;
+      kfr[n % 3] = kfrag(Ks, kb, kk);
+      if constexpr (kb == 0) qfr[kk & 1] = qfrag(qb, kk);
+    } else {
+      constexpr int step = jj >> 1, d = jj & 1;
+      vfr[n % 3] = vfrag(grp == 1 ? Vp : Vc, step, d);
+    }
+  };
+  auto mfma_slot = [&](auto nc) __attribute__((always_inline)) {
+    constexpr int n = decltype(nc)::value, grp = n >> 3, jj = n & 7;
+    if constexpr (grp == 0 || grp == 2) {
+      constexpr int kk = jj >> 1, kb = jj & 1, qb = grp == 0 ? 0 : 1;
+      s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[n % 3], qfr[kk & 1], kk == 0 ? cinit[qb] : s[qb][kb], 0, 0, 0);
+    } else {
+      constexpr int step = jj >> 1, d = jj & 1, qb = grp == 1 ? 1 : 0;
+      acc_o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[n % 3], pf[qb][step], acc_o[qb][d], 0, 0, 0);
+    }
+  };
+  // the cold path (see attn_fwd_w64_kernel): step `step` of block qb overflowed against the reference m
+  auto rescue = [&](int qb, int step) __attribute__((always_inline)) -> float {
+    const int tile = step - 1;
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; r++) z[r] = 0.f;
+    f32x16 rs[2];
+#pragma unroll
+    for (int kk = 0; kk < NKK; kk++)
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        const bf16x8 a = *(const bf16x8*)(Kb + (long)(tile * KT + kb * 32 + ql) * DH + kk * 16 + half * 8);
+        rs[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qfrag(qb, kk), kk == 0 ? z : rs[kb], 0, 0, 0);
+      }
+    float mx = rs[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, rs[kb][r]);
+    mx = other_half_max(mx);
+    const float mn = fmaxf(m[qb], mx);
+    const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
+    m[qb] = mn;
+    l[qb] *= alpha;
+#pragma unroll
+    for (int d = 0; d < NDB; d++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc_o[qb][d][r] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cinit[qb][r] = -mn;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[qb][kb][r] = rs[kb][r] - mn;
+    const float a0 = expo(qb, 0);
+    return a0 + expo(qb, 1);
+  };
+
+  // ---- step 0: the ragged tile with its masked row maximum; block A complete, block B up to its first 32 keys ----
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * DPO) : "memory");      // Q, K of step 0
+  __builtin_amdgcn_s_barrier();
+  if (active) {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; r++) z[r] = 0.f;
+    const int t0 = ntiles - 1;
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+      qk(qb, kslot(0), z);
+      float mx = -3e38f;
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int key = t0 * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= N) s[qb][kb][r] = -3e38f;
+          mx = fmaxf(mx, s[qb][kb][r]);
+        }
+      mx = other_half_max(mx);
+      m[qb] = mx;
+#pragma unroll
+      for (int r = 0; r < 16; r++) cinit[qb][r] = -mx;
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[qb][kb][r] -= mx;
+    }
+    const float a0 = expo(0, 0);
+    l[0] = a0 + expo(0, 1);
+    // block B's first 32 keys in the loop's own form: pairs 24 .. 30 finished, pair 31 pending
+    [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) {
+      ([&] { pair_exp(AIC<24 + J>{}); if constexpr (J < 7) pair_finish(AIC<24 + J>{}); }(), ...);
+    }(std::make_integer_sequence<int, 8>{});
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DPO) : "memory");      // V of step 0
+  __builtin_amdgcn_s_barrier();
+  if (active) pv(0, vslot(0));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // K, V of step 1
+  __builtin_amdgcn_s_barrier();
+
+  // ---- steps 1 .. ntiles - 1 ----
+  for (int i = 1; i < ntiles; i++) {
+    if constexpr (!(ABL & 16)) { dma_v(i + 1); dma_k(i + 1); }             // V slot of step i - 2 (last read in G2 of step i - 1), K slot of step i - 1
+    if (active) {
+      const unsigned char* Ks = kslot(i);
+      const unsigned char* Vp = vslot(i - 1);
+      const unsigned char* Vc = vslot(i);
+      frag_load(AIC<0>{}, Ks, Vp, Vc);
+      frag_load(AIC<1>{}, Ks, Vp, Vc);
+      __builtin_amdgcn_sched_barrier(0);
+      auto run = [&](auto n0c, auto n1c) __attribute__((always_inline)) {      // slots [n0, n1)
+        constexpr int n0 = decltype(n0c)::value, n1 = decltype(n1c)::value;
+        [&]<int... J>(std::integer_sequence<int, J...>) __attribute__((always_inline)) {
+          ([&] {
+            constexpr int n = n0 + J;
+            mfma_slot(AIC<n>{});
+            if constexpr (n != 8 && n != 24) pair_finish(AIC<(n + 31) & 31>{});      // pair n - 1 (slot 0: the last pair of the previous step's G4)
+            pair_exp(AIC<n>{});
+            if constexpr (n + 2 < 32) frag_load(AIC<n + 2>{}, Ks, Vp, Vc);
+            if constexpr (n == 7 || n == 23) pair_finish(AIC<n>{});      // a check follows: nothing pending across it
+            __builtin_amdgcn_sched_barrier(0);
+          }(), ...);
+        }(std::make_integer_sequence<int, n1 - n0>{});
+      };
+      // slot 0 finishes pair 31 of the previous step; slots 8 and 24 must NOT finish pairs 7 / 23 again
+      run(AIC<0>{}, AIC<8>{});
+      {
+        float lt_b = tb0 + tb1;
+        if (i > 1 && __builtin_expect(!__all(lt_b < thresh), 0)) lt_b = rescue(1, i - 1);
+        l[1] += lt_b; tb0 = 0.f; tb1 = 0.f;
+      }
+      run(AIC<8>{}, AIC<24>{});
+      {
+        float lt_a = ta0 + ta1;
+        if (__builtin_expect(!__all(lt_a < thresh), 0)) lt_a = rescue(0, i);
+        l[0] += lt_a; ta0 = 0.f; ta1 = 0.f;
+      }
+      run(AIC<24>{}, AIC<32>{});
+    }
+    if constexpr (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // V, K of step i + 1 (requested at the top of this step)
+    if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+  }
+  // ---- drain: block B's last step ----
+  if (!active) return;
+  {
+    pair_finish(AIC<31>{});
+    float lt_b = tb0 + tb1 + expo(1, 1);
+    if (ntiles > 1 && __builtin_expect(!__all(lt_b < thresh), 0)) lt_b = rescue(1, ntiles - 1);
+    l[1] += lt_b;
+    pv(1, vslot(ntiles - 1));
+  }
+  // ---- finalize: O[q][dv] = O^T[dv][q] / l ----
+  const int b = bh / H, h = bh % H;
+#pragma unroll
+  for (int qb = 0; qb < 2; qb++) {
+    const float lsum = l[qb] + __shfl_xor(l[qb], 32, 64);
+    const float inv = 1.f / lsum;
+    const int q = q0 + qb * 32 + ql;
+    if (q < N) {
+      bf16_t* op = O + ((long)b * N + q) * ((long)H * DH) + (long)h * DH;
+#pragma unroll
+      for (int d = 0; d < NDB; d++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+          bf16x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) o4[e] = (bf16_t)(acc_o[qb][d][g4 * 4 + e] * inv);
+          *(bf16x4*)(op + d * 32 + 8 * g4 + 4 * half) = o4;
+        }
+    }
   }
 }
 
@@ -907,7 +1293,7 @@ extern "C" int du_debug_attn_occupancy(int which) {
   int n = -1;
   hipError_t e;
   if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_w64_kernel<64, 2>, 256, 0);
-  else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_w64_kernel<128, 1>, 256, 0);
+  else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<128, false>, 256, 0);
   else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<64, false>, 256, 0);
   return e == hipSuccess ? n : -1;
 }
@@ -917,24 +1303,21 @@ extern "C" int du_attention_fwd(const void* q, const void* k, const void* v, voi
   hipStream_t st = (hipStream_t)stream;
   if (!q || !k || !v || !out || B <= 0 || H <= 0 || N <= 0 || Npad < N) return DU_ERR_BAD_ARG;
   if ((long)N * Dh * 2 > 0x7fffffffL) return DU_ERR_UNSUPPORTED;
-  if (g_attn_impl == 0 && (g_attn_w & ~64) == 0 && (Dh == 64 || Dh == 128)) {
-    // 64 (d_head 128: 32) queries per wave, two workgroups per CU (attn_fwd_w64_kernel); threshold of the cold rescale path: 2^60 unless a
-    // test turned it down
+  if (g_attn_impl == 0 && (g_attn_w & ~64) == 0 && Dh == 64) {
+    // 64 queries per wave, two workgroups per CU (attn_fwd_w64_kernel); threshold of the cold rescale path: 2^60 unless a test turned it
+    // down.  d_head 128 stays on attn_fwd_kernel (O alone is 128 registers for 64 queries; at 32 queries per wave the two kernels tie).
+    // g_attn_var (du_set_option key 8, tools only): 1000 + bits = timing ablations, 7 = second block's exponentials beside the first block's
+    // PV, 9 = the slot-pipelined kernel
     const float thresh = g_attn_thresh_log2 <= -1000 ? 0.f : ldexpf(1.f, g_attn_thresh_log2);
-    if (Dh == 64 && (g_attn_w & 64)) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2, true>), dim3((N + 255) / 256, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, attn_probe_buffer());
-#define DU_ABL2(bits) else if (Dh == 64 && g_attn_var == 1000 + (bits)) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2, false, 2, (bits)>), dim3((N + 255) / 256, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
-#define DU_ABL1(bits) else if (Dh == 64 && g_attn_var == 2000 + (bits)) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 1, false, 4, (bits)>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
+    const dim3 g64((N + 255) / 256, B * H), b64(256);
+#define DU_W64_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh
+    if (g_attn_w & 64) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2, true>), g64, b64, 0, st, DU_W64_ARGS, attn_probe_buffer());
+#define DU_ABL2(bits) else if (g_attn_var == 1000 + (bits)) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2, false, 2, (bits)>), g64, b64, 0, st, DU_W64_ARGS, nullptr);
     DU_ABL2(1) DU_ABL2(2) DU_ABL2(4) DU_ABL2(6) DU_ABL2(193) DU_ABL2(8) DU_ABL2(48) DU_ABL2(56) DU_ABL2(199) DU_ABL2(255) DU_ABL2(249)
-    DU_ABL1(1) DU_ABL1(2) DU_ABL1(4) DU_ABL1(6) DU_ABL1(193) DU_ABL1(8) DU_ABL1(48) DU_ABL1(56) DU_ABL1(199) DU_ABL1(255) DU_ABL1(249)
-    else if (Dh == 64 && g_attn_var == 7) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2, false, 2, 0, 3>), dim3((N + 255) / 256, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
-    else if (Dh == 64 && g_attn_var == 3) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2, false, 2, 0, 1>), dim3((N + 255) / 256, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
-    else if (Dh == 64 && g_attn_var == 4) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 1, false, 4, 0, 1>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
-    else if (Dh == 64 && g_attn_var == 5) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 1, false, 4, 0, 2>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
-    else if (Dh == 64 && g_attn_var == 6) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 1, false, 3, 0, 1>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
-    else if (Dh == 64 && g_attn_var == 1) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 1, false, 3>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
-    else if (Dh == 64 && g_attn_var == 2) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 1, false, 4>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
-    else if (Dh == 64) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2>), dim3((N + 255) / 256, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
-    else hipLaunchKernelGGL((attn_fwd_w64_kernel<128, 1>), dim3((N + 127) / 128, B * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, H, N, Npad, thresh, nullptr);
+    else if (g_attn_var == 7) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2, false, 2, 0, 3>), g64, b64, 0, st, DU_W64_ARGS, nullptr);
+    else if (g_attn_var == 9) hipLaunchKernelGGL((attn_fwd_pipe_kernel<false>), g64, b64, 0, st, DU_W64_ARGS, nullptr);
+    else if (g_attn_var == 1) hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 2>), g64, b64, 0, st, DU_W64_ARGS, nullptr);
+    else hipLaunchKernelGGL((attn_fwd_w64_kernel<64, 1, false, 4>), dim3((N + 127) / 128, B * H), b64, 0, st, DU_W64_ARGS, nullptr);
     return du_check_launch();
   }
   dim3 grid((N + 127) / 128, B * H), block(256);

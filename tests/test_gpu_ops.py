@@ -959,6 +959,95 @@ def test_vit_attention(dt, B, H, N, Dh):
     assert rel(out, ref) < (2e-4 if dt == torch.float32 else 3e-2)
 
 
+def _attn_raw(q_, k_, v_, B, H, N, Dh):
+    import ctypes as C
+    from dinounet_amd import _lib
+    Npad = q_.shape[2]
+    out = torch.zeros(B * N, H * Dh, dtype=torch.bfloat16, device=q_.device)
+    _lib.check(_lib.lib().du_attention_fwd(C.c_void_p(q_.data_ptr()), C.c_void_p(k_.data_ptr()), C.c_void_p(v_.data_ptr()), C.c_void_p(out.data_ptr()),
+                                          B, H, N, Npad, Dh, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "du_attention_fwd")
+    return out
+
+
+def _attn_ref(q_, k_, v_, B, H, N, Dh):
+    import math
+    s = torch.einsum("bhqd,bhkd->bhqk", q_[:, :, :N].double().cpu(), k_[:, :, :N].double().cpu()) * math.log(2.0)      # q carries log2(e): base-2 softmax
+    return torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v_[:, :, :N].double().cpu()).permute(0, 2, 1, 3).reshape(B * N, H * Dh).float()
+
+
+# every attention kernel of the library: (du_set_option(6, impl), du_set_option(8, variant)): the product kernel (32 queries per wave, no
+# running maximum, nearly empty query tiles first), the round-3 kernel (d_head 128's product kernel), and the measured-and-kept experiments
+# (64 queries per wave; its slot-pipelined form)
+ATTN_KERNELS = [(0, 0, "product"), (1, 0, "round 3"), (0, 1, "64 q per wave"), (0, 9, "slot-pipelined")]
+
+
+@pytest.mark.parametrize("impl,var,name", ATTN_KERNELS)
+@pytest.mark.parametrize("Dh", [64, 128])
+def test_attention_spiked_keys_and_forced_rescale(impl, var, name, Dh):
+    """A rare data-dependent branch needs its own test: keys whose score lies 100 - 600 (log2 units) above everything the kernel has seen
+    so far -- in either half-wave, in the first (ragged) tile and later ones, one and several per query block.  The kernels without a running
+    maximum must take their cold rescale path (the probabilities overflow fp32 otherwise); the round-2 / 3 kernel once took its running
+    maximum from the lower half-wave's keys only (hipcc folded the two results of permlane32_swap) and returned NaN on exactly these inputs.
+    Reference: fp64 softmax of the same bf16 operands.  Also: with the threshold of the cold path turned down to zero (every tile takes
+    it = a true running maximum) the result stays within rounding."""
+    from dinounet_amd import _lib
+    L = _lib.lib()
+    d = dev()
+    B, H, N = 1, 2, 1029
+    Npad = (N + 7) // 8 * 8
+    g = torch.Generator().manual_seed(5)
+    cases = [[(5, 100, 300.0)], [(5, 104, 300.0)], [(5, 100, 300.0), (9, 700, 300.0)], [(5, 100, 140.0), (40, 708, 600.0), (70, 1026, 250.0)],
+             [(5, 10, 100.0), (5, 500, 300.0)], [(1027, 64, 200.0), (300, 1028, 200.0)]]
+    L.du_set_option(6, impl); L.du_set_option(8, var)
+    try:
+        for spikes in cases:
+            q_ = (torch.randn(B, H, Npad, Dh, generator=g) * 0.05).to(d, torch.bfloat16)
+            k_ = (torch.randn(B, H, Npad, Dh, generator=g) * 0.05).to(d, torch.bfloat16)
+            v_ = torch.randn(B, H, Npad, Dh, generator=g).to(d, torch.bfloat16)
+            for h in range(H):
+                for qrow, key, val in spikes:
+                    q_[0, h, qrow] = 0; q_[0, h, qrow, (qrow + h) % Dh] = 1.0
+                for qrow, key, val in spikes:
+                    k_[0, h, key, (qrow + h) % Dh] = val
+            ref = _attn_ref(q_, k_, v_, B, H, N, Dh)
+            out = _attn_raw(q_, k_, v_, B, H, N, Dh)
+            assert bool(torch.isfinite(out.float()).all()), (name, spikes)
+            assert rel(out, ref) < 2e-2, (name, spikes)
+            if impl == 0 and Dh == 64:
+                L.du_set_option(7, -2000)
+                try:
+                    out0 = _attn_raw(q_, k_, v_, B, H, N, Dh)
+                finally:
+                    L.du_set_option(7, 60)
+                assert rel(out0, ref) < 2e-2, (name, spikes)
+    finally:
+        L.du_set_option(6, 0); L.du_set_option(8, 0)
+
+
+@pytest.mark.parametrize("impl,var,name", ATTN_KERNELS)
+@pytest.mark.parametrize("B,H,N,Dh", [(2, 8, 1029, 64), (1, 8, 64, 64), (1, 8, 65, 64), (1, 8, 7, 64), (2, 4, 1024, 64), (1, 8, 300, 128), (1, 3, 129, 64), (2, 16, 261, 64)])
+def test_attention_kernels_vs_fp64_softmax(impl, var, name, B, H, N, Dh):
+    """softmax(Q K^T) V of bf16 operands vs fp64, for every kernel and ragged / tiny / exact token counts; deterministic across runs."""
+    import math
+    from dinounet_amd import _lib
+    L = _lib.lib()
+    d = dev()
+    Npad = (N + 7) // 8 * 8
+    g = torch.Generator().manual_seed(N + Dh)
+    q_ = (torch.randn(B, H, Npad, Dh, generator=g) * Dh ** -0.5 * math.log2(math.e)).to(d, torch.bfloat16)
+    k_ = torch.randn(B, H, Npad, Dh, generator=g).to(d, torch.bfloat16)
+    v_ = torch.randn(B, H, Npad, Dh, generator=g).to(d, torch.bfloat16)
+    ref = _attn_ref(q_, k_, v_, B, H, N, Dh)
+    L.du_set_option(6, impl); L.du_set_option(8, var)
+    try:
+        out = _attn_raw(q_, k_, v_, B, H, N, Dh)
+        again = _attn_raw(q_, k_, v_, B, H, N, Dh)
+    finally:
+        L.du_set_option(6, 0); L.du_set_option(8, 0)
+    assert rel(out, ref) < 2e-2, name
+    assert torch.equal(out, again), name
+
+
 @pytest.mark.parametrize("B,H,N,D", [(8, 16, 1029, 1024), (2, 6, 1029, 384), (3, 12, 261, 768)])
 def test_vit_qkv_rope_in_gemm_epilogue(B, H, N, D):
     """qkv projection with RoPE + q scale + head-major store in the multi-phase GEMM's epilogue (DU_STORE_QKV_ROPE, rows past the last

@@ -4,6 +4,7 @@ import torch
 from dinounet_amd import _lib
 dev = torch.device("cuda", 0)
 L = _lib.lib()
+L.du_set_option(8, int(os.environ.get("ATT_VAR", "0")))
 def run(q, k, v, out, B, H, N, Npad, Dh):
     _lib.check(L.du_attention_fwd(C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(out.data_ptr()), B, H, N, Npad, Dh, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "x")
 Dh = 64; B, H, N = 1, 1, 1029
