@@ -204,14 +204,14 @@ __device__ __forceinline__ void stage_block_f32(const f32x16& a, float* stg, int
 }
 // rows [0, nrows) of the bf16 staging tile -> C rows mrow0 + ...: 16 bytes per lane, whole rows per wave.  TBN = staged columns,
 // n0 / ncols = first column / column count of C they map to (half the GEMM's for the SwiGLU gate)
-template <int TBN, bool QKV = false>
+template <int TBN, bool QKV = false, int NTHR = 512>
 __device__ __forceinline__ void readout_bf16(const GemmParams& P, const bf16_t* stg, int ldb, int nrows, int mrow0, int n0, int ncols,
                                              bf16_t* Cb, int tid) {
   constexpr int C8 = TBN / 8;
   // QKV: 8 consecutive d of one head are 16 contiguous bytes whatever the plane stride
   const bool wide = ((((uintptr_t)Cb) & 15) == 0) && P.ldc % 8 == 0 && (QKV || P.store_mode == DU_STORE_PLAIN || P.ps_C % 8 == 0);
 #pragma unroll 4
-  for (int v = tid; v < nrows * C8; v += 512) {
+  for (int v = tid; v < nrows * C8; v += NTHR) {
     const int row = v / C8, c8 = v % C8;
     const int m = mrow0 + row, n = n0 + c8 * 8;
     if (m >= P.M || n >= ncols) continue;
@@ -252,18 +252,18 @@ template <> struct RowVec<bf16_t, 8> {
   }
 };
 
-template <typename TC, int TBN, int ACT, int W>
+template <typename TC, int TBN, int ACT, int W, int NTHR = 512>
 __device__ __forceinline__ void readout_f32(const GemmParams& P, const float* stg, int ldf, int nrows, int mrow0, int n0, TC* Cb, const TC* Rb,
                                             int tid) {
   constexpr int CW = TBN / W, U = W == 8 ? 2 : 4;        // 16 residual floats in flight either way (the 256 x 256 kernel still holds
                                                           // half of its accumulators during the first pass)
   const int total = nrows * CW;
-  for (int v0 = tid; v0 < total; v0 += 512 * U) {
+  for (int v0 = tid; v0 < total; v0 += NTHR * U) {
     float rr[U][W];
     bool live[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const int v = v0 + u * 512;
+      const int v = v0 + u * NTHR;
       const int row = v / CW, cw = v % CW;
       const int m = mrow0 + row, n = n0 + cw * W;
       live[u] = v < total && m < P.M && n < P.N;
@@ -274,7 +274,7 @@ __device__ __forceinline__ void readout_f32(const GemmParams& P, const float* st
 #pragma unroll
     for (int u = 0; u < U; u++) {
       if (!live[u]) continue;
-      const int v = v0 + u * 512;
+      const int v = v0 + u * NTHR;
       const int row = v / CW, cw = v % CW;
       const int m = mrow0 + row, n = n0 + cw * W;
       float o[W];
@@ -316,23 +316,23 @@ __device__ __forceinline__ void readout_f32(const GemmParams& P, const float* st
 // thread (16 x 16 bytes) is requested BEFORE the accumulators are staged, so its HBM latency is paid once and under the staging pass;
 // readout_f32 keeps 4 loads in flight and pays it four times in a row (the epilogue was ~15 us of a 40 us proj product, r02 table).
 struct ResidualTile { float4 r[16]; };
-template <int TBN>
+template <int TBN, int NTHR = 512>
 __device__ __forceinline__ void residual_prefetch(const GemmParams& P, const float* Rb, int mrow0, int n0, int tid, ResidualTile& R) {
   constexpr int CW = TBN / 4;
 #pragma unroll
   for (int u = 0; u < 16; u++) {
-    const int v = tid + u * 512;
+    const int v = tid + u * NTHR;
     const int m = mrow0 + v / CW, n = n0 + (v % CW) * 4;
     R.r[u] = (m < P.M && n < P.N) ? *(const float4*)(Rb + (long)m * P.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
-template <int TBN>
+template <int TBN, int NTHR = 512>
 __device__ __forceinline__ void readout_f32_prefetched(const GemmParams& P, const float* stg, int ldf, int mrow0, int n0, float* Cb, int tid,
                                                        const ResidualTile& R) {
   constexpr int CW = TBN / 4;
 #pragma unroll
   for (int u = 0; u < 16; u++) {
-    const int v = tid + u * 512;
+    const int v = tid + u * NTHR;
     const int row = v / CW, cw = v % CW;
     const int m = mrow0 + row, n = n0 + cw * 4;
     if (m >= P.M || n >= P.N) continue;
@@ -358,7 +358,7 @@ __device__ __forceinline__ void readout_f32_prefetched(const GemmParams& P, cons
     *(float4*)(Cb + (long)m * P.ldc + n) = make_float4(o[0] + R.r[u].x, o[1] + R.r[u].y, o[2] + R.r[u].z, o[3] + R.r[u].w);
   }
 }
-template <typename TC, int TBN>
+template <typename TC, int TBN, int NTHR = 512>
 __device__ __forceinline__ void readout_f32_any(const GemmParams& P, const float* stg, int ldf, int nrows, int mrow0, int n0, TC* Cb,
                                                 const TC* Rb, int tid) {
   if constexpr (sizeof(TC) == 2) {
@@ -366,14 +366,14 @@ __device__ __forceinline__ void readout_f32_any(const GemmParams& P, const float
     const bool w8 = P.N % 8 == 0 && P.ldc % 8 == 0 && ((((uintptr_t)Cb) & 15) == 0) && (!Rb || (P.ldr % 8 == 0 && ((((uintptr_t)Rb) & 15) == 0))) &&
                     (P.store_mode == DU_STORE_PLAIN || P.ps_C % 8 == 0);
     if (w8) {
-      if (P.act == DU_ACT_NONE) readout_f32<TC, TBN, DU_ACT_NONE, 8>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
-      else readout_f32<TC, TBN, -1, 8>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
+      if (P.act == DU_ACT_NONE) readout_f32<TC, TBN, DU_ACT_NONE, 8, NTHR>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
+      else readout_f32<TC, TBN, -1, 8, NTHR>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
       return;
     }
   }
-  if (P.act == DU_ACT_NONE) readout_f32<TC, TBN, DU_ACT_NONE, 4>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
-  else if (P.act == DU_ACT_GELU) readout_f32<TC, TBN, DU_ACT_GELU, 4>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
-  else readout_f32<TC, TBN, -1, 4>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
+  if (P.act == DU_ACT_NONE) readout_f32<TC, TBN, DU_ACT_NONE, 4, NTHR>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
+  else if (P.act == DU_ACT_GELU) readout_f32<TC, TBN, DU_ACT_GELU, 4, NTHR>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
+  else readout_f32<TC, TBN, -1, 4, NTHR>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
 }
 // bf16 result whose epilogue is bias (+ GELU) only: staged as bf16 (the ViT's qkv and fc1)
 __device__ __forceinline__ bool bf16_simple(const GemmParams& P, const void* Rb) {
@@ -390,14 +390,14 @@ constexpr int P8_LDS = 256 * P8_STG_LDB * 2;   // 135 168 B >= 2 * BUF_B and >= 
 // 32 x 256 + 40 rows): workgroups behind the main tiles run the K-parallel skinny program on rows [P.M, P.M + tail_rows).  They are
 // dispatched when the first tiles retire and overlap the stragglers; as launches of their own the 40-row tails cost ~8 us each, 72 of
 // them per dinounet_l step (profiles/r02_launch_counts_v5.txt).
-template <typename TC>
+template <typename TC, int NW = 8>
 __device__ __forceinline__ void p8_tail(const GemmParams& P, unsigned char* smem) {
   SkinnyEpi E;
   E.C = (TC*)P.C + (long)P.M * P.ldc; E.ldc = P.ldc;
   E.residual = P.residual ? (const void*)((const TC*)P.residual + (long)P.M * P.ldr) : nullptr; E.ldr = P.ldr;
   E.bias = P.bias; E.gamma = P.gamma; E.row_scale = P.row_scale;
   E.alpha = P.alpha; E.act = P.act; E.rs_rows = P.rs_rows; E.out_bf16 = sizeof(TC) == 2; E.row0 = P.M;
-  skinny_fused_body<8>((const bf16_t*)P.a.p + (long)P.M * P.a.ld, P.a.ld, (const bf16_t*)P.b.p, P.b.ld, P.tail_rows, P.N, P.K, E, (float*)smem,
+  skinny_fused_body<NW>((const bf16_t*)P.a.p + (long)P.M * P.a.ld, P.a.ld, (const bf16_t*)P.b.p, P.b.ld, P.tail_rows, P.N, P.K, E, (float*)smem,
                        (int)blockIdx.x - P.main_wgs);
 }
 
@@ -1193,7 +1193,243 @@ __global__ __launch_bounds__(512) void gemm_nt_p8n_kernel(GemmParams P) {
   }
 }
 
-int g_p8_mode = -1;      // -1: heuristic, 0: off, 1: 256 x 256 wherever legal, 2: 256 x 128 wherever legal
+// ================================================================================================================================
+// 256 x 128 tiles on FOUR waves (2 x 2, 128 x 64 per wave), TWO workgroups per CU (round 4).
+//
+// Why: at K = 1024 (the ViT's qkv / fc1) a tile of the kernels above is 16 K-steps between a cold prologue and an exposed epilogue, and
+// with ONE workgroup per CU (135 - 147 KB of LDS, 8 waves) the matrix pipe idles through both: 14 - 22 us of a 65 - 84 us product
+// (profiles/r03_gemm_p8_table_v2.txt).  Two smaller workgroups per CU overlap them: the SIMD arbitrates oldest-first, so the older
+// workgroup runs its main loop at full speed while the younger one trails, and when the older one leaves the matrix pipe for its epilogue
+// (bias / GELU / LayerScale + residual in registers, LDS-staged row stores) the younger one takes the pipe -- measured on this chip a pure
+// MFMA stream and a pure VALU stream of DIFFERENT waves share a SIMD at full speed each (tools/scratch/corun_bench.hip: 32.5 cycles per
+// MFMA beside 6.1 cycles per v_add against 32.1 / 4.6 alone).  The dispatcher then keeps the pairs de-phased by itself.
+//
+//   * LDS: three 24 KB stages of K = 32 { A: 256 rows x 64 B, B: 128 rows x 64 B } = 72 KB per workgroup.  64-byte rows put four rows on one
+//     256-byte bank row: 16-byte chunk c of row r sits at chunk c ^ ((r >> 2) & 3) (source-side swizzle of the DMA, undone in the
+//     ds_read_b128 address): the 16 lanes of a read group then touch 16 different 16-byte slots.
+//   * a wave's 128 x 64 tile reads 0.75 LDS fragments per MFMA (the 64 x 64 tile of the 8-wave 256 x 128 kernel: 1.0).
+//   * a stage is cut into two k-halves of 8 MFMAs; every half reads the NEXT half's fragments into the other register set; the DMA of
+//     stage s + 3 goes into the buffer of stage s right behind the barrier that ends its last fragment read; counted vmcnt(6) (one stage
+//     stays in flight), one raw barrier per stage.  Steps past K are requested beyond the descriptor's range (zeros, no traffic, never
+//     read), so the wait counts hold for any K.
+//   * epilogues: the helpers of the 8-wave kernels with 256 threads; the bf16 tile is staged whole (68 KB), the fp32 tile in two passes of
+//     128 rows (the ring is 72 KB).
+// ================================================================================================================================
+constexpr int P4_STAGE_B = (256 + 128) * 32 * 2;       // 24 KB
+constexpr int P4_LDS = 3 * P4_STAGE_B;                 // 73 728 B >= 256 * N_STG_LDB * 2 = 69 632 and >= 128 * N_STG_LDF * 4 = 67 584
+
+template <typename TC>
+__global__ __launch_bounds__(256, 2) void gemm_nt_p4_kernel(GemmParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<TC, 4>(P, smem); return; }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int tm, tn;
+  tile_coords(P, tm, tn);
+  const int m0 = tm * PBM, n0 = tn * NBN;
+  const int batch = blockIdx.y;
+
+  const bf16_t* Ab = (const bf16_t*)P.a.p + (long)batch * P.a.bstride + (long)m0 * P.a.ld;
+  const bf16_t* Bb = (const bf16_t*)P.b.p + (long)batch * P.b.bstride + (long)n0 * P.b.ld;
+  long abytes = ((long)(P.M - m0) * P.a.ld - (P.a.ld - P.K)) * 2, bbytes = ((long)(P.N - n0) * P.b.ld - (P.b.ld - P.K)) * 2;
+  if (abytes > 0x6fffffffL) abytes = 0x6fffffffL;
+  if (bbytes > 0x6fffff00L) bbytes = 0x6fffff00L;
+  const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)abytes, 0x00020000);
+  const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (int)bbytes, 0x00020000);
+
+  // DMA: piece = 16 rows x 64 B; lane l -> row (l >> 2), physical chunk l & 3 = logical chunk ^ ((row >> 2) & 3), (row >> 2) & 3 = (l >> 4) & 3
+  unsigned va[4], vb[2];
+  {
+    const int lc = (lane & 3) ^ ((lane >> 4) & 3);
+#pragma unroll
+    for (int j = 0; j < 4; j++) va[j] = (unsigned)((wave + 4 * j) * 16 + (lane >> 2)) * (unsigned)(P.a.ld * 2) + lc * 16;
+#pragma unroll
+    for (int j = 0; j < 2; j++) vb[j] = (unsigned)((wave + 4 * j) * 16 + (lane >> 2)) * (unsigned)(P.b.ld * 2) + lc * 16;
+  }
+  const int ns = P.K / 32;
+  auto stage = [&](int st, int bo) {
+    const unsigned soff = st < ns ? (unsigned)st * 64u : 0x70000000u;       // past K: beyond the descriptors' range (zeros, no traffic)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(smem + bo + (wave + 4 * j) * 1024), 16, va[j], soff, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(smem + bo + 16384 + (wave + 4 * j) * 1024), 16, vb[j], soff, 0, 0);
+  };
+  // fragment address of row (lane & 31) of a 32-row block, k-half kk: logical chunk 2 kk + (lane >> 5)
+  int L[2];
+  {
+    const int r = lane & 31, hi = lane >> 5, sw = (r >> 2) & 3;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) L[kk] = r * 64 + (((kk * 2 + hi) ^ sw) << 4);
+  }
+  const int aoff = wm * 128 * 64, boff = 16384 + wn * 64 * 64;
+
+  bf16x8 Af[2][4];        // [register set = k-half parity][row block]
+  bf16x8 Bf[2][2];        // [set][column block]
+  f32x16 acc[4][2];       // [row block][column block]
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][c][r] = 0.f;
+
+  auto read_frags = [&](auto set_c, int bo) {          // k-half `set` of the stage at byte offset bo
+    constexpr int set = decltype(set_c)::value;
+#pragma unroll
+    for (int c = 0; c < 2; c++) Bf[set][c] = *(const bf16x8*)(smem + bo + boff + c * 2048 + L[set]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) Af[set][i] = *(const bf16x8*)(smem + bo + aoff + i * 2048 + L[set]);
+  };
+  auto mma = [&](auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+        acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[set][c], Af[set][i], acc[i][c], 0, 0, 0);
+  };
+  auto pin = [&](auto ndma_c) {
+    constexpr int ndma = decltype(ndma_c)::value;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (m < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (m >= 2 && m - 2 < ndma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    }
+  };
+
+  // ---- prologue: stages 0 .. 2 requested, stage 0 landed, its first k-half in registers ----
+  stage(0, 0); stage(1, P4_STAGE_B); stage(2, 2 * P4_STAGE_B);
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_frags(IC<0>{}, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  int bc = 0, bn = P4_STAGE_B, bnn = 2 * P4_STAGE_B;       // byte offsets of the buffers of stages s, s + 1, s + 2
+  for (int st = 0; st < ns; st++) {
+    // first k-half: the second half's fragments arrive meanwhile; then stage s + 1 must have landed (stage s + 2 may fly)
+    read_frags(IC<1>{}, bc);
+    mma(IC<0>{});
+    pin(IC<0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // second k-half: stage s + 3 into this stage's buffer (every wave has read it), first k-half of stage s + 1 into the other set
+    read_frags(IC<0>{}, bn);
+    stage(st + 3, bc);
+    mma(IC<1>{});
+    pin(IC<6>{});
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const int o = bc; bc = bn; bn = bnn; bnn = o;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the out-of-range requests of the last steps: nothing may land in the staging tile)
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue ----
+  TC* Cb = (TC*)P.C + (long)batch * P.cbs;
+  const TC* Rb = (const TC*)P.residual;
+  if (Rb) Rb += (long)batch * P.cbs;
+  if (P.dbg & 2) return;
+  if constexpr (sizeof(TC) == 2) {
+    if (bf16_simple(P, Rb) && P.act != DU_ACT_SWIGLU && P.store_mode != DU_STORE_QKV_ROPE) {
+      bf16_t* stg = (bf16_t*)smem;
+      const int hi = lane >> 5;
+      float4 bv[2][4];
+#pragma unroll
+      for (int c = 0; c < 2; c++) load_bias4(P, n0 + wn * 64 + c * 32, hi, bv[c]);
+      auto stage_all = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int c = 0; c < 2; c++)
+            stage_block_bf16<ACT>(acc[i][c], bv[c], stg, N_STG_LDB, wm * 128 + i * 32 + (lane & 31), wn * 64 + c * 32, hi);
+      };
+      if (P.act == DU_ACT_GELU) stage_all(IC<DU_ACT_GELU>{}); else stage_all(IC<DU_ACT_NONE>{});
+      __syncthreads();
+      readout_bf16<NBN, false, 256>(P, stg, N_STG_LDB, 256, m0, n0, P.N, (bf16_t*)Cb, tid);
+      return;
+    }
+  }
+  // fp32 staging, two passes: pass h holds row blocks 2 h, 2 h + 1 of both wave rows = tile rows wm * 128 + h * 64 + [0, 64)
+  float* stg = (float*)smem;
+  bool pre = false;
+  if constexpr (sizeof(TC) == 4) {
+    pre = Rb && P.store_mode == DU_STORE_PLAIN && !(P.dbg & 4) && P.ldr % 4 == 0 && P.ldc % 4 == 0 && !((((uintptr_t)Rb) | ((uintptr_t)Cb)) & 15);
+  }
+  auto pass = [&](auto h_c) {
+    constexpr int h = decltype(h_c)::value;
+    if constexpr (h > 0) __syncthreads();
+    stage_block_f32(acc[2 * h][0], stg, N_STG_LDF, wm * 64 + (lane & 31), wn * 64, lane);
+    stage_block_f32(acc[2 * h][1], stg, N_STG_LDF, wm * 64 + (lane & 31), wn * 64 + 32, lane);
+    stage_block_f32(acc[2 * h + 1][0], stg, N_STG_LDF, wm * 64 + 32 + (lane & 31), wn * 64, lane);
+    stage_block_f32(acc[2 * h + 1][1], stg, N_STG_LDF, wm * 64 + 32 + (lane & 31), wn * 64 + 32, lane);
+    __syncthreads();
+    // staging rows [0, 64) = tile rows h * 64 + [0, 64), staging rows [64, 128) = tile rows 128 + h * 64 + [0, 64)
+    auto half = [&](auto w_c) {
+      constexpr int w = decltype(w_c)::value;
+      const int mrow0 = m0 + w * 128 + h * 64;
+      const float* sp = stg + w * 64 * N_STG_LDF;
+      if constexpr (sizeof(TC) == 4) {
+        if (pre) {
+          // 64 rows x 128 columns = 2048 float4 = 8 per thread: the residual requested up front (its latency is paid once per half)
+          constexpr int CW = NBN / 4;
+          float4 rr[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int v = tid + u * 256;
+            const int m = mrow0 + v / CW, n = n0 + (v % CW) * 4;
+            rr[u] = (m < P.M && n < P.N) ? *(const float4*)((const float*)Rb + (long)m * P.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int v = tid + u * 256;
+            const int row = v / CW, cw = v % CW;
+            const int m = mrow0 + row, n = n0 + cw * 4;
+            if (m < P.M && n < P.N) {
+              const float4 tt = *(const float4*)(sp + row * N_STG_LDF + cw * 4);
+              float o[4] = {tt.x * P.alpha, tt.y * P.alpha, tt.z * P.alpha, tt.w * P.alpha};
+              if (P.bias) {
+                const float4 bb = *(const float4*)(P.bias + n);
+                o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
+              }
+              if (P.act != DU_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = apply_act(o[e], P.act);
+              }
+              if (P.gamma) {
+                const float4 gg = *(const float4*)(P.gamma + n);
+                o[0] *= gg.x; o[1] *= gg.y; o[2] *= gg.z; o[3] *= gg.w;
+              }
+              if (P.row_scale) {
+                const float rs = P.row_scale[m / P.rs_rows];
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] *= rs;
+              }
+              *(float4*)((float*)Cb + (long)m * P.ldc + n) = make_float4(o[0] + rr[u].x, o[1] + rr[u].y, o[2] + rr[u].z, o[3] + rr[u].w);
+            }
+          }
+          return;
+        }
+      }
+      readout_f32_any<TC, NBN, 256>(P, sp, N_STG_LDF, 64, mrow0, n0, Cb, Rb, tid);
+    };
+    half(IC<0>{});
+    half(IC<1>{});
+  };
+  pass(IC<0>{});
+  pass(IC<1>{});
+}
+
+int g_p8_mode = -1;      // -1: heuristic, 0: off, 1: 256 x 256 wherever legal, 2: 256 x 128 wherever legal, 3: the 4-wave 256 x 128 kernel wherever legal
 int g_p8_sched = 1;
 int g_p8_group = 4;
 int g_p8_debug = 0;      // bit 0: skip the bf16 global stores, bit 1: skip the whole epilogue (timing ablations only)
@@ -1220,6 +1456,27 @@ int launch_p8(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
     attr_set = true;
   }
   hipLaunchKernelGGL(kfn, grid, dim3(512), LDS_BYTES, st, P);
+  return du_check_launch();
+}
+
+template <typename TC>
+int launch_p4(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
+  GemmParams P = make_params(a, DU_PLAIN_ROW, DU_PLAIN_ROW, PBM, NBN, 32);
+  P.tiles_m = (a.M + PBM - 1) / PBM;
+  P.group_m = g_p8_group;
+  P.dbg = g_p8_debug;
+  dim3 grid(P.tiles_m * P.tiles_n, a.batch < 1 ? 1 : a.batch);
+  if (tail_rows > 0) {
+    P.tail_rows = tail_rows; P.main_wgs = P.tiles_m * P.tiles_n;
+    grid.x += (a.N + SK_BN - 1) / SK_BN;
+  }
+  void (*kfn)(GemmParams) = gemm_nt_p4_kernel<TC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS) != hipSuccess) return DU_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kfn, grid, dim3(256), P4_LDS, st, P);
   return du_check_launch();
 }
 
@@ -1303,12 +1560,13 @@ static bool p8_legal(const du_gemm_args& a) {
   return true;
 }
 
-// 0: not served by gemm_p8.hip, 1: 256 x 256 tiles, 2: 256 x 128 tiles
+// 0: not served by gemm_p8.hip, 1: 256 x 256 tiles, 2: 256 x 128 tiles (8 waves, one workgroup per CU), 3: 256 x 128 tiles on 4 waves, two workgroups per CU
 int du_gemm_p8_choice(const du_gemm_args& a) {
   if (g_p8_mode != 0 && g_p8_tn && p8_gather_legal(a))      // ConvT data gradient: 256 x 256 tiles once they fill most of the CUs
     return (g_p8_mode > 0 || (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 192) ? 1 : 0;
   if (g_p8_mode == 0 || !p8_legal(a)) return 0;
   if (a.store_mode == DU_STORE_QKV_ROPE) return 2;
+  if (g_p8_mode == 3) return a.act == DU_ACT_SWIGLU ? 2 : 3;
   if (g_p8_mode > 0) return g_p8_mode == 2 ? 2 : 1;
   // rounds of workgroups on the 256 CUs (one 8-wave workgroup per CU) x cost per workgroup (a 256 x 128 tile costs ~0.56 of a
   // 256 x 256 one: half the MFMAs at a lower operand reuse); measured crossovers: tools/gemm_p8_bench.py
@@ -1335,6 +1593,7 @@ int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st, int tail_rows) {
   if (a.a_mode == DU_IM2COL_ROW) return g_p8_sched ? launch_p8<bf16_t, 1, false, true>(a, st) : launch_p8<bf16_t, 0, false, true>(a, st);
   const bool bf = a.out_dtype == DU_BF16;
   const int tr = tail_rows;
+  if (c == 3) return bf ? launch_p4<bf16_t>(a, st, tr) : launch_p4<float>(a, st, tr);
   if (c == 1) {
     if (bf) return g_p8_sched ? launch_p8<bf16_t, 1, false>(a, st, tr) : launch_p8<bf16_t, 0, false>(a, st, tr);
     return g_p8_sched ? launch_p8<float, 1, false>(a, st, tr) : launch_p8<float, 0, false>(a, st, tr);
