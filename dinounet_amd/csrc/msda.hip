@@ -958,7 +958,129 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
   return du_check_launch();
 }
 
+// ---- fp64 (the reference extension dispatches AT_DISPATCH_FLOATING_TYPES: fp32 AND fp64, ms_deform_attn_cuda.cu:69,139; its own
+// acceptance script ops/test.py feeds .double() tensors through MSDeformAttnFunction and torch.autograd.gradcheck).  Not a hot path: one
+// workgroup per (batch, query, head), threads over the channels; everything (value, locations, weights, gradients) in double.
+// Sampling rule of ms_deform_im2col_cuda.cuh:242-304 (forward) and :92-164 (backward): pixel = loc * size - 0.5, a sample counts when
+// -1 < pixel < size, corners outside the level contribute zero.
+struct Corner64 { int h0, w0; double lh, lw; bool ok; };
+__device__ __forceinline__ Corner64 corner64(double ly, double lx, int H, int W) {
+  Corner64 c;
+  const double h = ly * H - 0.5, w = lx * W - 0.5;
+  c.ok = h > -1.0 && w > -1.0 && h < (double)H && w < (double)W;
+  const double fh = floor(h), fw = floor(w);
+  c.h0 = (int)fh; c.w0 = (int)fw; c.lh = h - fh; c.lw = w - fw;
+  return c;
+}
+__global__ __launch_bounds__(256) void msda_fwd_f64_kernel(const double* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                           const int64_t* __restrict__ lsi, const double* __restrict__ loc,
+                                                           const double* __restrict__ attn, double* __restrict__ out, int N, int S, int M,
+                                                           int D, int L, int Lq, int P) {
+  const long nqm = blockIdx.x;                  // (n, q, m)
+  const int m = (int)(nqm % M);
+  const long nq = nqm / M;
+  const int n = (int)(nq / Lq);
+  const double* lp = loc + nqm * L * P * 2;
+  const double* ap = attn + nqm * L * P;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    double acc = 0.0;
+    for (int l = 0; l < L; l++) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const double* vb = value + ((long)n * S + lsi[l]) * M * D + (long)m * D + d;
+      for (int p = 0; p < P; p++) {
+        const Corner64 c = corner64(lp[(l * P + p) * 2 + 1], lp[(l * P + p) * 2], H, W);
+        if (!c.ok) continue;
+        const double hh = 1.0 - c.lh, hw = 1.0 - c.lw;
+        double v = 0.0;
+        if (c.h0 >= 0 && c.w0 >= 0) v += hh * hw * vb[((long)c.h0 * W + c.w0) * M * D];
+        if (c.h0 >= 0 && c.w0 + 1 <= W - 1) v += hh * c.lw * vb[((long)c.h0 * W + c.w0 + 1) * M * D];
+        if (c.h0 + 1 <= H - 1 && c.w0 >= 0) v += c.lh * hw * vb[((long)(c.h0 + 1) * W + c.w0) * M * D];
+        if (c.h0 + 1 <= H - 1 && c.w0 + 1 <= W - 1) v += c.lh * c.lw * vb[((long)(c.h0 + 1) * W + c.w0 + 1) * M * D];
+        acc += ap[l * P + p] * v;
+      }
+    }
+    out[nq * M * D + (long)m * D + d] = acc;
+  }
+}
+// grad_value by fp64 atomics (zeroed by the launcher); grad_loc / grad_attn: per-thread partial sums over its channels, block reduction
+__global__ __launch_bounds__(256) void msda_bwd_f64_kernel(const double* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                           const int64_t* __restrict__ lsi, const double* __restrict__ loc,
+                                                           const double* __restrict__ attn, const double* __restrict__ gout,
+                                                           double* __restrict__ gv, double* __restrict__ gl, double* __restrict__ ga,
+                                                           int N, int S, int M, int D, int L, int Lq, int P) {
+  __shared__ double red[3][256];
+  const long nqm = blockIdx.x;
+  const int m = (int)(nqm % M);
+  const long nq = nqm / M;
+  const int n = (int)(nq / Lq);
+  const double* lp = loc + nqm * L * P * 2;
+  const double* ap = attn + nqm * L * P;
+  for (int l = 0; l < L; l++) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const long base = ((long)n * S + lsi[l]) * M * D + (long)m * D;
+    for (int p = 0; p < P; p++) {
+      const Corner64 c = corner64(lp[(l * P + p) * 2 + 1], lp[(l * P + p) * 2], H, W);
+      const double a = ap[l * P + p];
+      double s_a = 0.0, s_h = 0.0, s_w = 0.0;
+      if (c.ok) {
+        const double hh = 1.0 - c.lh, hw = 1.0 - c.lw;
+        const bool k1 = c.h0 >= 0 && c.w0 >= 0, k2 = c.h0 >= 0 && c.w0 + 1 <= W - 1, k3 = c.h0 + 1 <= H - 1 && c.w0 >= 0,
+                   k4 = c.h0 + 1 <= H - 1 && c.w0 + 1 <= W - 1;
+        const long o1 = base + ((long)c.h0 * W + c.w0) * M * D, o2 = o1 + (long)M * D, o3 = o1 + (long)W * M * D, o4 = o3 + (long)M * D;
+        for (int d = threadIdx.x; d < D; d += 256) {
+          const double g = gout[nq * M * D + (long)m * D + d];
+          const double v1 = k1 ? value[o1 + d] : 0.0, v2 = k2 ? value[o2 + d] : 0.0, v3 = k3 ? value[o3 + d] : 0.0, v4 = k4 ? value[o4 + d] : 0.0;
+          if (k1) atomicAdd(gv + o1 + d, hh * hw * a * g);
+          if (k2) atomicAdd(gv + o2 + d, hh * c.lw * a * g);
+          if (k3) atomicAdd(gv + o3 + d, c.lh * hw * a * g);
+          if (k4) atomicAdd(gv + o4 + d, c.lh * c.lw * a * g);
+          s_a += g * (hh * hw * v1 + hh * c.lw * v2 + c.lh * hw * v3 + c.lh * c.lw * v4);
+          s_h += g * a * (-hw * v1 - c.lw * v2 + hw * v3 + c.lw * v4);
+          s_w += g * a * (-hh * v1 + hh * v2 - c.lh * v3 + c.lh * v4);
+        }
+      }
+      red[0][threadIdx.x] = s_a; red[1][threadIdx.x] = s_h; red[2][threadIdx.x] = s_w;
+      __syncthreads();
+      for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+          red[0][threadIdx.x] += red[0][threadIdx.x + st]; red[1][threadIdx.x] += red[1][threadIdx.x + st]; red[2][threadIdx.x] += red[2][threadIdx.x + st];
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        ga[nqm * L * P + l * P + p] = red[0][0];
+        gl[(nqm * L * P + l * P + p) * 2] = red[2][0] * W;          // d / d loc_x
+        gl[(nqm * L * P + l * P + p) * 2 + 1] = red[1][0] * H;      // d / d loc_y
+      }
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int du_msda_forward_f64(const double* value, const int64_t* shapes, const int64_t* lsi, const double* loc, const double* attn,
+                                   double* out, int N, int S, int M, int D, int L, int Lq, int P, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!value || !shapes || !lsi || !loc || !attn || !out || N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0)
+    return DU_ERR_BAD_ARG;
+  if ((long)N * Lq * M > 0x7fffffffL) return DU_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(msda_fwd_f64_kernel, dim3((unsigned)((long)N * Lq * M)), dim3(256), 0, st, value, shapes, lsi, loc, attn, out, N, S, M, D, L, Lq, P);
+  return du_check_launch();
+}
+extern "C" int du_msda_backward_f64(const double* value, const int64_t* shapes, const int64_t* lsi, const double* loc, const double* attn,
+                                    const double* gout, double* gv, double* gl, double* ga, int N, int S, int M, int D, int L, int Lq, int P,
+                                    void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!value || !shapes || !lsi || !loc || !attn || !gout || !gv || !gl || !ga || N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 ||
+      P <= 0)
+    return DU_ERR_BAD_ARG;
+  if ((long)N * Lq * M > 0x7fffffffL) return DU_ERR_UNSUPPORTED;
+  if (hipMemsetAsync(gv, 0, (size_t)N * S * M * D * sizeof(double), st) != hipSuccess) return DU_ERR_LAUNCH;
+  hipLaunchKernelGGL(msda_bwd_f64_kernel, dim3((unsigned)((long)N * Lq * M)), dim3(256), 0, st, value, shapes, lsi, loc, attn, gout, gv, gl, ga, N, S, M, D,
+                     L, Lq, P);
+  return du_check_launch();
+}
 
 extern "C" int du_msda_forward(int dtype, const void* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
                                const float* attn, void* out, int N, int S, int M, int D, int L, int Lq, int P, void* stream) {

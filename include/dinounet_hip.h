@@ -278,6 +278,15 @@ int du_msda_backward(int dtype, const void* value, const int64_t* spatial_shapes
                      float* grad_sampling_loc, float* grad_attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
                      float* ws, int64_t ws_elems, void* stream);
 
+/* fp64 forms: the reference extension dispatches AT_DISPATCH_FLOATING_TYPES (fp32 and fp64, ops/src/cuda/ms_deform_attn_cuda.cu:69,139) and
+   its acceptance script feeds .double() tensors through MSDeformAttnFunction and torch.autograd.gradcheck (ops/test.py:40-58,101-121).
+   Every tensor double (value, sampling_loc, attn_weight, out / the three gradients); same semantics; grad_value is cleared by the library. */
+int du_msda_forward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index, const double* sampling_loc,
+                        const double* attn_weight, double* out, int N, int S, int M, int D, int L, int Lq, int P, void* stream);
+int du_msda_backward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index, const double* sampling_loc,
+                         const double* attn_weight, const double* grad_out, double* grad_value, double* grad_sampling_loc,
+                         double* grad_attn_weight, int N, int S, int M, int D, int L, int Lq, int P, void* stream);
+
 /* The same with grad_value written in bf16 (value's dtype: what the value projection's backward reads) -- no cast pass afterwards.
    bf16, one level, 4 points, D <= 32 only (the MFMA grad_value path); DU_ERR_UNSUPPORTED otherwise: use du_msda_backward and cast. */
 int du_msda_backward_bf16gv(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index, const float* sampling_loc,

@@ -41,9 +41,33 @@ def excerpt():
     return HEADER + "".join(lines[FIRST - 1:LAST])
 
 
+# Round 4: the reference's OWN acceptance script of the extension, ops/test.py, and the autograd Function it imports
+# (ops/functions/ms_deform_attn_func.py: forward AND backward through the compiled module), both whole and unmodified, so that
+# tests/test_gpu_boundary.py can execute the script's three checks as written (fp64 forward equality, fp32 forward allclose,
+# torch.autograd.gradcheck in double for D in {30, 32, 64, 71, 1025, 2048, 3096}) on top of the drop-in module.
+OPS = "/root/reference/dinounet/dinov3/eval/segmentation/models/utils/ops"
+WHOLE = [(os.path.join(OPS, "test.py"), os.path.join(HERE, "ops_test_ref.py")),
+         (os.path.join(OPS, "functions", "ms_deform_attn_func.py"), os.path.join(HERE, "functions", "ms_deform_attn_func.py")),
+         (os.path.join(OPS, "functions", "__init__.py"), os.path.join(HERE, "functions", "__init__.py"))]
+WHOLE_HEADER = ("# TEST FIXTURE -- verbatim copy of the reference's %s (tests/ref_vendor/update.py); Copyright (c) Meta Platforms, Inc. and\n"
+                "# affiliates / SenseTime (Deformable DETR, Apache-2.0), notices below.  Not product code: executed only by tests/test_gpu_boundary.py.\n")
+
+
+def whole(src):
+    rel = src[len("/root/reference/"):]
+    return WHOLE_HEADER % rel + open(src).read()
+
+
 if __name__ == "__main__":
     text = excerpt()
     if "--check" in sys.argv:
-        sys.exit(0 if open(OUT).read() == text else 1)
+        ok = open(OUT).read() == text
+        for src, dst in WHOLE:
+            ok = ok and os.path.exists(dst) and open(dst).read() == whole(src)
+        sys.exit(0 if ok else 1)
     open(OUT, "w").write(text)
     print(OUT)
+    for src, dst in WHOLE:
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        open(dst, "w").write(whole(src))
+        print(dst)

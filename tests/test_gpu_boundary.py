@@ -208,3 +208,24 @@ def test_torch_compile_wrapper_keeps_logits():
         y_eval = torch.compile(net)(x)
     assert torch.isfinite(y_eval).all()
     torch._dynamo.reset()
+
+
+def test_reference_ops_test_script_as_written_on_dropin_module():
+    """The reference extension's OWN acceptance script (ops/test.py, vendored whole and unmodified as tests/ref_vendor/ops_test_ref.py
+    together with the autograd Function it imports, ops/functions/ms_deform_attn_func.py: forward AND backward through the compiled
+    module) executed as a script on top of the drop-in `MultiScaleDeformableAttention`: check_forward_equal_with_pytorch_double
+    (torch.allclose at default tolerances, .double() tensors: ops/test.py:40-58), check_forward_equal_with_pytorch_float (:61-83) and
+    torch.autograd.gradcheck in double for D in {30, 32, 64, 71, 1025, 2048, 3096} (:86-121).  Needs the fp64 dispatch of the reference
+    (AT_DISPATCH_FLOATING_TYPES, ms_deform_attn_cuda.cu:69,139) = du_msda_forward_f64 / du_msda_backward_f64."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_vendor")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "ops_test_ref.py"], cwd=here, env=env, capture_output=True, text=True, timeout=1500)
+    print(r.stdout[-3000:], r.stderr[-3000:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("* ")]
+    assert len(lines) == 2 + 7, lines
+    assert all(ln.startswith("* True") for ln in lines), lines
