@@ -1665,6 +1665,7 @@ static bool tn_group_legal(const du_tn_job& j) {
     return (long)j.K * 4 * j.ldb * 2 <= 0x7fffff00L;
   }
   if (j.N != 9 * j.Cb || !pow2(j.Hs) || j.b_colsum) return false;
+  if (j.Ws % 64) return false;          // the 3 x 3 gather assumes a K-tile (64 consecutive pixels) inside ONE image row
   return (long)j.K * j.ldb * 2 <= 0x7fffff00L;
 }
 extern "C" int du_gemm_tn_group_legal(const du_tn_job* job) { return (job && g_p8_mode != 0 && tn_group_legal(*job)) ? 1 : 0; }

@@ -518,7 +518,9 @@ class WgradQueue:
         self.keep = []          # dY / X tensors of the queued jobs
         self.flops = 0.0
         self.nbytes = 0.0
-        self._armed = False     # an end-of-pass callback is queued with the autograd engine
+        self._armed_task = None # id of the autograd graph task (backward pass) whose end-of-pass callback is queued
+        self.keep_bytes = 0     # bytes of dY / X pinned by the queued jobs
+        self.keep_limit = int(os.environ.get("DINOUNET_WGRAD_KEEP_MB", "16384")) << 20
         self.state = {}         # id(parameter) -> group key (contributions pending in that group's buffers) | "done" (handed over complete)
         self.groups = {}        # group key (ids of a node's parameters) -> {"bufs", "jobs", "first", "ret", "key"}
         self.flush_aware_hooks = 0   # > 0: the post-accumulate hooks on the parameters belong to GradAllReducer
@@ -527,8 +529,15 @@ class WgradQueue:
 
     @staticmethod
     def _param(w):
+        """the leaf Parameter behind `w`: w itself, or a view of it whose backward hands the gradient back as a VIEW of the same memory
+        (same element count, contiguous: conv1x1's w.view(Cout, -1)).  A slice / expand view would have autograd copy or sum the still
+        unfinished buffer (SliceBackward, ExpandBackward): those weights are not deferred."""
         b = w._base if w._base is not None else w
-        return b if (isinstance(b, torch.nn.Parameter) and b.is_leaf) else None
+        if not (isinstance(b, torch.nn.Parameter) and b.is_leaf):
+            return None
+        if w is not b and not (w.numel() == b.numel() and w.is_contiguous() and b.is_contiguous()):
+            return None
+        return b
 
     def note_use(self, *ws):
         """forward side -> weak references to the leaf Parameters behind the weights for begin(), or None when they are not
@@ -543,13 +552,28 @@ class WgradQueue:
         return [weakref.ref(p) for p in ps]
 
     def _arm(self):
-        if not self._armed:
+        """make sure THIS backward pass ends with _end_of_pass().  Keyed on the engine's graph-task id, not on a flag: a pass that raised
+        (out of memory, KeyboardInterrupt, a failed hipGraph capture) never runs its final callbacks -- a flag would stay set and every later
+        backward() would return with unfinished gradients.  Whatever such a dead pass left queued is dropped here (its tensors belong to a
+        pass nobody will finish; launching them later could write into freed capture-pool memory)."""
+        tid = torch._C._current_graph_task_id()
+        if tid == -1:                      # not inside a backward pass: nothing will call back
+            return False
+        if self._armed_task != tid:
+            if self._armed_task is not None:
+                self._drop()
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
-                self._armed = True
-            except RuntimeError:           # not inside a backward pass: nothing will call back
+            except RuntimeError:
                 return False
+            self._armed_task = tid
         return True
+
+    def _drop(self):
+        self.jobs, self.keep, self.flops, self.nbytes, self.keep_bytes = [], [], 0.0, 0.0, 0
+        self.groups.clear()
+        self.state.clear()
+        self._armed_task = None
 
     def _hand_over(self, ids):
         """the parameters `ids` are about to receive a COMPLETE contribution: whatever is queued for them must be complete first"""
@@ -583,7 +607,7 @@ class WgradQueue:
             return None
         grp = self.groups.get(ids)
         if grp is None:
-            grp = {"key": ids, "bufs": {}, "jobs": [], "first": True, "ret": True}
+            grp = {"key": ids, "bufs": {}, "jobs": [], "first": True, "ret": True, "refs": list(refs)}
             self.groups[ids] = grp
             for i in ids:
                 self.state[i] = ids
@@ -620,22 +644,29 @@ class WgradQueue:
             grp["jobs"].append(job)
         self.jobs.append(job)
         self.keep.extend(keep)
+        self.keep_bytes += sum(t.numel() * t.element_size() for t in keep)
         self.queued += 1
         self.flops += 2.0 * job.M * job.N * job.K
         self.nbytes += 2.0 * job.K * (job.M + job.N) + 4.0 * job.M * job.N
-        if not self._armed and not self._arm():
+        if not self._arm():
+            self.flush()
+        elif self.keep_bytes > self.keep_limit:       # bound what the queue pins (dY and X of every deferred layer) by launching early
             self.flush()
 
     def _end_of_pass(self):
-        self._armed = False
+        self._armed_task = None
         self.flush()
         self.state.clear()
+        self.groups.clear()
 
     def flush(self):
-        for ids in list(self.groups):
+        done = []
+        for ids, grp in list(self.groups.items()):
+            if not grp["jobs"]:            # begun (FAPM begins three groups up front) but nothing queued yet: stays open
+                continue
             for i in ids:
                 self.state[i] = "done"
-        self.groups.clear()
+            done.append(self.groups.pop(ids))
         if not self.jobs:
             return
         n = len(self.jobs)
@@ -643,9 +674,21 @@ class WgradQueue:
         e0 = PROFILE.start() if PROFILE is not None else None
         rc = _lib.lib().du_gemm_tn_group(arr, n, _st())
         fl, nb = self.flops, self.nbytes
-        self.jobs, self.keep, self.flops, self.nbytes = [], [], 0.0, 0.0
+        self.jobs, self.keep, self.flops, self.nbytes, self.keep_bytes = [], [], 0.0, 0.0, 0
         _lib.check(rc, "du_gemm_tn_group")
         self.launches += 1
+        # Did autograd adopt the buffers by reference?  Where it did not (AccumulateGrad clones when the layout contract fails or grad
+        # mode is on; the engine's input buffer adds out of place when the parameter has another, non-queued use in the pass) the
+        # parameter holds a copy made while the buffer was still ZERO: the product is added to it here, behind the launch.
+        for grp in done:
+            for name, r in zip(("dw", "db"), grp.get("refs", ())):
+                buf, p = grp["bufs"].get(name), r()
+                if buf is None or p is None or p.grad is None:
+                    continue
+                if p.grad.untyped_storage().data_ptr() != buf.untyped_storage().data_ptr():
+                    if p.grad.numel() != buf.numel():
+                        raise RuntimeError("WgradQueue: a deferred gradient was not adopted by reference and has another shape")
+                    p.grad.add_(buf.view(p.grad.shape).to(p.grad.dtype))
         if PROFILE is not None:
             PROFILE.stop("gemm_tn_group_kernel<bf16,wgrad>" + (f" jobs{n}" if PROFILE.detail else ""), e0, fl, nb)
 

@@ -117,7 +117,9 @@ typedef struct {
   float* a_colsum;    /* optional, weight-gradient products only (a_mode PLAIN_COL, bf16): a_colsum[m] += sum_k A(m, k), fp32 atomics
                          into a buffer the caller zero-initialised -- the bias gradient sum_rows dY for free while dY^T X streams dY
                          anyway (nn.Linear backward).  du_gemm returns DU_ERR_UNSUPPORTED if the kernel family serving the product
-                         cannot do it (du_gemm_route != 1 and != 5): call du_colsum then */
+                         cannot do it (du_gemm_route != 1 and != 5): call du_colsum then.  The side sum carries the product's `alpha`
+                         (a_colsum[m] += alpha * sum_k A(m, k): the per-sample DropPath scale of the grouped jobs needs it); pass alpha = 1
+                         for a plain bias gradient */
   float* b_colsum;    /* optional, ConvTranspose2d k2 s2 weight-gradient products only (a_mode PLAIN_COL, b_mode IM2COL_COL, bf16):
                          b_colsum[n % geom.C] += sum_k B(n, k) -- every dY pixel appears exactly once among the (input pixel, tap) pairs, so
                          this is the bias gradient sum_pixels dY[.., co]; same contract as a_colsum (zero-initialised, atomics,
@@ -144,7 +146,8 @@ int du_gemm_route(const du_gemm_args* args);
    du_gemm_tn_group_legal: 1 if a job can be queued (K % 128 == 0, K >= 512, lda / ldb % 8 == 0, 16-byte aligned operands, < 2 GB
    operands); du_gemm_tn_group returns DU_ERR_UNSUPPORTED if any job is not.
    Convolution weight gradients (gather != 0) read B in place from an NHWC tensor, K = B * Hs * Ws contraction pixels (Ws -- and for
-   gather 3 also Hs -- a power of two), Cb channels per tap (Cb % 8 == 0), N = taps * Cb:
+   gather 3 also Hs -- a power of two; gather 3: Ws % 64 == 0, a 64-pixel K-tile lies inside one image row), Cb channels per tap
+   (Cb % 8 == 0), N = taps * Cb:
      gather 2: nn.ConvTranspose2d(k 2, s 2) (dinounet_training.py:255-264,558; dinov3_adapter.py:360): A = x (K, M = Cin), B(k, (tap, co)) =
                dy[pixel (2y + tap / 2, 2x + tap % 2)][co] with dy (B, 2 Hs, 2 Ws, Cb), pixel stride ldb; b_colsum (nullable, Cb floats,
                zeroed) += the bias gradient sum_pixels dy;

@@ -69,7 +69,7 @@ def test_gradient_is_the_deferred_buffer_and_complete_when_backward_returns(queu
     x = torch.ones(5, requires_grad=True)
     y = _Lin.apply(_Lin.apply(x, w1), w2)
     y.sum().backward()
-    assert len(fake.launched) == 2 and not q.jobs and not q.keep and not q.state and not q.groups and not q._armed
+    assert len(fake.launched) == 2 and not q.jobs and not q.keep and not q.state and not q.groups and q._armed_task is None
     # the values the launch wrote AFTER the nodes had returned their buffers: AccumulateGrad adopted the buffers, it did not clone them
     assert torch.equal(w1.grad, torch.full((2, 3), 2.5)) and torch.equal(w2.grad, torch.full((4, 3), 4.5))
     assert q.queued == 2 and q.launches == 1
@@ -125,3 +125,55 @@ def test_a_complete_contribution_flushes_what_is_pending_for_that_parameter(queu
     # backward order: the LAST applied function runs first -> _Lin (deferred) then _Abort
     _Lin.apply(_Abort.apply(x, w), w).sum().backward()
     assert torch.equal(w.grad, torch.full((2, 3), 12.5))
+
+
+def test_a_backward_pass_that_raised_does_not_disarm_the_queue(queue):
+    """the engine does not run final callbacks when a pass raises; a boolean 'armed' flag would stay set and every later
+    backward() would return with unfinished gradients.  Arming is keyed on the graph task: the next pass drops what the dead one left
+    queued and arms itself."""
+    q, fake = queue
+
+    class _Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    w = torch.nn.Parameter(torch.ones(2, 3))
+    x = torch.ones(5, requires_grad=True)
+    y = _Boom.apply(_Lin.apply(x, w))          # _Lin's backward runs AFTER _Boom's: nothing queued yet when it raises
+    with pytest.raises(RuntimeError):
+        y.sum().backward()
+    y = _Lin.apply(_Boom.apply(x), w)          # _Lin queues its job, THEN the pass dies
+    with pytest.raises(RuntimeError):
+        y.sum().backward()
+    assert q.jobs and q._armed_task is not None and not fake.launched      # the dead pass left its job behind
+    w.grad = None
+    w2 = torch.nn.Parameter(torch.ones(4, 3))
+    _Lin.apply(x, w2).sum().backward()         # a healthy pass: the leftovers are dropped, its own gradient is complete on return
+    assert fake.launched == [(4, 3, 0)] and not q.jobs and not q.keep and q._armed_task is None
+    assert torch.equal(w2.grad, torch.full((4, 3), 4.5)) and w.grad is None
+
+
+def test_slice_views_of_a_parameter_are_not_deferred(queue):
+    """through a slice view SliceBackward would copy the still-zero buffer: only the Parameter itself or a same-size contiguous
+    view of it may be deferred."""
+    q, _ = queue
+    w = torch.nn.Parameter(torch.ones(4, 3))
+    assert q.note_use(w) is not None and q.note_use(w.view(2, 6)) is not None
+    assert q.note_use(w[:2]) is None and q.note_use(w.t()) is None and q.note_use(w.expand(2, 4, 3)) is None
+
+
+def test_a_buffer_autograd_did_not_adopt_is_added_after_the_launch(queue):
+    """weight tying -- the parameter also has a non-queued use in the pass, so the engine adds the two contributions OUT OF
+    PLACE as soon as both exist, i.e. while the deferred buffer is still zero.  flush() sees that p.grad is not the buffer and adds the
+    product behind the launch."""
+    q, fake = queue
+    w = torch.nn.Parameter(torch.ones(2, 3))
+    x = torch.ones(5, requires_grad=True)
+    y = _Lin.apply(x, w).sum() + (w * 2.0).sum()          # deferred contribution 2.5 everywhere + plain contribution 2.0
+    y.backward()
+    assert torch.equal(w.grad, torch.full((2, 3), 4.5)), w.grad

@@ -219,12 +219,13 @@ def test_gemm_tn_group_many_products_one_launch():
     W = ops.WGRAD
     assert W.enabled
     l0, q0 = W.launches, W.queued
-    W._armed = True                                    # hold the queue (outside a backward pass a job would be launched at once)
+    hold = W._arm
+    W._arm = lambda: True                              # hold the queue (outside a backward pass a job would be launched at once)
     try:
         outs = [ops.mm_wgrad(a, b, with_colsum=cs, defer=True) for a, b, cs in ins]
         assert W.queued - q0 == len(shapes) and len(W.jobs) == len(shapes)
     finally:
-        W._armed = False
+        W._arm = hold
     W.flush()
     assert W.launches - l0 == 1 and not W.jobs and not W.keep
     for (rows, N, K, cs), o, (rw, rb) in zip(shapes, outs, refs):
@@ -275,7 +276,7 @@ def test_deferred_weight_gradients_match_immediate_ones_through_autograd():
         if pre is not None:
             pre()
         dc_and_ce_loss(net(x), t).backward()
-        assert not W.jobs and not W.keep and not W._armed and not W.state and not W.groups
+        assert not W.jobs and not W.keep and W._armed_task is None and not W.state and not W.groups
         torch.cuda.synchronize()
         return {k: p.grad.detach().float().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}, W.queued - q0, W.launches - l0
 
