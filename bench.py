@@ -117,31 +117,48 @@ def main():
     graph_used = ts.graph is not None          # False when capture was off or fell back to eager steps
     # roofline leg: the same step run eagerly with a HIP-event pair around every launch of the GEMM / attention kernels
     prof = None
-    if not a.no_roofline:
-        # every rank runs these eager steps (they contain the gradient / SyncBN / Dice collectives); only rank 0 times its launches
+    if not a.no_roofline or reducer is not None:
+        # every rank runs these eager steps (they contain the gradient / SyncBN / Dice collectives); only rank 0 times its launches.
+        # With a reducer they run even under --no-roofline: the `comm` record (exposed all-reduce time, bucket timeline) comes from them
         ts.use_graph = False
         ts()
         torch.cuda.synchronize()
-        if rank == 0:
+        if rank == 0 and not a.no_roofline:
             ops.PROFILE = ops.KernelProfile()
         if reducer is not None:
             ts.comm_events = []
+            reducer.timeline = []
+            step_ev = []
         for _ in range(2):
+            if reducer is not None:
+                e = torch.cuda.Event(enable_timing=True); e.record(); step_ev.append(e)
             ts()
         torch.cuda.synchronize()
     prof = ops.PROFILE
     ops.PROFILE = None
     comm = None
     if reducer is not None:
-        # what the N > 1 runs exchange per step and how much of it is exposed: bucket sizes, collective count, and the time the (eager)
-        # step spends in reducer.finish() after backward = all-reduce time NOT hidden behind the backward pass + the bucket divides
+        # what the N > 1 runs exchange per step and how much of it is exposed: bucket sizes, collective count, the time the (eager)
+        # step spends in reducer.finish() after backward = all-reduce time NOT hidden behind the backward pass + the bucket divides, and
+        # per bucket (last eager step) when its gradients were gathered, when its all-reduce started and ended, in ms from the step's start
         nb = [int(f.numel()) for f in reducer.flat]
         exposed = [e0.elapsed_time(e1) for e0, e1 in (ts.comm_events or [])]
+        tl = []
+        nbk = len(nb)
+        for bi, ev in (reducer.timeline or [])[-nbk:]:
+            tl.append({"bucket": bi, "elems": nb[bi], "ready_ms": round(step_ev[-1].elapsed_time(ev[0]), 3),
+                       "allreduce_start_ms": round(step_ev[-1].elapsed_time(ev[1]), 3), "allreduce_done_ms": round(step_ev[-1].elapsed_time(ev[2]), 3)})
+        step_end = None
+        if ts.comm_events:
+            step_end = round(step_ev[-1].elapsed_time(ts.comm_events[-1][1]), 3)
         comm = {"gradient_buckets_elems": nb, "gradient_bytes_per_step": 4 * sum(nb), "gradient_allreduces_per_step": len(nb),
                 "small_collectives_per_step": {"syncbn_fwd": 7, "syncbn_bwd": 7, "dice_sums": 1} if world > 1 else {},
                 "exposed_after_backward_ms": round(sum(exposed) / max(len(exposed), 1), 3) if exposed else None,
-                "note": "eager steps; reducer.finish() = wait for the side-stream all-reduces + divide by world size"}
+                "bucket_timeline": tl, "gradients_installed_ms": step_end,
+                "note": "eager steps; reducer.finish() = wait for the side-stream all-reduces + divide by world size; timeline in ms from the "
+                        "start of the last eager step (compute-stream events for `ready`, side-stream events for the all-reduce)"}
         ts.comm_events = None
+        reducer.timeline = None
     if world > 1:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

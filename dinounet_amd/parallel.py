@@ -79,6 +79,7 @@ class GradAllReducer:
         if cur:
             self.buckets.append(cur)
         self.flat, self.views, self.pending, self.works, self.gather = [], [], [], [], []
+        self.timeline = None         # list -> eager steps record, per bucket, (ready on the compute stream, all-reduce start, all-reduce done)
         self._hooks = []
         self._keep = []
         dev = named[0][1].device
@@ -157,9 +158,18 @@ class GradAllReducer:
     def _launch(self, bi):
         flat = self.flat[bi]
         if self.is_cuda:
+            rec = self.timeline is not None and not torch.cuda.is_current_stream_capturing()
+            if rec:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()                         # the bucket is gathered (compute stream)
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
+                if rec:
+                    ev[1].record()
                 self.works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if rec:
+                    ev[2].record()
+                    self.timeline.append((bi, ev))
         else:
             self.works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 

@@ -121,6 +121,14 @@ class TrainStep:
                 self._n += 1
                 return self.loss
             torch.cuda.synchronize()
+            if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+                # Quiesce RCCL's watchdog before the capture.  The eager warm-up steps left Work objects in its list; it retires them by
+                # polling their events every ~100 ms from its own thread.  A poll that lands while this thread is beginning the capture is
+                # the one window in which round 3 saw a watchdog-thread SIGABRT (1 of 18 single-rank runs, never reproduced): after the
+                # synchronize above every one of those events is complete, so waiting out a few poll periods empties the list and the
+                # watchdog has nothing to query during the capture (collectives issued INSIDE a capture are not handed to it).
+                import time
+                time.sleep(0.35)
             try:
                 graph = torch.cuda.CUDAGraph()
                 # With a process group alive, ProcessGroupNCCL's watchdog thread polls its work events (hipEventQuery) while this
