@@ -388,6 +388,8 @@ def main():
         train_case_pinned("dinounet_l_256_train_pinned", "dinounet_l", 2, 256, 256, sample=16384)
     if "pinned512" in which:   # the same at a BASELINE.json shape (512 x 512: N = 1029 tokens, Lq = 5376, 512^2 decoder), round 3
         train_case_pinned("dinounet_s_512_train_pinned", "dinounet_s", 2, 512, 512, sample=8192)
+    if "pinned512l" in which:  # the HEADLINE model at its own resolution (dinounet_l, 512 x 512, batch 1), round 4
+        train_case_pinned("dinounet_l_512_train_pinned", "dinounet_l", 1, 512, 512, sample=8192)
 
 
 if __name__ == "__main__":

@@ -64,9 +64,14 @@ def test_eval_logits_fp32_vs_reference(name):
     ref = torch.from_numpy(g["logits"])
     e = rel(y, ref)
     mism, bad = argmax_check(y, ref, 1e-3)
-    print(f"[{name}] fp32 HIP vs reference: rel err {e:.2e}, argmax mismatches {mism} (outside tie band: {bad})")
+    npix = ref.argmax(1).numel()
+    print(f"[{name}] fp32 HIP vs reference: rel err {e:.2e}, argmax mismatches {mism} of {npix} pixels (outside tie band: {bad})")
     assert e < 1e-3
     assert bad == 0
+    # "argmax masks bit-exact" is tested as: identical wherever the reference's own top-2 margin exceeds 1e-3 * max|logit| (a pixel inside
+    # that band flips under ANY fp32 reordering of the reference itself).  The band must stay a measure-zero curiosity: at most 1 pixel in
+    # 10 000 (and never more than 20) may differ inside it
+    assert mism <= min(20, max(1, npix // 10000)), (mism, npix)
 
 
 @pytest.mark.parametrize("name", ["dinounet_s_64_eval", "dinounet_l_64_eval", "dinounet_s_512_eval"])
@@ -242,6 +247,54 @@ def test_train_step_bf16_runs_and_learns():
     assert losses[-1] < losses[0], losses
 
 
+def test_bf16_training_trajectory_follows_fp32_mode_512():
+    """one more link between the bf16 throughput mode and the reference than single-step gradient bands.  50 optimizer
+    steps (the trainer's SGD: Nesterov 0.99, weight decay 3e-5, clip 12, nnUNetTrainer.py:486,922-924) of the bf16 kernels and of the fp32
+    parity kernels from IDENTICAL state on the same four 512 x 512 slices (dinounet_s; every DropPath mask and RoPE draw pinned to the same
+    values in both runs): the loss curves must stay together (the fp32 mode is what the reference goldens pin), the final logits must give
+    the same segmentation, and the Dice of the final masks against the training target must agree."""
+    B, steps = 4, 50
+    x = weights.make_input(B, 3, 512, 512, seed=6).cuda()
+    tgt = weights.make_target(B, 512, 512, 2, seed=6).cuda()
+    curves, finals = {}, {}
+    for prec in ("fp32", "bf16"):
+        net = _build("dinounet_s", 2, prec).train()
+        _pin_randomness(net, B)
+        params = [p for p in net.parameters() if p.requires_grad]
+        opt = torch.optim.SGD(params, 1e-2, momentum=0.99, nesterov=True, weight_decay=3e-5)
+        ls = []
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            loss = O.dc_and_ce_loss(net(x), tgt)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 12)
+            opt.step()
+            ls.append(float(loss))
+        net.eval()
+        with torch.no_grad():
+            finals[prec] = net(x).float().cpu()
+        curves[prec] = ls
+        del net, opt
+    c32, c16 = np.array(curves["fp32"]), np.array(curves["bf16"])
+    assert np.isfinite(c16).all() and np.isfinite(c32).all()
+    drop = c32[0] - c32[-1]
+    gap = np.abs(c16 - c32)
+    m32, m16 = finals["fp32"].argmax(1), finals["bf16"].argmax(1)
+    t = tgt[:, 0].cpu()
+
+    def dice(m):
+        tp = float(((m == 1) & (t == 1)).sum()); fp = float(((m == 1) & (t != 1)).sum()); fn = float(((m != 1) & (t == 1)).sum())
+        return 2 * tp / max(2 * tp + fp + fn, 1.0)
+    agree = float((m32 == m16).float().mean())
+    print(f"[trajectory, dinounet_s 4 x 512^2, {steps} steps] loss fp32 {c32[0]:.4f} -> {c32[-1]:.4f}, bf16 {c16[0]:.4f} -> {c16[-1]:.4f}; "
+          f"max |gap| {gap.max():.4f} (mean {gap.mean():.4f}) of a {drop:.4f} descent; final masks agree on {agree:.4f} of the pixels; "
+          f"Dice vs target fp32 {dice(m32):.4f} bf16 {dice(m16):.4f}")
+    assert drop > 0.05, "the fixed batch must be learnable for the comparison to mean anything"
+    assert gap.max() < 0.25 * drop and gap.mean() < 0.08 * drop, (gap.max(), gap.mean(), drop)
+    assert c16[-1] < c16[0] - 0.6 * drop
+    assert agree > 0.97 and abs(dice(m32) - dice(m16)) < 0.03
+
+
 @pytest.mark.parametrize("model", ["dinounet_s", "dinounet_b", "dinounet_l"])
 def test_bf16_mode_vs_fp32_mode_512(model):
     """The throughput (bf16) mode against the parity (fp32) mode of the SAME HIP path at the BASELINE.json shape (512 x 512, batch 2:
@@ -276,7 +329,8 @@ def _pin_randomness(net, B):
         m.pinned_mask = mk
 
 
-@pytest.mark.parametrize("name", ["dinounet_s_64_train_pinned", "dinounet_l_256_train_pinned", "dinounet_s_512_train_pinned"])
+@pytest.mark.parametrize("name", ["dinounet_s_64_train_pinned", "dinounet_l_256_train_pinned", "dinounet_s_512_train_pinned",
+                                  "dinounet_l_512_train_pinned"])
 def test_train_step_pinned_randomness_vs_reference(name):
     """train() with the per-block RoPE rescale draws (LAY/rope_position_encoding.py:93-97) and the DropPath masks (ADP:18-26) pinned to
     the values the reference was given (oracle/make_golden.py: pin_reference_randomness): logits, loss, and EVERY trainable
