@@ -313,7 +313,7 @@ int launch(const HaloParams& P, hipStream_t st) {
 }  // namespace
 
 // x (B,H,W,C1) [+ x2 (B,H,W,Cin-C1)] NHWC bf16 with pixel strides ldx/ldx2; w bf16 [Cout][9*Cin] in (tap, ci) column order;
-// y (B,H,W,Cout) bf16, pixel stride ldy.  stats_part (nullable): (B * (H/8) * (W/16), Cout, 2) fp32 per-tile partial sums.
+// y (B,H,W,Cout) bf16, pixel stride ldy.  stats_part (nullable): (du_conv3x3_halo_parts(...), Cout, 2) fp32 partial sums, image-major.
 // Returns DU_ERR_UNSUPPORTED for shapes this kernel does not serve (caller falls back to the implicit-GEMM path).
 extern "C" int du_conv3x3_halo(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int C1, int Cin, int Cout, int B, int H, int W,
                                const void* w, const float* bias, void* y, int64_t ldy, float* stats_part, void* stream) {
@@ -322,6 +322,10 @@ extern "C" int du_conv3x3_halo(const void* x, int64_t ldx, const void* x2, int64
   if (H % TH || W % TW || ldx % 8 || ldy % 8 || (x2 && (ldx2 % 8 || C1 % 8)) || Cin % 8) return DU_ERR_UNSUPPORTED;
   if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)x2)) & 15) return DU_ERR_UNSUPPORTED;
   if (!x2) C1 = Cin;
+  if (!x2) {       // streaming strip kernel (conv_strip.hip) where it serves the shape
+    const int rc = du_conv3x3_strip(x, ldx, Cin, Cout, B, H, W, w, bias, y, ldy, stats_part, stream);
+    if (rc != DU_ERR_UNSUPPORTED) return rc;
+  }
   HaloParams P{};
   P.x = (const bf16_t*)x; P.ldx = ldx; P.x2 = (const bf16_t*)x2; P.ldx2 = ldx2; P.C1 = C1; P.Cin = Cin; P.Cout = Cout;
   P.B = B; P.H = H; P.W = W; P.w = (const bf16_t*)w; P.bias = bias; P.y = (bf16_t*)y; P.ldy = ldy; P.stats_part = stats_part;

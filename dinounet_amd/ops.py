@@ -859,7 +859,8 @@ def conv3x3_halo(x, wp, bias, x2=None, want_stats=False):
     elif C1 != Cin:
         return None
     y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
-    part = torch.empty((B * (H // 8) * (W // 16), Cout, 2), dtype=torch.float32, device=x.device) if want_stats else None
+    nparts = int(_lib.lib().du_conv3x3_halo_parts(C1, Cin, Cout, B, H, W)) if want_stats else 0
+    part = torch.empty((nparts, Cout, 2), dtype=torch.float32, device=x.device) if want_stats else None
     e0 = PROFILE.start() if PROFILE is not None else None
     rc = _lib.lib().du_conv3x3_halo(_p(x), ld, p2, ld2, C1, Cin, Cout, B, H, W, _p(wp), _p(bias), _p(y), Cout, _p(part), _st())
     if rc == -2:                                  # DU_ERR_UNSUPPORTED

@@ -175,11 +175,17 @@ int du_gemm_tn_group(const du_tn_job* jobs, int njobs, void* stream);
 /* ---- LDS-tiled direct 3x3 convolution (stride 1, pad 1), bf16 NHWC: decoder / FAPM / SPM-stem convs (dinounet_training.py:581-592,
         dinov3_adapter.py:243-249) and, with flipped + transposed weights, their data gradients --------------------------------------- */
 /* x (B,H,W,C1) [+ x2 (B,H,W,Cin-C1): fused concat, nullable]; w bf16 [Cout][9*Cin] in (tap, ci) column order; y (B,H,W,Cout).
-   stats_part (nullable): (B*(H/8)*(W/16), Cout, 2) fp32 per-tile (sum, sum of squares) of the stored outputs, tiles of one image
-   contiguous -- feed to du_strip_finalize(G = B).  Returns DU_ERR_UNSUPPORTED for shapes it does not serve (H%8, W%16, Cout not in
+   stats_part (nullable): (du_conv3x3_halo_parts(...), Cout, 2) fp32 partial (sum, sum of squares) of the outputs, the partials of
+   one image contiguous -- feed to du_strip_finalize(G = B).  Returns DU_ERR_UNSUPPORTED for shapes it does not serve (H%8, W%16, Cout not in
    {32,64,128}, channel counts not multiples of 32): the caller then uses du_gemm's implicit-GEMM path. */
 int du_conv3x3_halo(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int C1, int Cin, int Cout, int B, int H, int W,
                     const void* w, const float* bias, void* y, int64_t ldy, float* stats_part, void* stream);
+/* rows of the partial-statistics array du_conv3x3_halo writes for this shape (depends on the kernel that serves it; 0 = not served) */
+int du_conv3x3_halo_parts(int C1, int Cin, int Cout, int B, int H, int W);
+/* The streaming kernel behind du_conv3x3_halo for 32 input channels, Cout in {32, 64}, W % 128 == 0 (one wave per 32-column strip,
+   weights in registers, rows by LDS-DMA; csrc/conv_strip.hip).  DU_ERR_UNSUPPORTED for any other shape. */
+int du_conv3x3_strip(const void* x, int64_t ldx, int Cin, int Cout, int B, int H, int W, const void* w, const float* bias,
+                     void* y, int64_t ldy, float* stats_part, void* stream);
 /* Weight gradient of the same convolution, dw (Cout, 9*Cin) fp32 in (tap, ci) column order (OVERWRITTEN).  part: scratch of
    du_conv3x3_wgrad_halo_blocks(...) * Cout * 9*Cin floats (0 blocks = shape not served -> use du_gemm's IM2COL_COL path).
    with_db != 0: the bias gradient db[co] = sum_pixels dy rides along -- dw then has Cout * 9*Cin + Cout elements (db behind the weight
