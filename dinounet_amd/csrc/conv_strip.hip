@@ -17,7 +17,7 @@
 //     them carry a different base / row pitch).
 //   * with the pixel on the lane axis the accumulator holds 16 output channels of ONE pixel per lane: bf16 pairs, four
 //     v_permlane32_swap, two 16-byte stores per lane and row -- no staging tile.  Channel statistics (sum, sum of squares for the
-//     following InstanceNorm) accumulate per lane over the whole strip and are reduced across lanes once per wave.
+//     following InstanceNorm, of the bf16-rounded outputs) accumulate per lane over the whole strip and are reduced across lanes once per wave.
 //
 // Roofline: HBM.  Algorithmic bytes per pixel = (Cin + Cout) * 2; 18 MFMAs (576 matrix-pipe cycles) per 4 KB at 32 -> 32.
 #include <stdlib.h>
@@ -42,13 +42,16 @@ struct StripParams {
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int N_> struct SIC { static constexpr int value = N_; };
 
 __device__ __forceinline__ void dma16(const u32x4& srd, unsigned voff, unsigned lds_addr) {
-  unsigned keep;
-  const unsigned zero = 0u;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(srd), "s"(zero), "s"(lds_addr) : "memory");
+  // M0 = LDS destination (declared clobbered: the compiler has no use for it between two of these in this kernel, so no save / restore)
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(srd), "s"(lds_addr) : "memory", "m0");
+}
+// a's lanes 32-63 <-> b's lanes 0-31
+__device__ __forceinline__ void swap_halves(unsigned& a, unsigned& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 template <int N_> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_strip_kernel
     return (yy >= 0 && yy < P.H && trel < P.RS + 2 && !(P.dbg & 2)) ? (unsigned)(yy * P.W + x0) * pb : OOB;
   };
   auto dma_row = [&](int trel, int slot) {
-    const unsigned rs = row_scalar(trel);
+    const unsigned rs = __builtin_amdgcn_readfirstlane(row_scalar(trel));     // (the loop's induction variables land in VGPRs otherwise)
     unsigned o0 = (unsigned)dvo[0] + rs, o1 = (unsigned)dvo[1] + rs;
     o0 = kill_left ? OOB : o0;
     dma16(srd, o0, lds_base + slot * S_ROW);
@@ -147,9 +150,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_strip_kernel
   const auto yrs = __builtin_amdgcn_make_buffer_rsrc((void*)P.y, 0, (int)((unsigned)P.B * (unsigned)P.H * (unsigned)P.W * (unsigned)P.ldy * 2u), 0x00020000);
   const unsigned yvo = (unsigned)n * (unsigned)P.ldy * 2u + (unsigned)co0 * 2u + (unsigned)h * 32u;
 
-  float s1[16], s2[16];
+  f32x2 s1[8], s2[8];                       // per-lane (sum, sum of squares) of accumulator registers (2c, 2c + 1)
 #pragma unroll
-  for (int r = 0; r < 16; r++) { s1[r] = 0.f; s2[r] = 0.f; }
+  for (int c = 0; c < 8; c++) { s1[c] = f32x2{0.f, 0.f}; s2[c] = f32x2{0.f, 0.f}; }
 
   f32x16 a0, a1, a2;
 #pragma unroll
@@ -175,15 +178,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_strip_kernel
     if constexpr (J == 1) dma_edge(trel / S_NR + 1);
     dma_row(trel + S_AHEAD, (J + S_AHEAD) % S_NR);
 
-    // fragment reads one (dx, kk) ahead of the three MFMAs that use them; the scheduling barriers keep the compiler from hoisting all six
-    // reads (24 registers) to the top of the step, which spills the statistics accumulators
-    auto fr = [&](auto dc, auto kc) __attribute__((always_inline)) -> bf16x8 {
-      constexpr int dx = decltype(dc)::value, kk = decltype(kc)::value;
+    // Schedule of a step (pinned with scheduling barriers: left alone the compiler hoists all reads, spills the statistics, and puts the
+    // whole epilogue behind the last MFMA where nothing covers it).  Phase A: the six MFMAs that complete the oldest accumulator.
+    // Phase B: the twelve MFMAs of the two younger accumulators, with the epilogue of the completed row (bf16 pairs, statistics,
+    // half-wave swaps, stores) spread over their shadows -- a wave issues ~5 VALU operations under one 32-cycle MFMA for free.  The
+    // fragments are read twice (once per phase): LDS reads are cheap here (12 per 18 MFMAs), registers are not.
+    auto fr = [&](auto ic) __attribute__((always_inline)) -> bf16x8 {
+      constexpr int dx = decltype(ic)::value >> 1, kk = decltype(ic)::value & 1;
       if constexpr (dx == 0) return *(const bf16x8*)(lds + fb[0][kk] + J * S_ROW);
       else return *(const bf16x8*)(lds + fb[dx][kk] + J * pitch[dx]);
     };
-    auto mm = [&](auto dc, auto kc, const bf16x8& f) __attribute__((always_inline)) {
-      constexpr int dx = decltype(dc)::value, kk = decltype(kc)::value;
+    auto mO = [&](auto ic, const bf16x8& f) __attribute__((always_inline)) {
+      constexpr int dx = decltype(ic)::value >> 1, kk = decltype(ic)::value & 1;
+      accO = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[6 + dx][kk], f, accO, 0, 0, 0);
+    };
+    auto mNM = [&](auto ic, const bf16x8& f) __attribute__((always_inline)) {
+      constexpr int dx = decltype(ic)::value >> 1, kk = decltype(ic)::value & 1;
       if constexpr (dx == 0 && kk == 0) {
         if constexpr (BIAS) accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[0][0], f, biasv, 0, 0, 0);
         else {
@@ -194,46 +204,54 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_strip_kernel
         }
       } else accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[dx][kk], f, accN, 0, 0, 0);
       accM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[3 + dx][kk], f, accM, 0, 0, 0);
-      accO = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[6 + dx][kk], f, accO, 0, 0, 0);
     };
-    bf16x8 fa = fr(SIC<0>{}, SIC<0>{}), fbb = fr(SIC<0>{}, SIC<1>{});
-    __builtin_amdgcn_sched_barrier(0);
-    mm(SIC<0>{}, SIC<0>{}, fa); fa = fr(SIC<1>{}, SIC<0>{});
-    __builtin_amdgcn_sched_barrier(0);
-    mm(SIC<0>{}, SIC<1>{}, fbb); fbb = fr(SIC<1>{}, SIC<1>{});
-    __builtin_amdgcn_sched_barrier(0);
-    mm(SIC<1>{}, SIC<0>{}, fa); fa = fr(SIC<2>{}, SIC<0>{});
-    __builtin_amdgcn_sched_barrier(0);
-    mm(SIC<1>{}, SIC<1>{}, fbb); fbb = fr(SIC<2>{}, SIC<1>{});
-    __builtin_amdgcn_sched_barrier(0);
-    mm(SIC<2>{}, SIC<0>{}, fa);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(SIC<2>{}, SIC<1>{}, fbb);
-    __builtin_amdgcn_sched_barrier(0);
+    unsigned pk[8];
+    // epilogue chunk c (0..7): registers 2c, 2c + 1 of the completed accumulator -> one bf16 pair + their statistics
+    auto epi = [&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      if constexpr (EPI) {
+        const bf16x2 t = {(bf16_t)accO[2 * c], (bf16_t)accO[2 * c + 1]};
+        pk[c] = __builtin_bit_cast(unsigned, t);
+        if constexpr (STATS) {
+          // of the ROUNDED values: what the following norm layer reads (and what autocast's InstanceNorm of a bf16 tensor sees)
+          const f32x2 v = {__builtin_bit_cast(float, pk[c] << 16), __builtin_bit_cast(float, pk[c] & 0xffff0000u)};
+          s1[c] += v; s2[c] = __builtin_elementwise_fma(v, v, s2[c]);
+          asm volatile("" : "+v"(s1[c]), "+v"(s2[c]));       // pinned here: their only use is after the loop, and the compiler sinks them behind the step
+        }
+      }
+    };
+    // lanes h = 0 hold channels {0-3, 8-11, 16-19, 24-27}, h = 1 {4-7, 12-15, 20-23, 28-31}: swap (pk[i], pk[4 + i]) across the halves ->
+    // h = 0: channels 0-15, h = 1: 16-31, in register order 0 1 4 5 2 3 6 7
+#define SB __builtin_amdgcn_sched_barrier(0)
+    bf16x8 b0 = fr(SIC<0>{}), b1 = fr(SIC<1>{}), b2 = fr(SIC<2>{});
+    SB;
+    if constexpr (EPI) {
+      mO(SIC<0>{}, b0); b0 = fr(SIC<3>{}); SB;
+      mO(SIC<1>{}, b1); b1 = fr(SIC<4>{}); SB;
+      mO(SIC<2>{}, b2); b2 = fr(SIC<5>{}); SB;
+      mO(SIC<3>{}, b0); b0 = fr(SIC<0>{}); SB;
+      mO(SIC<4>{}, b1); b1 = fr(SIC<1>{}); SB;
+      mO(SIC<5>{}, b2); b2 = fr(SIC<2>{}); SB;
+    }
+    mNM(SIC<0>{}, b0); b0 = fr(SIC<3>{}); SB;
+    mNM(SIC<1>{}, b1); b1 = fr(SIC<4>{}); epi(SIC<0>{}); epi(SIC<1>{}); SB;
+    mNM(SIC<2>{}, b2); b2 = fr(SIC<5>{}); epi(SIC<2>{}); epi(SIC<3>{}); epi(SIC<4>{}); SB;
+    mNM(SIC<3>{}, b0); epi(SIC<5>{}); epi(SIC<6>{}); epi(SIC<7>{}); SB;
+    mNM(SIC<4>{}, b1);
+    if constexpr (EPI) { swap_halves(pk[0], pk[4]); swap_halves(pk[1], pk[5]); swap_halves(pk[2], pk[6]); swap_halves(pk[3], pk[7]); }
+    SB;
+    mNM(SIC<5>{}, b2);
     // output row r0 + trel - 2 is complete
     if constexpr (EPI) {
-      if constexpr (STATS) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) { s1[r] += accO[r]; s2[r] = __builtin_fmaf(accO[r], accO[r], s2[r]); }
-      }
-      unsigned pk[8];
-#pragma unroll
-      for (int r = 0; r < 8; r++) {
-        const bf16x2 t = {(bf16_t)accO[2 * r], (bf16_t)accO[2 * r + 1]};
-        pk[r] = __builtin_bit_cast(unsigned, t);
-      }
-      // lanes h = 0 hold channels {0-3, 8-11, 16-19, 24-27}, h = 1 {4-7, 12-15, 20-23, 28-31}: swap (pk[i], pk[4 + i]) across the halves ->
-      // h = 0: channels 0-15, h = 1: 16-31, in register order 0 1 4 5 2 3 6 7
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(pk[i]), "+v"(pk[4 + i]));
-      const unsigned so = (unsigned)(((long)b * P.H + (r0 + trel - 2)) * P.W + x0) * (unsigned)P.ldy * 2u;
+      const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(((long)b * P.H + (r0 + trel - 2)) * P.W + x0) * (unsigned)P.ldy * 2u);
       const u32x4 lo = {pk[0], pk[1], pk[4], pk[5]}, hi = {pk[2], pk[3], pk[6], pk[7]};
       if (!(P.dbg & 1)) {
         __builtin_amdgcn_raw_buffer_store_b128(lo, yrs, yvo, so, 0);
         __builtin_amdgcn_raw_buffer_store_b128(hi, yrs, yvo + 16u, so, 0);
       }
     }
+    SB;
+#undef SB
   };
 
   step(SIC<0>{}, SIC<0>{}, SIC<8>{}, 0, a0, a1, a2);
@@ -259,7 +277,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_strip_kernel
       vm_wait<0>();                                  // every (dummy) DMA into this wave's LDS has landed: reuse it
       float* red = (float*)lds;                      // [64 lanes][33]
 #pragma unroll
-      for (int r = 0; r < 16; r++) { red[lane * 33 + r] = s1[r]; red[lane * 33 + 16 + r] = s2[r]; }
+      for (int r = 0; r < 16; r++) { red[lane * 33 + r] = s1[r >> 1][r & 1]; red[lane * 33 + 16 + r] = s2[r >> 1][r & 1]; }
       // lane j: value vi = j & 31 of half j >> 5, summed over that half's 32 lanes
       const int vi = lane & 31;
       float t = 0.f;
