@@ -322,8 +322,8 @@ extern "C" int du_conv3x3_halo(const void* x, int64_t ldx, const void* x2, int64
   if (H % TH || W % TW || ldx % 8 || ldy % 8 || (x2 && (ldx2 % 8 || C1 % 8)) || Cin % 8) return DU_ERR_UNSUPPORTED;
   if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)x2)) & 15) return DU_ERR_UNSUPPORTED;
   if (!x2) C1 = Cin;
-  if (!x2) {       // streaming strip kernel (conv_strip.hip) where it serves the shape
-    const int rc = du_conv3x3_strip(x, ldx, Cin, Cout, B, H, W, w, bias, y, ldy, stats_part, stream);
+  {                // streaming strip kernel (conv_strip.hip) where it serves the shape
+    const int rc = du_conv3x3_strip(x, ldx, x2, ldx2, C1, Cin, Cout, B, H, W, w, bias, y, ldy, stats_part, stream);
     if (rc != DU_ERR_UNSUPPORTED) return rc;
   }
   HaloParams P{};

@@ -182,10 +182,11 @@ int du_conv3x3_halo(const void* x, int64_t ldx, const void* x2, int64_t ldx2, in
                     const void* w, const float* bias, void* y, int64_t ldy, float* stats_part, void* stream);
 /* rows of the partial-statistics array du_conv3x3_halo writes for this shape (depends on the kernel that serves it; 0 = not served) */
 int du_conv3x3_halo_parts(int C1, int Cin, int Cout, int B, int H, int W);
-/* The streaming kernel behind du_conv3x3_halo for 32 input channels, Cout in {32, 64}, W % 128 == 0 (one wave per 32-column strip,
-   weights in registers, rows by LDS-DMA; csrc/conv_strip.hip).  DU_ERR_UNSUPPORTED for any other shape. */
-int du_conv3x3_strip(const void* x, int64_t ldx, int Cin, int Cout, int B, int H, int W, const void* w, const float* bias,
-                     void* y, int64_t ldy, float* stats_part, void* stream);
+/* The streaming kernel behind du_conv3x3_halo for Cin in {32, 64 (one tensor, or a 32 + 32 concat)}, Cout in {32, 64}, W % 128 == 0,
+   H % 8 == 0 (one wave per 32-column strip, weights in registers / an LDS image, rows by LDS-DMA; csrc/conv_strip.hip).  Arguments as
+   du_conv3x3_halo.  DU_ERR_UNSUPPORTED for any other shape. */
+int du_conv3x3_strip(const void* x, int64_t ldx, const void* x2, int64_t ldx2, int C1, int Cin, int Cout, int B, int H, int W,
+                     const void* w, const float* bias, void* y, int64_t ldy, float* stats_part, void* stream);
 /* Weight gradient of the same convolution, dw (Cout, 9*Cin) fp32 in (tap, ci) column order (OVERWRITTEN).  part: scratch of
    du_conv3x3_wgrad_halo_blocks(...) * Cout * 9*Cin floats (0 blocks = shape not served -> use du_gemm's IM2COL_COL path).
    with_db != 0: the bias gradient db[co] = sum_pixels dy rides along -- dw then has Cout * 9*Cin + Cout elements (db behind the weight
