@@ -229,9 +229,18 @@ def north_star_targets(prof):
     if "attn_fwd_kernel" in agg and agg["attn_fwd_kernel"][0] > 0:
         t, fl, _ = agg["attn_fwd_kernel"]
         out["attention_mfma_frac"] = {"measured": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "target": 0.40, "kernel": "attn_fwd_kernel"}
-    if "conv3x3_halo_kernel" in agg and agg["conv3x3_halo_kernel"][0] > 0:
+    if "conv3x3_halo_kernel" in agg and agg["conv3x3_halo_kernel"][0] > 0:        # 3x3 convolutions with <= 64 output channels (512^2, 256^2)
         t, _, nb = agg["conv3x3_halo_kernel"]
-        out["decoder_conv_hbm_frac"] = {"measured": round(nb / t / 1e9 / HBM_PEAK_GBS, 4), "target": 0.60, "kernel": "conv3x3_halo_kernel"}
+        out["decoder_conv_hbm_frac"] = {"measured": round(nb / t / 1e9 / HBM_PEAK_GBS, 4), "target": 0.60,
+                                        "kernel": "conv3x3_strip_kernel / conv3x3_halo_kernel, Cout <= 64", "ms": round(t * 1e3, 3)}
+    if "conv3x3_halo_c128_kernel" in agg and agg["conv3x3_halo_c128_kernel"][0] > 0:   # 128 output channels: above the ridge -> MFMA roof
+        t, fl, _ = agg["conv3x3_halo_c128_kernel"]
+        out["decoder_conv_mfma_frac"] = {"measured": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "target": 0.35,
+                                         "kernel": "conv3x3_halo_kernel, Cout = 128", "ms": round(t * 1e3, 3)}
+    for key, name, tgt in (("msda_fwd", "msda_fwd_hbm_frac", 0.35), ("msda_bwd", "msda_bwd_hbm_frac", 0.25)):
+        if key in agg and agg[key][0] > 0:                                        # the gather path of MSDeformAttn (algorithmic bytes)
+            t, _, nb = agg[key]
+            out[name] = {"measured": round(nb / t / 1e9 / HBM_PEAK_GBS, 4), "target": tgt, "gbs": round(nb / t / 1e9, 1), "ms": round(t * 1e3, 3)}
     out["scaling_8gpu"] = {"measured": None, "target": 6.5, "note": "the driver's SCALE run measures it"}
     return out
 

@@ -1574,7 +1574,9 @@ int du_gemm_p8_choice(const du_gemm_args& a) {
   const long tm = (a.M + 255) / 256;
   const long t256 = tm * ((a.N + 255) / 256) * batch, t128 = tm * ((a.N + 127) / 128) * batch;
   if (t128 < 192) return 0;
-  const double c256 = (double)((t256 + 255) / 256) * 1.0, c128 = (double)((t128 + 255) / 256) * 0.56;
+  // (round 4: at K = 1024 the narrow tile's fixed costs -- prologue, exposed epilogue -- weigh more: 3 rounds of 256 x 128 tiles cost 62.8-67.6 us
+  //  against 62.8-63.5 us for 2 rounds of 256 x 256 on the 8192 / 8232 x 3072 qkv product, ratio 0.66-0.72 per round, not 0.56)
+  const double c256 = (double)((t256 + 255) / 256) * 1.0, c128 = (double)((t128 + 255) / 256) * (a.K >= 1024 ? 0.68 : 0.56);
   // (>= 128 tiles since round 3: the tall products of the adapter with ONE 256-wide tile column -- 43008 x {192, 256} x 1024 -- read their A
   //  operand once with the 256 x 256 tile and twice with two half-empty 128-wide columns: 31.8 / 32.6 us against 34.7 / 37.3 us)
   if (t256 >= 128 && c256 <= c128) return 1;

@@ -108,6 +108,123 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const T* __restri
   }
 }
 
+// LayerNorm backward in ONE pass over x / dy (round 4; the two kernels above and below read both tensors twice: 0.74 + 0.44 ms per step
+// on the adapter's 43008 x 1024 LayerNorms).  A workgroup owns a strip of rows, one wave per row as in layernorm_bwd_dx_kernel; on the way
+// every lane also accumulates the weight / bias gradient terms of ITS columns (dw += dy * xhat, db += dy) over the rows its wave visits.
+// The four waves' sums are combined through LDS and written as one partial row per workgroup: part[strip][D][2] -> finalize_kernel.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                  const float* __restrict__ w, const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, T* __restrict__ dx, long rows, int D,
+                                                                  const T* __restrict__ dres, int strip, float* __restrict__ part) {
+  constexpr int VI = Elem<T>::VEC;
+  extern __shared__ float ln_red[];                     // [3][D][2]: the sums of waves 1-3
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = D / VI;
+  float wv[MAXV][VI], sa[MAXV][VI], sb[MAXV][VI];
+#pragma unroll
+  for (int i = 0; i < MAXV; i++) {
+    const int vi = lane + i * 64;
+#pragma unroll
+    for (int j = 0; j < VI; j++) { wv[i][j] = vi < nvec ? w[vi * VI + j] : 0.f; sa[i][j] = 0.f; sb[i][j] = 0.f; }
+  }
+  const long r0 = (long)blockIdx.x * strip;
+  const long r1 = r0 + strip < rows ? r0 + strip : rows;
+  // two rows of the wave in flight per iteration (a strip gives a wave ~20 rows: one row at a time left the loads latency-bound)
+  for (long row0 = r0 + wave; row0 < r1; row0 += 8) {
+    uint4 rx[2][MAXV], rg[2][MAXV];
+    float mu[2], rs[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const long row = row0 + 4 * u;
+      const bool live = row < r1;
+      mu[u] = live ? mean[row] : 0.f; rs[u] = live ? rstd[row] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; i++) {
+        const int vi = lane + i * 64;
+        rx[u][i] = make_uint4(0, 0, 0, 0); rg[u][i] = make_uint4(0, 0, 0, 0);
+        if (live && vi < nvec) {
+          rx[u][i] = *(const uint4*)(x + row * (long)D + (long)vi * VI);
+          rg[u][i] = *(const uint4*)(dy + row * (long)D + (long)vi * VI);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const long row = row0 + 4 * u;
+      if (row >= r1) break;
+      float xh[MAXV][VI], g[MAXV][VI];
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; i++) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+          Vec16<T> tx = as_vec<T>(rx[u][i]);
+          Vec16<T> tg = as_vec<T>(rg[u][i]);
+#pragma unroll
+          for (int j = 0; j < VI; j++) {
+            const float gy = to_f32(tg.v[j]);
+            xh[i][j] = (to_f32(tx.v[j]) - mu[u]) * rs[u];
+            g[i][j] = gy * wv[i][j];
+            c1 += g[i][j];
+            c2 += g[i][j] * xh[i][j];
+            sa[i][j] += gy * xh[i][j];
+            sb[i][j] += gy;
+          }
+        }
+      }
+      c1 = wave_sum(c1) / (float)D;
+      c2 = wave_sum(c2) / (float)D;
+#pragma unroll
+      for (int i = 0; i < MAXV; i++) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+          Vec16<T> o;
+          if (dres) {
+            Vec16<T> tr = as_vec<T>(*(const uint4*)(dres + row * (long)D + (long)vi * VI));
+#pragma unroll
+            for (int j = 0; j < VI; j++) o.v[j] = from_f32<T>(rs[u] * (g[i][j] - c1 - xh[i][j] * c2) + to_f32(tr.v[j]));
+          } else {
+#pragma unroll
+            for (int j = 0; j < VI; j++) o.v[j] = from_f32<T>(rs[u] * (g[i][j] - c1 - xh[i][j] * c2));
+          }
+          *(uint4*)(dx + row * (long)D + (long)vi * VI) = as_u4(o);
+        }
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+#pragma unroll
+        for (int j = 0; j < VI; j += 2)
+          *(float4*)(ln_red + ((long)(wave - 1) * D + vi * VI + j) * 2) = make_float4(sa[i][j], sb[i][j], sa[i][j + 1], sb[i][j + 1]);
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+#pragma unroll
+        for (int j = 0; j < VI; j += 2) {
+          float4 t = make_float4(sa[i][j], sb[i][j], sa[i][j + 1], sb[i][j + 1]);
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            const float4 u = *(const float4*)(ln_red + ((long)q * D + vi * VI + j) * 2);
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+          }
+          *(float4*)(part + ((long)blockIdx.x * D + vi * VI + j) * 2) = t;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Channel statistics over NHWC: thread = (pixel lane, channel vector); block = one strip of one group.
 // ------------------------------------------------------------------------------------------------------
@@ -630,6 +747,20 @@ int ln_bwd_dispatch(const void* x, const void* dy, const float* w, const float* 
   const int nvec = D / Elem<T>::VEC;
   const int maxv = (nvec + 63) / 64;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  {
+    // one pass (dx + the weight / bias gradient partials) when the scratch for the partials is there and a lane's columns fit in registers
+    static const bool off = getenv("DU_LN_BWD_FUSED") && atoi(getenv("DU_LN_BWD_FUSED")) == 0;
+    const int STRIP = pick_strip(1, rows, D, Elem<T>::VEC);
+    const long strips = (rows + STRIP - 1) / STRIP;
+    const size_t lds = (size_t)3 * D * 2 * sizeof(float);
+    if (!off && maxv <= 4 && ws && ws_elems >= strips * D * 2 && lds <= 64 * 1024) {
+      return strip_launch(dwdb, ws, ws_elems, 1, strips, D, st, [&](float* part) {
+#define LNF_LAUNCH(MV) hipLaunchKernelGGL((layernorm_bwd_fused_kernel<T, MV>), dim3((unsigned)strips), block, lds, st, (const T*)x, (const T*)dy, w, mean, rstd, (T*)dx, rows, D, (const T*)dres, STRIP, part)
+        if (maxv <= 1) LNF_LAUNCH(1); else if (maxv <= 2) LNF_LAUNCH(2); else LNF_LAUNCH(4);
+#undef LNF_LAUNCH
+      }, 2);
+    }
+  }
 #define LNB_LAUNCH(MV) hipLaunchKernelGGL((layernorm_bwd_dx_kernel<T, MV>), grid, block, 0, st, (const T*)x, (const T*)dy, w, mean, rstd, (T*)dx, rows, D, (const T*)dres)
   if (maxv <= 1) LNB_LAUNCH(1); else if (maxv <= 2) LNB_LAUNCH(2); else if (maxv <= 4) LNB_LAUNCH(4);
   else if (maxv <= 8) LNB_LAUNCH(8); else if (maxv <= 16) LNB_LAUNCH(16); else return DU_ERR_UNSUPPORTED;

@@ -867,7 +867,8 @@ def conv3x3_halo(x, wp, bias, x2=None, want_stats=False):
         return None
     _lib.check(rc, "du_conv3x3_halo")
     if PROFILE is not None:
-        PROFILE.stop("conv3x3_halo_kernel<bf16>" + (f" {H}x{W} {Cin}->{Cout}" if PROFILE.detail else ""), e0,
+        # <= 64 output channels: HBM-bound layers (512^2 / 256^2); 128: above the ridge (bench.py reports them against the MFMA peak)
+        PROFILE.stop(("conv3x3_halo_kernel<bf16>" if Cout <= 64 else "conv3x3_halo_c128_kernel<bf16>") + (f" {H}x{W} {Cin}->{Cout}" if PROFILE.detail else ""), e0,
                      2.0 * B * H * W * Cin * Cout * 9, 2.0 * B * H * W * (Cin + Cout))
     return y, part
 
@@ -1656,8 +1657,12 @@ def msda_forward_raw(value, shapes, lsi, loc, attn):
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = loc.shape
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    e0 = PROFILE.start() if PROFILE is not None else None
     _lib.check(_lib.lib().du_msda_forward(_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(attn), _p(out), N, S, M, D,
                                           L, Lq, P, _st()), "du_msda_forward")
+    if PROFILE is not None:       # algorithmic bytes: value + sampling locations + attention weights read once, the output written once
+        PROFILE.stop("msda_fwd<gather>", e0, 8.0 * N * Lq * M * L * P * D,
+                     float(value.numel() * value.element_size() + loc.numel() * 4 + attn.numel() * 4 + out.numel() * out.element_size()))
     return out
 
 
@@ -1671,17 +1676,26 @@ def msda_backward_raw(value, shapes, lsi, loc, attn, grad_out, gv_like_value=Fal
     ga = torch.empty(attn.shape, dtype=torch.float32, device=value.device)
     n = int(_lib.lib().du_msda_bwd_ws_elems(N, S, M, D, L, Lq, P))
     ws = torch.empty(max(n, 1), dtype=torch.float32, device=value.device)
+    e0 = PROFILE.start() if PROFILE is not None else None
+
+    def _prof(gv):                # algorithmic bytes: value, locations, weights, grad_out read once; the three gradients written once
+        if PROFILE is not None:
+            PROFILE.stop("msda_bwd<gather>", e0, 24.0 * N * Lq * M * L * P * D,
+                         float(value.numel() * value.element_size() + loc.numel() * 8 + attn.numel() * 8
+                               + grad_out.numel() * grad_out.element_size() + gv.numel() * gv.element_size()))
     if gv_like_value and value.dtype == torch.bfloat16:
         gvb = torch.empty((N, S, M, D), dtype=torch.bfloat16, device=value.device)
         rc = _lib.lib().du_msda_backward_bf16gv(_p(value), _p(shapes), _p(lsi), _p(loc), _p(attn), _p(grad_out), _p(gvb), _p(gl), _p(ga),
                                                 N, S, M, D, L, Lq, P, _p(ws), n, _st())
         if rc == 0:
+            _prof(gvb)
             return gvb, gl, ga
         if rc != -2:
             _lib.check(rc, "du_msda_backward_bf16gv")
     gv = torch.empty((N, S, M, D), dtype=torch.float32, device=value.device)      # all three are fully written by the library
     _lib.check(_lib.lib().du_msda_backward(_code(value.dtype), _p(value), _p(shapes), _p(lsi), _p(loc), _p(attn), _p(grad_out), _p(gv),
                                            _p(gl), _p(ga), N, S, M, D, L, Lq, P, _p(ws), n, _st()), "du_msda_backward")
+    _prof(gv)
     return gv, gl, ga
 
 

@@ -1129,7 +1129,9 @@ def test_seg_head_streaming_kernels_match_conv1x1(B, H, W, K, ld):
                                               (1, 32, 48, 32, 0, 64), (3, 8, 16, 128, 0, 64),
                                               # served by the streaming strip kernel (conv_strip.hip): W % 128 == 0, 32 input channels; segments
                                               # of 8 / 12 / 10 rows, image borders on every side of a strip, 64 outputs = wave pairs
-                                              (1, 8, 128, 32, 0, 32), (2, 24, 256, 32, 0, 32), (2, 40, 384, 32, 0, 64), (8, 64, 128, 32, 0, 32)])
+                                              (1, 8, 128, 32, 0, 32), (2, 24, 256, 32, 0, 32), (2, 40, 384, 32, 0, 64), (8, 64, 128, 32, 0, 32),
+                                              # ... 64 input channels = two ring planes (one tensor, or the two tensors of a concat)
+                                              (1, 16, 128, 64, 0, 32), (2, 24, 256, 32, 32, 32), (2, 40, 128, 64, 0, 64), (3, 64, 128, 32, 32, 64)])
 def test_conv3x3_halo_kernel_fwd_bwd_stats(B, H, W, C1, C2, Cout):
     """LDS-tiled direct conv (bf16): forward (+fused concat), flipped-weight data gradient, weight gradient, and the per-tile channel
     statistics it emits, vs torch conv2d / the separate statistics kernel."""
