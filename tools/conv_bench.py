@@ -17,10 +17,12 @@ if "--lib" in sys.argv:                      # A/B against another build of the 
     _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 
 SHAPES = [            # (H, W, C1, C2, Cout)   C2 > 0: fused concat of two sources
-    (512, 512, 32, 0, 32),
-    (512, 512, 32, 32, 32),
+    (512, 512, 32, 0, 32),        # conv2 of the 512^2 stage and its data gradient
+    (512, 512, 32, 32, 32),       # conv1 of the 512^2 stage (concat of the skip and the upsampled tensor)
+    (512, 512, 32, 0, 64),        # its data gradient (towards both halves of the concat)
     (256, 256, 64, 0, 64),
     (256, 256, 64, 64, 64),
+    (256, 256, 64, 0, 128),
     (256, 256, 32, 0, 64),
     (128, 128, 128, 0, 128),
     (128, 128, 128, 128, 128),
@@ -34,7 +36,8 @@ def main():
     torch.manual_seed(0)
     print(f"# library {os.path.relpath(_lib.LIB_PATH, ROOT)}")
     print(f"# du_conv3x3_halo, batch {B}, bf16, ring of buffers > 256 MB; GB/s = (x [+ x2] + y bytes) / time; frac of 8000 GB/s")
-    print(f"# {'H x W':>9} {'Cin':>7} {'Cout':>4} {'us':>8} {'GB/s':>8} {'frac':>6} {'TFLOP/s':>8}")
+    print("# kernel: strip = csrc/conv_strip.hip (one wave per 32-column strip, round 4), halo = csrc/conv_halo.hip (LDS-tiled); DU_CONV_STRIP=0 forces halo")
+    print(f"# {'H x W':>9} {'Cin':>7} {'Cout':>4} {'us':>8} {'GB/s':>8} {'frac':>6} {'TFLOP/s':>8} {'of 2.5 PF':>9}  kernel")
     for H, W, C1, C2, Cout in SHAPES:
         Cin = C1 + C2
         per = B * H * W * (Cin + Cout) * 2
@@ -58,7 +61,9 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / n
         gbs = per / us / 1e3
         tf = 2.0 * B * H * W * Cin * Cout * 9 / us / 1e6
-        print(f"{H:5d}x{W:<4d} {C1:3d}+{C2:<3d} {Cout:4d} {us:8.1f} {gbs:8.0f} {gbs / 8000:6.3f} {tf:8.1f}")
+        strip = os.environ.get("DU_CONV_STRIP", "1") != "0" and W % 128 == 0 and H % 8 == 0 and Cout in (32, 64) and \
+            (Cin == 32 and not C2 or Cin == 64 and (not C2 or C1 == 32))
+        print(f"{H:5d}x{W:<4d} {C1:3d}+{C2:<3d} {Cout:4d} {us:8.1f} {gbs:8.0f} {gbs / 8000:6.3f} {tf:8.1f} {tf / 2500:9.3f}  {'strip' if strip else 'halo'}")
         del xs, x2s
 
 
