@@ -57,31 +57,39 @@ def load_dinov3_model(model_name: str, pretrained_path: str = None, allow_random
 
 
 def _act_code(nonlin, nonlin_kwargs):
+    """Activation code of the fused norm + activation kernel, or None when the kernel has no such activation (the block then applies the
+    nn.Module itself after an un-activated norm: a LeakyReLU slope other than 0.01, GELU, PReLU ... -- never hit by the 2D plans, but the
+    reference's constructor accepts them, dinounet_training.py:581-592)."""
     if nonlin is None:
         return ACT_NONE
     if issubclass(nonlin, nn.LeakyReLU):
         slope = (nonlin_kwargs or {}).get("negative_slope", 0.01)
-        if abs(slope - 0.01) > 1e-12:
-            raise NotImplementedError("LeakyReLU slope other than 0.01")
-        return ACT_LEAKY
+        return ACT_LEAKY if abs(slope - 0.01) <= 1e-12 else None
     if issubclass(nonlin, nn.ReLU):
         return ACT_RELU
-    raise NotImplementedError(f"activation {nonlin}")
+    return None
+
+
+def _nchw_module(mod, x):
+    """Run a torch module that expects NCHW on our NHWC tensor (a channels-last view: no copy)."""
+    return mod(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
 
 
 def _norm_act(x, norm_mod, act, training, stats_part=None):
     """InstanceNorm2d (plans default) or BatchNorm2d container -> fused norm+activation kernel.  stats_part: partial channel
     statistics emitted by the producing convolution (ops.conv2d_stats), saves the statistics pass."""
-    if isinstance(norm_mod, nn.InstanceNorm2d):
-        if not norm_mod.affine:
-            raise NotImplementedError("non-affine InstanceNorm")
-        return ops.norm_act(x, norm_mod.weight, norm_mod.bias, "in", act, norm_mod.eps, True, stats_part=stats_part)
+    if isinstance(norm_mod, nn.InstanceNorm2d) and not norm_mod.track_running_stats:
+        w, b = norm_mod.weight, norm_mod.bias
+        if not norm_mod.affine:                       # the kernel wants a scale / shift: ones / zeros (their gradients are dropped)
+            w = torch.ones(x.shape[-1], dtype=torch.float32, device=x.device)
+            b = torch.zeros(x.shape[-1], dtype=torch.float32, device=x.device)
+        return ops.norm_act(x, w, b, "in", act, norm_mod.eps, True, stats_part=stats_part)
     if isinstance(norm_mod, nn.modules.batchnorm._BatchNorm):
         if training and norm_mod.track_running_stats and norm_mod.num_batches_tracked is not None:
             norm_mod.num_batches_tracked += 1          # nn.BatchNorm2d.forward does (state_dict parity with the reference)
         return ops.norm_act(x, norm_mod.weight, norm_mod.bias, "bn", act, norm_mod.eps, training, norm_mod.running_mean,
                             norm_mod.running_var, norm_mod.momentum or 0.1, None, stats_part=stats_part if training else None)
-    raise NotImplementedError(f"norm {type(norm_mod)}")
+    raise TypeError(f"_norm_act: no kernel for {type(norm_mod)} (ConvDropoutNormReLU routes such layers through the torch module)")
 
 
 class SqueezeExcitation(nn.Module):
@@ -232,29 +240,47 @@ class ConvDropoutNormReLU(nn.Module):
             kernel_size = [kernel_size] * 2
         if not isinstance(stride, (tuple, list)):
             stride = [stride] * 2
-        if dropout_op is not None:
-            raise NotImplementedError("dropout in the decoder (plans use dropout_op None)")
-        if nonlin_first:
-            raise NotImplementedError("nonlin_first")
         mods = []
         self.conv = conv_op(input_channels, output_channels, kernel_size, stride, padding=[(i - 1) // 2 for i in kernel_size],
                             dilation=1, bias=conv_bias)
         mods.append(self.conv)
+        if dropout_op is not None:
+            self.dropout = dropout_op(**(dropout_op_kwargs or {}))
+            mods.append(self.dropout)
         if norm_op is not None:
             self.norm = norm_op(output_channels, **(norm_op_kwargs or {}))
             mods.append(self.norm)
         if nonlin is not None:
             self.nonlin = nonlin(**(nonlin_kwargs or {}))
             mods.append(self.nonlin)
+        if nonlin_first and norm_op is not None and nonlin is not None:     # conv -> dropout -> nonlin -> norm
+            mods[-1], mods[-2] = mods[-2], mods[-1]
+        self.nonlin_first = bool(nonlin_first)
         self._act = _act_code(nonlin, nonlin_kwargs)
         self.all_modules = nn.Sequential(*mods)
 
     def forward(self, x, x2=None):
         k, s = self.conv.kernel_size[0], self.conv.stride[0]
         y, st = ops.conv2d_stats(x, self.conv.weight, self.conv.bias, stride=s, pad=(k - 1) // 2, x2=x2)
-        if hasattr(self, "norm"):
+        kernel_norm = hasattr(self, "norm") and (isinstance(self.norm, nn.modules.batchnorm._BatchNorm) or
+                                                 (isinstance(self.norm, nn.InstanceNorm2d) and not self.norm.track_running_stats))
+        fused = kernel_norm and not hasattr(self, "dropout") and not self.nonlin_first and self._act is not None
+        if fused:                                     # what the 2D plans build: conv -> norm + activation in one kernel
             return _norm_act(y, self.norm, self._act, self.training, st)
-        raise NotImplementedError("conv block without norm")
+        # the other orders / layers the reference's constructor accepts (dinounet_training.py:581-592), composed from the same pieces; the
+        # convolution's own statistics describe its raw output only, so they are used only when the norm directly follows it
+        if hasattr(self, "dropout"):
+            y, st = _nchw_module(self.dropout, y), None
+        has_act = hasattr(self, "nonlin")
+        if self.nonlin_first and has_act:
+            y, st = _nchw_module(self.nonlin, y), None
+        late = has_act and not self.nonlin_first                # the activation still to come after the norm
+        if kernel_norm:
+            y = _norm_act(y, self.norm, self._act if late and self._act is not None else ACT_NONE, self.training, st)
+            late = late and self._act is None
+        elif hasattr(self, "norm"):                             # GroupNorm, InstanceNorm2d with running statistics ...: the torch module itself
+            y = _nchw_module(self.norm, y)
+        return _nchw_module(self.nonlin, y) if late else y
 
 
 class StackedConvBlocks(nn.Module):

@@ -229,3 +229,47 @@ def test_reference_ops_test_script_as_written_on_dropin_module():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("* ")]
     assert len(lines) == 2 + 7, lines
     assert all(ln.startswith("* True") for ln in lines), lines
+
+
+@pytest.mark.parametrize("variant", ["dropout_p0", "nonlin_first", "leaky_slope", "gelu", "in_no_affine", "groupnorm", "no_norm"])
+def test_decoder_block_variants_the_constructor_accepts(variant):
+    """ConvDropoutNormReLU / StackedConvBlocks with the arguments the 2D plans never use but the reference's constructor takes
+    (dinounet_training.py:581-592: dropout_op, nonlin_first, other activations / norms): composed from the same kernels plus the torch
+    module for the piece that has no kernel, against the plain torch composition in the same order, forward and gradients."""
+    from torch import nn
+    import torch.nn.functional as F
+    from dinounet_amd.network_architecture.dinounet import ConvDropoutNormReLU
+    kw = dict(conv_bias=True, norm_op=nn.InstanceNorm2d, norm_op_kwargs={"eps": 1e-5, "affine": True}, nonlin=nn.LeakyReLU,
+              nonlin_kwargs={"inplace": True})
+    if variant == "dropout_p0":
+        kw.update(dropout_op=nn.Dropout2d, dropout_op_kwargs={"p": 0.0})
+    elif variant == "nonlin_first":
+        kw.update(nonlin_first=True)
+    elif variant == "leaky_slope":
+        kw.update(nonlin_kwargs={"negative_slope": 0.2})
+    elif variant == "gelu":
+        kw.update(nonlin=nn.GELU, nonlin_kwargs={})
+    elif variant == "in_no_affine":
+        kw.update(norm_op_kwargs={"eps": 1e-5, "affine": False})
+    elif variant == "groupnorm":
+        kw.update(norm_op=lambda c, **k: nn.GroupNorm(4, c), norm_op_kwargs={})
+    elif variant == "no_norm":
+        kw.update(norm_op=None, norm_op_kwargs=None)
+    torch.manual_seed(3)
+    blk = ConvDropoutNormReLU(nn.Conv2d, 16, 32, 3, 1, **kw).cuda().train()
+    x = torch.randn(2, 24, 40, 16, device="cuda", requires_grad=True)        # NHWC, fp32 mode
+    y = blk(x)
+    go = torch.randn_like(y)
+    y.backward(go)
+    got = [y.detach(), x.grad.detach()] + [p.grad.detach() for p in blk.parameters()]
+    # reference: the registered modules in their registered order on the NCHW view
+    for p in blk.parameters():
+        p.grad = None
+    xr = x.detach().clone().requires_grad_(True)
+    yr = blk.all_modules(xr.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    yr.backward(go)
+    want = [yr.detach(), xr.grad.detach()] + [p.grad.detach() for p in blk.parameters()]
+    for a, b in zip(got, want):
+        assert a.shape == b.shape
+        # (+ an absolute floor: a conv bias in front of a norm has a mathematically zero gradient, ~1e-5 of rounding noise on both sides)
+        assert (a - b).norm() <= 2e-4 * b.norm() + 1e-3, (variant, float((a - b).norm()), float(b.norm()))
