@@ -807,6 +807,183 @@ __global__ __launch_bounds__(256) void msda_bwd_q8_kernel(const bf16_t* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// LDS-resident value plane (round 4): single level, 4 points, 32 channels per head, S * 128 B <= 128 KB (the adapter's Extractor: the
+// ViT's 32 x 32 token map, 16 heads).  The q8 kernels above gather their 16 corners per (query, head) from L2 -- 64-byte segments, 16 of
+// them per wave instruction through the texture-address path -- and sit at ~2x their VALU time (51 / 78 us, profiles/r03 steady trace).
+// Here a workgroup owns the value plane of TWO adjacent heads of one image ([pixel][2 x 32 channels] = 128 B per pixel, as it lies in
+// `value`) in LDS and walks a chunk of the queries: the gathers are ds_read_b128 (256 B / clock / CU, ~100-cycle latency).  8 lanes serve
+// one query (2 heads x 4 channel slices), so the output / grad_out rows are full 128-byte lines and loc / attn are read in 64 / 32-byte
+// pieces; the workgroups of the 8 head pairs of the same (image, query chunk) are dispatched 8 apart = onto the same XCD, whose L2
+// then serves the other halves of those lines.
+// Backward (grad_sampling_loc / grad_attn_weight): the channel dot products of a corner with this lane's grad_out slice are four
+// v_dot2_f32_bf16 on the packed pairs as they come from LDS -- no unpacking.
+// ------------------------------------------------------------------------------------------------------
+constexpr int MP_THREADS = 1024;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct PlaneJob { int b, hp, q0, q1; };
+__device__ __forceinline__ PlaneJob plane_job(int N, int M, int Lq, int nchunk) {
+  // blockIdx -> (slot = image x chunk, head pair): head pairs of one slot sit 8 workgroups apart (same XCD)
+  const int HP = M / 2;
+  const int bid = blockIdx.x;
+  const int lane8 = bid & 7, rest = bid >> 3;
+  const int hp = rest % HP, grp = rest / HP;
+  const int slot = grp * 8 + lane8;
+  PlaneJob j;
+  j.hp = hp;
+  j.b = slot / nchunk;
+  const int ch = slot - j.b * nchunk;
+  const int qpc = (Lq + nchunk - 1) / nchunk;
+  j.q0 = ch * qpc; j.q1 = j.q0 + qpc < Lq ? j.q0 + qpc : Lq;
+  if (j.b >= N) { j.q0 = 0; j.q1 = 0; j.b = 0; }
+  return j;
+}
+__device__ __forceinline__ void plane_load(unsigned char* plane, const bf16_t* value, int b, int hp, int S, int M) {
+  // [pixel][128 B] <- value[b][pixel][2 hp .. 2 hp + 1][0 .. 31]
+  const bf16_t* src = value + ((long)b * S * M + 2 * hp) * 32;
+  for (int v = threadIdx.x; v < S * 8; v += MP_THREADS)
+    *(uint4*)(plane + v * 16) = *(const uint4*)(src + (long)(v >> 3) * M * 32 + (v & 7) * 8);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(MP_THREADS) void msda_fwd_plane_kernel(const bf16_t* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                                   const float* __restrict__ loc, const float* __restrict__ attn,
+                                                                   bf16_t* __restrict__ out, int N, int S, int M, int Lq, int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char mp_plane[];
+  const PlaneJob J = plane_job(N, M, Lq, nchunk);
+  plane_load(mp_plane, value, J.b, J.hp, S, M);
+  const int H = (int)shapes[0], W = (int)shapes[1];
+  const int tid = threadIdx.x;
+  const int pt = tid & 3, hsel = (tid >> 2) & 1;
+  const int m = 2 * J.hp + hsel;
+  const unsigned lbase = (unsigned)((tid & 7) * 16);                  // this lane's 16 bytes inside a pixel's 128
+  const int qend = J.q0 + ((J.q1 - J.q0 + 7) & ~7);                    // whole groups of 8 queries = whole waves in the loop (DPP exchanges)
+  for (int q = J.q0 + (tid >> 3); q < qend; q += MP_THREADS / 8) {
+    const bool live = q < J.q1;
+    const long pr = ((long)J.b * Lq + (live ? q : J.q1 - 1)) * M + m;
+    const float2 lxy = *(const float2*)(loc + (pr * 4 + pt) * 2);
+    const float a = attn[pr * 4 + pt];
+    PointSetup ps = point_setup(lxy.x, lxy.y, H, W, 128u);
+    float ca[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) ca[k] = ps.cw[k] * a;
+    f32x2 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[j] = f32x2{0.f, 0.f};
+    auto point = [&](auto p_c) {
+      constexpr int p = decltype(p_c)::value;
+      uint4 v[4];
+      float f[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        f[k] = quad_bcastf<p>(ca[k]);
+        v[k] = *(const uint4*)(mp_plane + lbase + (unsigned)quad_bcast<p>(ps.off[k]));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        const f32x2 ff = {f[k], f[k]};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const f32x2 x = {__builtin_bit_cast(float, w[j] << 16), __builtin_bit_cast(float, w[j] & 0xffff0000u)};
+          acc[j] = __builtin_elementwise_fma(ff, x, acc[j]);
+        }
+      }
+    };
+    point(std::integral_constant<int, 0>{}); point(std::integral_constant<int, 1>{});
+    point(std::integral_constant<int, 2>{}); point(std::integral_constant<int, 3>{});
+    if (live) {
+      bf16x8 o8;
+#pragma unroll
+      for (int j = 0; j < 4; j++) { o8[2 * j] = (bf16_t)acc[j][0]; o8[2 * j + 1] = (bf16_t)acc[j][1]; }
+      *(uint4*)(out + pr * 32 + (tid & 3) * 8) = __builtin_bit_cast(uint4, o8);
+    }
+  }
+}
+
+__global__ __launch_bounds__(MP_THREADS) void msda_bwd_plane_kernel(const bf16_t* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                                   const float* __restrict__ loc, const float* __restrict__ attn,
+                                                                   const bf16_t* __restrict__ gout, float* __restrict__ gloc,
+                                                                   float* __restrict__ gattn, int N, int S, int M, int Lq, int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char mp_plane[];
+  const PlaneJob J = plane_job(N, M, Lq, nchunk);
+  plane_load(mp_plane, value, J.b, J.hp, S, M);
+  const int H = (int)shapes[0], W = (int)shapes[1];
+  const int tid = threadIdx.x;
+  const int pt = tid & 3, hsel = (tid >> 2) & 1;
+  const int m = 2 * J.hp + hsel;
+  const unsigned lbase = (unsigned)((tid & 7) * 16);
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const int qend = J.q0 + ((J.q1 - J.q0 + 7) & ~7);                    // whole groups of 8 queries = whole waves in the loop
+  for (int q = J.q0 + (tid >> 3); q < qend; q += MP_THREADS / 8) {
+    const bool live = q < J.q1;
+    const long pr = ((long)J.b * Lq + (live ? q : J.q1 - 1)) * M + m;
+    const uint4 tgv = *(const uint4*)(gout + pr * 32 + (tid & 3) * 8);
+    const unsigned tgw[4] = {tgv.x, tgv.y, tgv.z, tgv.w};
+    const float2 lxy = *(const float2*)(loc + (pr * 4 + pt) * 2);
+    const float a = attn[pr * 4 + pt];
+    PointSetup ps = point_setup(lxy.x, lxy.y, H, W, 128u);
+    // d(val)/dh and d(val)/dw corner coefficients (cuh:122-158), scaled by H * a / W * a like the reference's grad_loc; zero outside
+    const float hh = 1.f - ps.lh, hw = 1.f - ps.lw;
+    const float dh0[4] = {-hw, -ps.lw, hw, ps.lw}, dw0[4] = {-hh, hh, -ps.lh, ps.lh};
+    float dh[4], dw[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      dh[k] = ps.ok[k] ? dh0[k] * ((float)H * a) : 0.f;
+      dw[k] = ps.ok[k] ? dw0[k] * ((float)W * a) : 0.f;
+    }
+    float ga[4], gx[4], gy[4];
+    auto point = [&](auto p_c) {
+      constexpr int p = decltype(p_c)::value;
+      uint4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = *(const uint4*)(mp_plane + lbase + (unsigned)quad_bcast<p>(ps.off[k]));
+      float sa = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w[j]), __builtin_bit_cast(bf16x2_t, tgw[j]), t, false);
+        sa = fmaf(quad_bcastf<p>(ps.cw[k]), t, sa);
+        sx = fmaf(quad_bcastf<p>(dw[k]), t, sx);
+        sy = fmaf(quad_bcastf<p>(dh[k]), t, sy);
+      }
+      ga[p] = sa; gx[p] = sx; gy[p] = sy;
+    };
+    point(std::integral_constant<int, 0>{}); point(std::integral_constant<int, 1>{});
+    point(std::integral_constant<int, 2>{}); point(std::integral_constant<int, 3>{});
+    // sum over the 4 lanes of the (query, head) pair: inside the quad by DPP
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      ga[p] += quad_xor1(ga[p]); gx[p] += quad_xor1(gx[p]); gy[p] += quad_xor1(gy[p]);
+      ga[p] += quad_xor2(ga[p]); gx[p] += quad_xor2(gx[p]); gy[p] += quad_xor2(gy[p]);
+    }
+    const float oa = pt == 0 ? ga[0] : pt == 1 ? ga[1] : pt == 2 ? ga[2] : ga[3];
+    const float ox = pt == 0 ? gx[0] : pt == 1 ? gx[1] : pt == 2 ? gx[2] : gx[3];
+    const float oy = pt == 0 ? gy[0] : pt == 1 ? gy[1] : pt == 2 ? gy[2] : gy[3];
+    if (live) {
+      const long e = pr * 4 + pt;
+      gattn[e] = oa;
+      *(float2*)(gloc + e * 2) = make_float2(ox, oy);
+    }
+  }
+}
+
+// the plane kernels serve: bf16, one level, 4 points, 32 channels per head, an even number of heads, the two-head plane within 128 KB
+static bool plane_serves(int N, int S, int M, int D, int L, int P, int Lq) {
+  static const bool off = getenv("DU_MSDA_NO_PLANE") != nullptr;      // debugging / A-B aid
+  return !off && L == 1 && P == 4 && D == 32 && M % 2 == 0 && (long)S * 128 <= 128 * 1024 && Lq >= 64;
+}
+// query chunks per (image, head pair): one workgroup per CU with room to spare, slots (image x chunk) in multiples of 8
+static int plane_chunks(int N, int M, int Lq) {
+  int nchunk = (int)((256 + (long)N * (M / 2) - 1) / ((long)N * (M / 2)));
+  while ((N * nchunk) % 8) nchunk++;
+  const int maxc = Lq / 64 > 0 ? Lq / 64 : 1;
+  return nchunk > maxc ? maxc : nchunk;
+}
+
 int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
 // the round-3 fast kernels serve: bf16, 4 points, D / 8 in {4, 8, 16}, value < 2 GB (32-bit byte offsets), < 2^24 pixels and row bytes
@@ -822,6 +999,15 @@ template <typename T>
 int fwd_dispatch(const void* value, const int64_t* shapes, const int64_t* lsi, const float* loc, const float* attn, void* out,
                  int N, int S, int M, int D, int L, int Lq, int P, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
+    if (plane_serves(N, S, M, D, L, P, Lq)) {
+      const int nchunk = plane_chunks(N, M, Lq);
+      const int slots = ((N * nchunk + 7) / 8) * 8;
+      const int lds = S * 128;
+      if (hipFuncSetAttribute((const void*)msda_fwd_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DU_ERR_LAUNCH;
+      hipLaunchKernelGGL(msda_fwd_plane_kernel, dim3((unsigned)(slots * (M / 2))), dim3(MP_THREADS), lds, st, (const bf16_t*)value, shapes, loc, attn,
+                         (bf16_t*)out, N, S, M, Lq, nchunk);
+      return du_check_launch();
+    }
     if (q8_serves(N, S, M, D, P)) {
       const int lpp = D / 8;
       const long npairs = (long)N * Lq * M;
@@ -877,7 +1063,14 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
   if constexpr (sizeof(T) == 2) {
     if (!no_mfma && L == 1 && P == 4 && D <= 32 && LP <= 4) {
       // (1) gather-only pass: grad_sampling_loc / grad_attn_weight (no atomics)
-      if (q8_serves(N, S, M, D, P)) {
+      if (plane_serves(N, S, M, D, L, P, Lq)) {
+        const int nchunk = plane_chunks(N, M, Lq);
+        const int slots = ((N * nchunk + 7) / 8) * 8;
+        const int lds = S * 128;
+        if (hipFuncSetAttribute((const void*)msda_bwd_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DU_ERR_LAUNCH;
+        hipLaunchKernelGGL(msda_bwd_plane_kernel, dim3((unsigned)(slots * (M / 2))), dim3(MP_THREADS), lds, st, (const bf16_t*)value, shapes, loc, attn,
+                           (const bf16_t*)gout, gl, ga, N, S, M, Lq, nchunk);
+      } else if (q8_serves(N, S, M, D, P)) {
         const long gpw8 = 256 / (D / 8);
         long b8 = (npairs + gpw8 - 1) / gpw8;
         if (b8 > 256 * 32) b8 = 256 * 32;
