@@ -91,37 +91,6 @@ __global__ __launch_bounds__(256 * NCO, (NP == 1 && NCO == 1) ? 2 : 1) void conv
   unsigned char* lds = smem_raw + (wave & 3) * RING;
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds);
 
-  // ---- weights of plane 0: A fragment of (tap, kk) = w[co0 + n][tap * Cin + kk * 16 + h * 8 ..], in registers
-  bf16x8 Wf[9][2];
-  {
-    const bf16_t* wr = P.w + (long)(co0 + n) * 9 * Cin + h * 8;
-#pragma unroll
-    for (int tap = 0; tap < 9; tap++)
-#pragma unroll
-      for (int kk = 0; kk < 2; kk++) Wf[tap][kk] = *(const bf16x8*)(wr + tap * Cin + kk * 16);
-  }
-  // bias as the C input of the first MFMA of every output row: accumulator register r = channel (r & 3) + 8 (r >> 2) + 4 h.  NP = 1: in
-  // registers; NP = 2 (registers are short): an LDS image read back just before that MFMA
-  f32x16 biasv;
-  if constexpr (NP == 1) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) biasv[r] = BIAS ? P.bias[co0 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
-  }
-  const unsigned char* wl = smem_raw + WL_OFF + part * 18 * 1024 + lane * 16;          // + (tap * 2 + kk) * 1024
-  const float* bl = (const float*)(smem_raw + BL_OFF + part * 4096 + lane * 64);
-  if constexpr (NP == 2) {
-    // fragment f = tap * 2 + kk of plane 1; the four waves of a part share the work
-    const bf16_t* wr = P.w + (long)(co0 + n) * 9 * Cin + 32 + h * 8;
-    for (int f = wave & 3; f < 18; f += 4)
-      *(uint4*)(smem_raw + WL_OFF + part * 18 * 1024 + f * 1024 + lane * 16) = *(const uint4*)(wr + (f >> 1) * Cin + (f & 1) * 16);
-    if constexpr (BIAS) {
-      if ((wave & 3) == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) ((float*)(smem_raw + BL_OFF + part * 4096 + lane * 64))[r] = P.bias[co0 + (r & 3) + 8 * (r >> 2) + 4 * h];
-      }
-    }
-  }
-
   // ---- source descriptors (one image per plane) and the per-lane DMA offsets
   u32x4 srd[NP];
   unsigned pbp[NP];                                     // pixel pitch of the plane's source in bytes
@@ -203,12 +172,46 @@ __global__ __launch_bounds__(256 * NCO, (NP == 1 && NCO == 1) ? 2 : 1) void conv
 #pragma unroll
   for (int r = 0; r < 16; r++) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; }
 
-  if constexpr (NP == 2) __syncthreads();   // the weight / bias images
-
   // ---- prologue: edge group 0 and rows 0 .. AHEAD - 1
   dma_edge(0);
 #pragma unroll
   for (int t = 0; t < S_AHEAD; t++) dma_row(t, t);
+
+  // (the weights are fetched BEHIND the ring's first rows: their latency and the rows' overlap; the compiler's waits for these loads
+  //  also cover the older DMA pieces, which is harmless)
+  // ---- weights of plane 0: A fragment of (tap, kk) = w[co0 + n][tap * Cin + kk * 16 + h * 8 ..], in registers
+  bf16x8 Wf[9][2];
+  {
+    const bf16_t* wr = P.w + (long)(co0 + n) * 9 * Cin + h * 8;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) Wf[tap][kk] = *(const bf16x8*)(wr + tap * Cin + kk * 16);
+  }
+  // bias as the C input of the first MFMA of every output row: accumulator register r = channel (r & 3) + 8 (r >> 2) + 4 h.  NP = 1: in
+  // registers; NP = 2 (registers are short): an LDS image read back just before that MFMA
+  f32x16 biasv;
+  if constexpr (NP == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) biasv[r] = BIAS ? P.bias[co0 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+  }
+  const unsigned char* wl = smem_raw + WL_OFF + part * 18 * 1024 + lane * 16;          // + (tap * 2 + kk) * 1024
+  const float* bl = (const float*)(smem_raw + BL_OFF + part * 4096 + lane * 64);
+  if constexpr (NP == 2) {
+    // fragment f = tap * 2 + kk of plane 1; the four waves of a part share the work
+    const bf16_t* wr = P.w + (long)(co0 + n) * 9 * Cin + 32 + h * 8;
+    for (int f = wave & 3; f < 18; f += 4)
+      *(uint4*)(smem_raw + WL_OFF + part * 18 * 1024 + f * 1024 + lane * 16) = *(const uint4*)(wr + (f >> 1) * Cin + (f & 1) * 16);
+    if constexpr (BIAS) {
+      if ((wave & 3) == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) ((float*)(smem_raw + BL_OFF + part * 4096 + lane * 64))[r] = P.bias[co0 + (r & 3) + 8 * (r >> 2) + 4 * h];
+      }
+    }
+  }
+
+  if constexpr (NP == 2) __syncthreads();   // the weight / bias images
+
 
   // one input row trel: J = trel % 6 = its ring slot (static); EPI: the step completes an output row (trel >= 2); VMW: the vector-memory
   // operations this wave issued after its DMA pieces of row trel = what may still be in flight when the row is needed.  Steady state:
