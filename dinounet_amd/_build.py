@@ -19,7 +19,11 @@ NO_SCRATCH = ("gemm_bf16.hip", "gemm_glds.hip", "gemm_p8.hip", "gemm_skinny.hip"
 REMARK = "-Rpass-analysis=kernel-resource-usage"
 # timing-ablation and cycle-probe instantiations of the attention kernel (tools/attn_ablate.py) may spill: they never run in the product
 import re as _re
-_ABLATION = _re.compile(r"attn_fwd_w64_kernelILi\d+ELi\d+ELb\dELi\d+ELi[1-9]\d*ELi\d+ELb\dEEE|attn_fwd_w64_kernelILi\d+ELi\d+ELb1E|attn_fwd_w64_kernelILi\d+ELi\d+ELb\dELi\d+ELi\d+ELi\d+ELb1EEE|attn_fwd_pipe_kernelILb\dELi[1-9]\d*EEE")
+_ABLATION = _re.compile(
+    r"attn_fwd_kernelILi\d+ELb1EEE"                                            # round-3 kernel, ablation instantiation
+    r"|attn_fwd_w64_kernelILi\d+ELi\d+ELb1E"                                   # round-4 kernel with the cycle probe
+    r"|attn_fwd_w64_kernelILi\d+ELi\d+ELb\dELi\d+ELi[1-9]\d*ELi\d+EEE"         # ... with ablation bits (template <DH, NQB, PROBE, OCC, ABL, PRIO>)
+    r"|attn_fwd_pipe_kernelILb1ELi\d+EEE|attn_fwd_pipe_kernelILb\dELi[1-9]\d*EEE")  # slot-pipelined experiment: probe / ablation builds
 
 
 def _digest():

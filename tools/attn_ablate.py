@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""GPU tuning aid: where does a K/V tile of du_attention_fwd spend its time?  Times the kernel with pieces of the tile program switched
+"""GPU tuning aid (round 3 kernel): where does a K/V tile of du_attention_fwd spend its time?  (Any bit set in option 4 routes the launch
+to the round-3 kernel `attn_fwd_kernel` and its ablation instantiation; the round-4 product kernel's ablations are compile-time variants
+driven by tools/scratch/attn_abl.py / attn_abl2.py, summary in profiles/r04_attention_ablation_v1.txt.)  Times the kernel with pieces of the tile program switched
 off through du_set_option(4, bits) (results are wrong then; timing only) at three occupancies: one workgroup per CU, the dinounet_l
 step's grid, and a long sequence.
 Column 1 is the product kernel (4 workgroups / CU); every other column is the ablation instantiation (3 workgroups / CU: its
