@@ -265,18 +265,20 @@ __global__ __launch_bounds__(256 * NCO, (NP == 1 && NCO == 1) ? 2 : 1) void conv
       }
     };
 #define SB __builtin_amdgcn_sched_barrier(0)
-    bf16x8 bq[3], aq[2][2];                               // B fragments three deep; LDS weight fragments one slot ahead: [slot parity][N / M or O]
+    bf16x8 bq[3], aq[2][2];                               // B fragments three deep; LDS weight fragments two slots ahead: [slot parity][N / M or O]
     bq[0] = fr(SIC<0>{}); bq[1] = fr(SIC<1>{}); bq[2] = fr(SIC<2>{});
     SB;
     if constexpr (EPI) {
       // ---- phase A
       [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
         ([&] {
-          constexpr int i = I, pl = (i >> 1) % NP, pln = ((i + 1) >> 1) % NP;
+          constexpr int i = I, pl = (i >> 1) % NP;
           if constexpr (pl == 0) accO = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag(SIC<i>{}, SIC<2>{}), bq[i % 3], accO, 0, 0, 0);
           else accO = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[i & 1][0], bq[i % 3], accO, 0, 0, 0);
           bq[i % 3] = fr(SIC<i + 3>{});                   // wraps into phase B's first fragments
-          if constexpr (i + 1 < NF && pln == 1) aq[(i + 1) & 1][0] = wfrag(SIC<i + 1>{}, SIC<2>{});
+          // LDS weight fragments TWO slots ahead (a slot is one 32-cycle MFMA here, an LDS read takes ~130): the plane-0 slots of a dx
+          // fetch the plane-1 weights of the same dx
+          if constexpr (i + 2 < NF && pl == 0 && NP == 2) aq[i & 1][0] = wfrag(SIC<i + 2>{}, SIC<2>{});
           SB;
         }(), ...);
       }(std::make_integer_sequence<int, NF>{});
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256 * NCO, (NP == 1 && NCO == 1) ? 2 : 1) void conv
     }
     [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
       ([&] {
-        constexpr int i = I, pl = (i >> 1) % NP, pln = ((i + 1) >> 1) % NP;
+        constexpr int i = I, pl = (i >> 1) % NP;
         if constexpr (pl == 0) {
           accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag(SIC<i>{}, SIC<0>{}), bq[i % 3], i == 0 ? cin : accN, 0, 0, 0);
           accM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag(SIC<i>{}, SIC<1>{}), bq[i % 3], accM, 0, 0, 0);
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256 * NCO, (NP == 1 && NCO == 1) ? 2 : 1) void conv
           accM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[i & 1][1], bq[i % 3], accM, 0, 0, 0);
         }
         if constexpr (i + 3 < NF) bq[i % 3] = fr(SIC<i + 3>{});
-        if constexpr (i + 1 < NF && pln == 1) { aq[(i + 1) & 1][0] = wfrag(SIC<i + 1>{}, SIC<0>{}); aq[(i + 1) & 1][1] = wfrag(SIC<i + 1>{}, SIC<1>{}); }
+        if constexpr (i + 2 < NF && pl == 0 && NP == 2) { aq[i & 1][0] = wfrag(SIC<i + 2>{}, SIC<0>{}); aq[i & 1][1] = wfrag(SIC<i + 2>{}, SIC<1>{}); }
         // the completed row's epilogue, spread over slots 1 .. NF - 2
         if constexpr (NF == 6) {
           if constexpr (i == 1) { epi(SIC<0>{}); epi(SIC<1>{}); }
