@@ -492,6 +492,29 @@ def test_gemm_dispatch_host_logic_without_gpu():
     assert route(8232, 3072, 1024, dt=DU_F32, od=DU_F32)[0] == 0
 
 
+def test_conv3x3_kernel_choice_host_logic_without_gpu():
+    """Which 3x3 kernel serves a shape, and how many partial-statistics rows it writes (du_conv3x3_halo_parts: what the caller
+    allocates) -- pure host logic of csrc/conv_strip.hip / conv_halo.hip.  Strip kernel: Cin in {32, 64 (one tensor or a 32 + 32 concat)},
+    Cout in {32, 64}, W % 128 == 0, H % 8 == 0: one partial row per (image, row segment, 32-column strip); anything else: the LDS-tiled
+    kernel's 8 x 16 tiles.  du_conv3x3_strip declines (DU_ERR_UNSUPPORTED) without touching the device."""
+    from dinounet_amd import _lib
+    L = _lib.lib()
+    parts = lambda C1, Cin, Cout, B, H, W: int(L.du_conv3x3_halo_parts(C1, Cin, Cout, B, H, W))
+    # dinounet_l decoder at batch 8: 512^2 32 -> 32 in 16-row... segments chosen for >= 512 workgroups: 8 x (512 / 128) x (512 / 32) => RS = 32
+    assert parts(32, 32, 32, 8, 512, 512) == 8 * (512 // 32) * (512 // 32)
+    assert parts(32, 64, 32, 8, 512, 512) == 8 * (512 // 64) * (512 // 32)          # concat 32 + 32: one workgroup per CU wanted => RS = 64
+    assert parts(64, 64, 64, 8, 256, 256) == 8 * (256 // 16) * (256 // 32)          # 256 workgroups => RS = 16
+    assert parts(32, 32, 32, 1, 8, 128) == 1 * 1 * 4                                 # a single 8-row segment
+    assert parts(32, 32, 32, 2, 40, 384) == 2 * 4 * 12                               # 40 rows -> segments of 10
+    # not served by the strip kernel: 8 x 16 tiles of the LDS-tiled kernel
+    for C1, Cin, Cout, B, H, W in [(128, 128, 128, 8, 128, 128), (64, 128, 64, 8, 256, 256), (32, 32, 32, 2, 16, 48), (64, 64, 32, 2, 16, 32)]:
+        assert parts(C1, Cin, Cout, B, H, W) == B * (H // 8) * (W // 16)
+    assert parts(32, 32, 32, 1, 12, 128) == 0                                        # H % 8: neither kernel
+    import ctypes as C
+    args = (None, C.c_int64(128), None, C.c_int64(0), 128, 128, 128, 8, 128, 128, None, None, None, C.c_int64(128), None, None)
+    assert int(L.du_conv3x3_strip(*args)) == -2                                      # DU_ERR_UNSUPPORTED, before any pointer is looked at
+
+
 def test_bench_roofline_reads_pmc_summaries_only_for_matching_kernel_sources(monkeypatch):
     """roofline.traffic / roofline.pmc_cycles come from committed rocprofv3 PMC summaries (counters cannot be collected inside the timed
     process); each summary names the digest of the kernel sources it was measured on, and bench.py must ignore a summary taken on other
