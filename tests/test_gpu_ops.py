@@ -1455,3 +1455,23 @@ def test_augmentation_kernels_vs_numpy_restatement():
         assert torch.equal(o1, o2) and torch.equal(s1, s2)
         assert o1.shape == (B, Cc, H, W) and torch.isfinite(o1).all()
         assert set(s1.unique().tolist()) <= {0.0, 1.0, 2.0, 3.0}
+
+
+@pytest.mark.parametrize("Cin,Cout,off,wide", [(32, 32, 32, 96), (64, 64, 16, 96), (64, 32, 0, 72), (32, 64, 8, 40)])
+def test_conv3x3_strip_kernel_on_channel_slices_of_wider_tensors(Cin, Cout, off, wide):
+    """The strip kernel addresses its input through a pixel pitch (ldx) like every conv kernel here: a channel slice of a wider NHWC
+    tensor (FAPM's shared / specific halves, the decoder's concat halves) is read in place -- 16-byte aligned slices at pitches that are
+    no multiple of the slice width, one tensor feeding both 32-channel ring planes."""
+    from dinounet_amd import ops
+    d = dev()
+    dt = torch.bfloat16
+    B, H, W = 2, 24, 256
+    xw = q(gen(B, H, W, wide, seed=51), dt).to(d, dt)
+    x = xw[..., off:off + Cin]
+    assert not x.is_contiguous()
+    w = gen(Cout, Cin, 3, 3, seed=52, scale=0.1)
+    bias = gen(Cout, seed=53, scale=0.1)
+    y, part = ops.conv2d_stats(x, w.to(d), bias.to(d), 1, 1)
+    assert part is not None and part.shape[0] == int(__import__("dinounet_amd._lib", fromlist=["lib"]).lib().du_conv3x3_halo_parts(Cin, Cin, Cout, B, H, W))
+    yr = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), q(w, dt), bias, 1, 1).permute(0, 2, 3, 1)
+    assert rel(y, yr) < TOL[dt]
