@@ -425,14 +425,17 @@ __global__ __launch_bounds__(256) void msda_gv_rows_kernel(const int64_t* __rest
     rows[((long)b * M + m) * nblk + blk] = hi_s[m] < 0 ? 0xffffu : ((unsigned)lo_s[m] | ((unsigned)hi_s[m] << 16));
 }
 
-constexpr int GV_PT = 512;        // plane pixels per workgroup
+constexpr int GV_PT = 512;        // plane pixels per 1024-thread workgroup (32 per wave); the 512-thread form owns 256
 template <int N_> struct GvSlot { static constexpr int value = N_; };
 constexpr int GV_MAXBLK = 1024;   // query blocks per chunk the skip list holds (more: every block is walked)
 constexpr int GV_KQ = 32;         // queries per K step
 constexpr int GV_WLD = 128 + 8;   // W row pitch (bf16): 272 B, conflict-free ds_read_b128 fragments
 constexpr int GV_GLD = 128 + 8;
 
-__global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __restrict__ gout, const int64_t* __restrict__ shapes,
+// NT = 1024: 16 waves, 512 plane pixels, one workgroup per CU (139 KB of LDS).  NT = 512 (round 4): 8 waves, 256 pixels, 78 KB -- TWO
+// workgroups per CU, so one's barrier-paced steps run under the other's, and a 256-pixel tile is reached by fewer query blocks.
+template <int NT>
+__global__ __launch_bounds__(NT) void msda_gv_mfma_kernel(const bf16_t* __restrict__ gout, const int64_t* __restrict__ shapes,
                                                             const float* __restrict__ loc, const float* __restrict__ attn,
                                                             float* __restrict__ gvalue, int N, int S, int M, int D, int Lq,
                                                             int q_per_chunk, int tiles, long chunk_stride, int out_bf16,
@@ -441,8 +444,10 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
   __shared__ unsigned step_mask[3];
   __shared__ unsigned short need[GV_MAXBLK];
   __shared__ int wave_cnt[16];
+  constexpr int PT = NT / 2;                            // plane pixels of this workgroup: 32 per wave
+  constexpr int GQ = 1024 / NT;                         // grad_out elements per thread and step (32 queries x 32 channels)
   bf16_t* Wl = (bf16_t*)smem_raw;                       // [GV_PT][GV_WLD]
-  bf16_t* Gt = Wl + GV_PT * GV_WLD;                     // [32 channels][GV_GLD]   (G^T: k contiguous)
+  bf16_t* Gt = Wl + PT * GV_WLD;                     // [32 channels][GV_GLD]   (G^T: k contiguous)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Hs = (int)shapes[0], Ws = (int)shapes[1];   // single level
   // XCD-aware order (workgroup y lands on XCD y % 8 for the usual one-chunk grid): the loc / attn / grad_out rows of a query hold
@@ -456,29 +461,29 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
     bm = bb * M + hp / tiles; ptile = hp % tiles;
   }
   const int b = bm / M, m = bm % M;
-  const int pix0 = ptile * GV_PT;
+  const int pix0 = ptile * PT;
   const int q0 = blockIdx.x * q_per_chunk;
   const int q1 = min(Lq, q0 + q_per_chunk);
-  for (int i = tid; i < (GV_PT * GV_WLD + 32 * GV_GLD) / 8; i += 1024) ((uint4*)Wl)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < (PT * GV_WLD + 32 * GV_GLD) / 8; i += NT) ((uint4*)Wl)[i] = make_uint4(0, 0, 0, 0);
   if (tid < 3) step_mask[tid] = 0u;
   // ---- ordered list of the query blocks of this chunk whose rows meet this tile (thread t = block t of the chunk) ----
   const int nblk = (q1 - q0 + GV_KQ - 1) / GV_KQ;
-  const bool listed = rows != nullptr && nblk <= GV_MAXBLK;
+  const bool listed = rows != nullptr && nblk <= (GV_MAXBLK < NT ? GV_MAXBLK : NT);
   int nneed = nblk;
   if (listed) {
     bool want = false;
     if (tid < nblk) {
       const unsigned r = rows[((long)b * M + m) * nblk_all + q0 / GV_KQ + tid];
       const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
-      // pixels the block can touch: [lo * Ws, hi * Ws + Ws - 1]; this tile: [pix0, pix0 + GV_PT - 1]
-      want = lo != 0xffff && lo * Ws <= pix0 + GV_PT - 1 && hi * Ws + Ws - 1 >= pix0;
+      // pixels the block can touch: [lo * Ws, hi * Ws + Ws - 1]; this tile: [pix0, pix0 + PT - 1]
+      want = lo != 0xffff && lo * Ws <= pix0 + PT - 1 && hi * Ws + Ws - 1 >= pix0;
     }
     const unsigned long long bal = __ballot(want);
     if (lane == 0) wave_cnt[wave] = __popcll(bal);
     __syncthreads();
     int base = 0, total = 0;
 #pragma unroll
-    for (int w2 = 0; w2 < 16; w2++) { const int c2 = wave_cnt[w2]; if (w2 < wave) base += c2; total += c2; }
+    for (int w2 = 0; w2 < NT / 64; w2++) { const int c2 = wave_cnt[w2]; if (w2 < wave) base += c2; total += c2; }
     if (want) need[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)tid;
     nneed = total;
   }
@@ -492,14 +497,18 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
   // scatter role (threads 0..511): column col = (query ql, point p), one bilinear corner each
   const int col = tid >> 2, corner = tid & 3;
   const int ql_s = col >> 2, p_s = col & 3;
-  // G role (all threads): query ql_g, channel c_g
+  // G role (all threads): queries ql_g + (NT / 32) j, j < GQ, channel c_g
   const int ql_g = tid >> 5, c_g = tid & 31;
   int my_off = -1;
   // the per-step operands (sampling location, attention weight, grad_out element) are fetched THREE steps ahead into a ring of three
   // register sets (round 3: a step is ~1 us, about one L2 / HBM latency -- with one step of prefetch every step began by waiting for its
   // own operands).  The step body exists three times, one per set, so set indices are static and the compiler's vmcnt stays counted.
   float lx_r[3] = {0.f, 0.f, 0.f}, ly_r[3] = {0.f, 0.f, 0.f}, a_r[3] = {0.f, 0.f, 0.f};
-  bf16_t g_r[3] = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+  bf16_t g_r[3][GQ];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < GQ; j++) g_r[i][j] = (bf16_t)0.f;
   // every thread issues the same three loads in every fetch (clamped addresses; validity is applied when the values are used): with
   // loads under divergent or wave-dependent conditions the number of younger loads differs by path and the compiler falls back to
   // s_waitcnt vmcnt(0) in front of every use -- which drains the ring
@@ -510,8 +519,11 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
     const float2 l2 = *(const float2*)(loc + (pr * 4 + p_s) * 2);
     lx_r[SL] = l2.x; ly_r[SL] = l2.y;
     a_r[SL] = attn[pr * 4 + p_s];
-    const int qg = min(qs + ql_g, Lq - 1);
-    g_r[SL] = gout[(((long)b * Lq + qg) * M + m) * D + min(c_g, D - 1)];
+#pragma unroll
+    for (int j = 0; j < GQ; j++) {
+      const int qg = min(qs + ql_g + (NT / 32) * j, Lq - 1);
+      g_r[SL][j] = gout[(((long)b * Lq + qg) * M + m) * D + min(c_g, D - 1)];
+    }
   };
   auto block_q_or_end = [&](int i) { return i < nneed ? block_q(i) : q1; };
   fetch(GvSlot<0>{}, block_q_or_end(0));
@@ -521,9 +533,11 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
   auto do_step = [&](auto slot, int step) {
     constexpr int par = decltype(slot)::value;
     const int qs = block_q(step);
-    const bool ok_s = qs + ql_s < q1, ok_g = qs + ql_g < q1 && c_g < D;
+    const bool ok_s = qs + ql_s < q1;
     const float lx = ok_s ? lx_r[par] : -4.f, ly = ok_s ? ly_r[par] : -4.f, a = ok_s ? a_r[par] : 0.f;
-    const bf16_t gval = ok_g ? g_r[par] : (bf16_t)0.f;
+    bf16_t gval[GQ];
+#pragma unroll
+    for (int j = 0; j < GQ; j++) gval[j] = (qs + ql_g + (NT / 32) * j < q1 && c_g < D) ? g_r[par][j] : (bf16_t)0.f;
     fetch(slot, block_q_or_end(step + 3));
     if (tid < 512) {                                   // waves 0..7 (wave-uniform)
       float wv = 0.f; int woff = -1; unsigned blk = 0u;
@@ -534,7 +548,7 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
         const int hy = h0 + (corner >> 1), wx = w0 + (corner & 1);
         if (hy >= 0 && hy < Hs && wx >= 0 && wx < Ws) {
           const int pl = hy * Ws + wx - pix0;
-          if (pl >= 0 && pl < GV_PT) {
+          if (pl >= 0 && pl < PT) {
             wv = ((corner >> 1) ? lh : 1.f - lh) * ((corner & 1) ? lw : 1.f - lw) * a;
             woff = pl * GV_WLD + col;
             blk = 1u << (pl >> 5);
@@ -554,9 +568,10 @@ __global__ __launch_bounds__(1024) void msda_gv_mfma_kernel(const bf16_t* __rest
                        __builtin_amdgcn_readlane((int)blk, 32) | __builtin_amdgcn_readlane((int)blk, 48));
       if (lane == 0 && blk) atomicOr(&step_mask[par], blk);
     }
-    {
-      bf16x4 g4; g4[0] = gval; g4[1] = gval; g4[2] = gval; g4[3] = gval;
-      *(bf16x4*)(Gt + c_g * GV_GLD + ql_g * 4) = g4;
+#pragma unroll
+    for (int j = 0; j < GQ; j++) {
+      bf16x4 g4; g4[0] = gval[j]; g4[1] = gval[j]; g4[2] = gval[j]; g4[3] = gval[j];
+      *(bf16x4*)(Gt + c_g * GV_GLD + (ql_g + (NT / 32) * j) * 4) = g4;
     }
     __syncthreads();
     const unsigned touched = step_mask[par];           // block-uniform
@@ -985,6 +1000,11 @@ static int plane_chunks(int N, int M, int Lq) {
 }
 
 int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+// threads per workgroup of the MFMA grad_value kernel: 512 (256-pixel tiles, two workgroups per CU) unless DU_MSDA_GV_THREADS=1024
+static int gv_threads() {
+  static const int nt = (getenv("DU_MSDA_GV_THREADS") && atoi(getenv("DU_MSDA_GV_THREADS")) == 1024) ? 1024 : 512;
+  return nt;
+}
 
 // the round-3 fast kernels serve: bf16, 4 points, D / 8 in {4, 8, 16}, value < 2 GB (32-bit byte offsets), < 2^24 pixels and row bytes
 static bool q8_serves(int N, int S, int M, int D, int P) {
@@ -1082,8 +1102,11 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
                          (const T*)gout, gv, gl, ga, N, S, M, D, L, Lq, P, LPP, npairs);
       // (2) grad_value on the MFMA pipe
       {
-        const int tiles = (S + GV_PT - 1) / GV_PT;
-        int nchunk = (int)((256 + (long)N * M * tiles - 1) / ((long)N * M * tiles));
+        const int NT = gv_threads();
+        const int PT = NT / 2;
+        const int tiles = (S + PT - 1) / PT;
+        const int want_wgs = NT == 512 ? 512 : 256;                // two resident workgroups per CU in the 512-thread form
+        int nchunk = (int)((want_wgs + (long)N * M * tiles - 1) / ((long)N * M * tiles));
         if (nchunk < 1) nchunk = 1;
         if (nchunk > 16) nchunk = 16;
         int qpc = (Lq + nchunk - 1) / nchunk;
@@ -1095,12 +1118,9 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
           if (ws && ws_elems >= (long)nchunk * plane_all && plane_all % 4 == 0) { dstp = ws; cstride = plane_all; }
           else { nchunk = 1; qpc = ((Lq + GV_KQ - 1) / GV_KQ) * GV_KQ; }
         }
-        const int lds_bytes = (GV_PT * GV_WLD + 32 * GV_GLD) * 2;
-        static bool attr_set = false;
-        if (!attr_set) {
-          if (hipFuncSetAttribute((const void*)msda_gv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return DU_ERR_LAUNCH;
-          attr_set = true;
-        }
+        const int lds_bytes = (PT * GV_WLD + 32 * GV_GLD) * 2;
+        if (hipFuncSetAttribute(NT == 512 ? (const void*)msda_gv_mfma_kernel<512> : (const void*)msda_gv_mfma_kernel<1024>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return DU_ERR_LAUNCH;
         // rows table of the query blocks (behind the chunk partials in the workspace); without room for it every block is walked
         const int nblk_all = (Lq + GV_KQ - 1) / GV_KQ;
         const long tab_off = nchunk > 1 ? (long)nchunk * plane_all : 0, tab_n = (long)N * M * nblk_all;
@@ -1108,8 +1128,12 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
         unsigned* rows = (!no_skip && M <= 64 && ws && ws_elems >= tab_off + tab_n) ? (unsigned*)(ws + tab_off) : nullptr;
         if (rows)
           hipLaunchKernelGGL(msda_gv_rows_kernel, dim3((unsigned)(N * nblk_all)), dim3(256), 0, st, shapes, loc, rows, N, M, Lq, nblk_all);
-        hipLaunchKernelGGL(msda_gv_mfma_kernel, dim3(nchunk, N * M * tiles), dim3(1024), lds_bytes, st, (const bf16_t*)gout, shapes, loc, attn,
-                           dstp, N, S, M, D, Lq, qpc, tiles, cstride, (gv_bf16 && nchunk == 1) ? 1 : 0, (const unsigned*)rows, nblk_all);
+        if (NT == 512)
+          hipLaunchKernelGGL(msda_gv_mfma_kernel<512>, dim3(nchunk, N * M * tiles), dim3(512), lds_bytes, st, (const bf16_t*)gout, shapes, loc, attn,
+                             dstp, N, S, M, D, Lq, qpc, tiles, cstride, (gv_bf16 && nchunk == 1) ? 1 : 0, (const unsigned*)rows, nblk_all);
+        else
+          hipLaunchKernelGGL(msda_gv_mfma_kernel<1024>, dim3(nchunk, N * M * tiles), dim3(1024), lds_bytes, st, (const bf16_t*)gout, shapes, loc, attn,
+                             dstp, N, S, M, D, Lq, qpc, tiles, cstride, (gv_bf16 && nchunk == 1) ? 1 : 0, (const unsigned*)rows, nblk_all);
         if (nchunk > 1) {
           const long n4 = plane_all / 4;
           long g = (n4 + 255) / 256; if (g > 4096) g = 4096;
@@ -1296,8 +1320,9 @@ extern "C" int64_t du_msda_bwd_ws_elems(int N, int S, int M, int D, int L, int L
   int nchunk = 1, qpc;
   if ((size_t)S * D * sizeof(float) <= 144 * 1024) lds_chunking(N, M, Lq, LPP, &nchunk, &qpc);
   // MFMA grad_value path (bf16, single level, 4 points): query chunks so that ~256 workgroups exist
-  const int tiles = (S + GV_PT - 1) / GV_PT;
-  int nc2 = (int)((256 + (long)N * M * tiles - 1) / ((long)N * M * tiles));
+  const int PT = gv_threads() / 2;
+  const int tiles = (S + PT - 1) / PT;
+  int nc2 = (int)(((gv_threads() == 512 ? 512 : 256) + (long)N * M * tiles - 1) / ((long)N * M * tiles));
   if (nc2 > 16) nc2 = 16;
   if (nc2 > nchunk) nchunk = nc2;
   return (nchunk > 1 ? (int64_t)nchunk * N * S * M * D : 0) + tab;
