@@ -100,7 +100,7 @@ def render(data, used, n_inst, path):
                 "# conflict = LDS_BANK_CONFLICT / LDS_IDX_ACTIVE (extra cycles per LDS-array cycle)\n")
         f.write(f"# {'launches':>8} {'gui_active':>11} {'parked':>6} {'stall':>6} {'lds':>6} {'issue':>6} | {'mfma':>6} {'valu':>6} {'ldsi':>6} "
                 f"{'vmem':>6} | {'conflict':>8}  kernel\n")
-        for _, name, n, d, wc, gui in rows[:40]:
+        for _, name, n, d, wc, gui in rows[:80]:
             den = gui * simd if gui else None
 
             def duty(k, mul):
@@ -111,7 +111,7 @@ def render(data, used, n_inst, path):
                     f"{duty('SQ_VALU_MFMA_BUSY_CYCLES', 1)} {duty('SQ_ACTIVE_INST_VALU', 4)} {duty('SQ_ACTIVE_INST_LDS', 4)} "
                     f"{duty('SQ_ACTIVE_INST_VMEM', 4)} | {ratio(g(d, 'SQ_LDS_BANK_CONFLICT'), g(d, 'SQ_LDS_IDX_ACTIVE')):>8}  {short(name)}\n")
         f.write("\n# raw means per counter instance\n")
-        for _, name, n, d, wc, gui in rows[:40]:
+        for _, name, n, d, wc, gui in rows[:80]:
             f.write(f"{short(name)}\n")
             for cn in sorted(d):
                 f.write(f"    {cn:28s} {d[cn][1]:16.1f}   ({d[cn][0]} rows)\n")
