@@ -27,7 +27,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: dense
 HBM_PEAK_GBS = 8000.0
 MFMA_BF16_MEASURED_TFLOPS = 2382.0   # same guide: micro-benchmark ceiling of v_mfma_f32_32x32x16_bf16
 HBM_MEASURED_GBS = 6290.0            # same guide: float4 copy
-PMC_ROUNDS = ("r04", "r03", "r02")           # profiles/<round>_pmc_*: counter summaries, newest first; only one measured on the built kernel sources is used
+PMC_ROUNDS = ("r05", "r04", "r03", "r02")           # profiles/<round>_pmc_*: counter summaries, newest first; only one measured on the built kernel sources is used
 
 
 def _pmc_file(stem):
@@ -129,6 +129,7 @@ def main():
             ts.comm_events = []
             reducer.timeline = []
             step_ev = []
+            ops.SMALL_COLLECTIVES = []       # SyncBN / Dice all-reduces of these eager steps, bracketed by compute-stream events
         for _ in range(2):
             if reducer is not None:
                 e = torch.cuda.Event(enable_timing=True); e.record(); step_ev.append(e)
@@ -151,18 +152,33 @@ def main():
         step_end = None
         if ts.comm_events:
             step_end = round(step_ev[-1].elapsed_time(ts.comm_events[-1][1]), 3)
+        small = ops.SMALL_COLLECTIVES or []
+        ops.SMALL_COLLECTIVES = None
+        small_cnt, small_ms = {}, 0.0
+        for what, e0, e1 in small:
+            small_cnt[what] = small_cnt.get(what, 0) + 1
+            small_ms += e0.elapsed_time(e1)
         comm = {"gradient_buckets_elems": nb, "gradient_bytes_per_step": 4 * sum(nb), "gradient_allreduces_per_step": len(nb),
-                "small_collectives_per_step": {"syncbn_fwd": 7, "syncbn_bwd": 7, "dice_sums": 1} if world > 1 else {},
+                # measured on the 2 eager steps: how many latency-bound all-reduces (SyncBatchNorm statistics, batch-Dice sums) a step issues
+                # and how long the compute stream spends in them (they sit on the critical path; absent at world size 1)
+                "small_collectives_per_step": {k: v // 2 for k, v in small_cnt.items()},
+                "small_collectives_ms_per_step": round(small_ms / 2, 3) if small else None,
                 "exposed_after_backward_ms": round(sum(exposed) / max(len(exposed), 1), 3) if exposed else None,
                 "bucket_timeline": tl, "gradients_installed_ms": step_end,
                 "note": "eager steps; reducer.finish() = wait for the side-stream all-reduces + divide by world size; timeline in ms from the "
-                        "start of the last eager step (compute-stream events for `ready`, side-stream events for the all-reduce)"}
+                        "start of the last eager step (compute-stream events for `ready`; `allreduce_done_ms` is recorded on the side stream "
+                        "BEHIND Work.wait(), i.e. after the collective itself has finished on RCCL's stream)"}
         ts.comm_events = None
         reducer.timeline = None
     if world > 1:
         t = torch.tensor([dt], device=dev)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_ms = [round(float(v.item()) / a.steps * 1e3, 3) for v in every]      # spread of the ranks' own clocks around the same K steps
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if comm is not None:
+            comm["ms_per_step_by_rank"] = per_rank_ms
     ms = dt / a.steps * 1e3
     value = a.batch * world / (dt / a.steps)
 
@@ -183,7 +199,8 @@ def main():
                 out["roofline"], out["kernel_breakdown"] = prof.roofline(MFMA_BF16_PEAK_TFLOPS, HBM_PEAK_GBS, 2)
                 r = out["roofline"]
                 r["timing"] = ("HIP events around EAGER launches of the same step (a kernel cannot be timed alone inside the replayed graph); the "
-                               "rocprofv3 kernel trace of the replayed graph (profiles/) shows the same kernels ~15-20 % faster: frac is pessimistic")
+                               "rocprofv3 kernel trace of the replayed graph is committed under profiles/ (steady-state table): for the GEMM "
+                               "kernels eager and replayed durations agree to ~1 %")
                 r["targets"] = north_star_targets(prof, 2)
                 meas = MFMA_BF16_MEASURED_TFLOPS if r.get("bound") == "mfma" else HBM_MEASURED_GBS
                 r["measured_peak"] = meas                      # what a micro-benchmark reaches on this chip (same unit as peak)
@@ -229,12 +246,28 @@ def north_star_targets(prof, steps=1):
     if "attn_fwd_kernel" in agg and agg["attn_fwd_kernel"][0] > 0:
         t, fl, _ = agg["attn_fwd_kernel"]
         out["attention_mfma_frac"] = {"measured": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "target": 0.40, "kernel": "attn_fwd_kernel"}
-    if "conv3x3_halo_kernel" in agg and agg["conv3x3_halo_kernel"][0] > 0:        # 3x3 convolutions with <= 64 output channels (512^2, 256^2)
-        t, _, nb = agg["conv3x3_halo_kernel"]
+    # decoder 3x3 convolutions, named by the kernel that ran: strip = streaming kernel (32 / 64 channels, W % 128 == 0), halo = LDS-tiled
+    # kernel (64 + 64 concat and whatever the strip kernel declines), c128 = LDS-tiled kernel with 128 output channels (above the ridge:
+    # reported against the MFMA roof).  `decoder_conv_hbm_frac` keeps its round-4 meaning (all layers with <= 64 output channels, both
+    # kernels); `decoder_conv_all_hbm_frac` is the round 1-3 / BASELINE definition (EVERY decoder 3x3 convolution, 128-channel ones included).
+    fam = {k: agg[k] for k in ("conv3x3_strip_kernel", "conv3x3_halo_kernel", "conv3x3_halo_c128_kernel") if k in agg and agg[k][0] > 0}
+    le64 = [fam[k] for k in ("conv3x3_strip_kernel", "conv3x3_halo_kernel") if k in fam]
+    if le64:
+        t, nb = sum(v[0] for v in le64), sum(v[2] for v in le64)
         out["decoder_conv_hbm_frac"] = {"measured": round(nb / t / 1e9 / HBM_PEAK_GBS, 4), "target": 0.60,
-                                        "kernel": "conv3x3_strip_kernel / conv3x3_halo_kernel, Cout <= 64", "ms_per_step": round(t * 1e3 / steps, 3)}
-    if "conv3x3_halo_c128_kernel" in agg and agg["conv3x3_halo_c128_kernel"][0] > 0:   # 128 output channels: above the ridge -> MFMA roof
-        t, fl, _ = agg["conv3x3_halo_c128_kernel"]
+                                        "kernel": "conv3x3_strip_kernel + conv3x3_halo_kernel, Cout <= 64", "ms_per_step": round(t * 1e3 / steps, 3)}
+        for k, label in (("conv3x3_strip_kernel", "decoder_conv_strip_hbm_frac"), ("conv3x3_halo_kernel", "decoder_conv_halo_hbm_frac")):
+            if k in fam:
+                t1, _, nb1 = fam[k]
+                out[label] = {"measured": round(nb1 / t1 / 1e9 / HBM_PEAK_GBS, 4), "target": 0.60, "kernel": k + ", Cout <= 64",
+                              "ms_per_step": round(t1 * 1e3 / steps, 3)}
+    if fam:
+        t, nb = sum(v[0] for v in fam.values()), sum(v[2] for v in fam.values())
+        out["decoder_conv_all_hbm_frac"] = {"measured": round(nb / t / 1e9 / HBM_PEAK_GBS, 4), "target": 0.60,
+                                            "kernel": "every 3x3 stride-1 convolution of the step (rounds 1-3 definition: 128-channel layers included)",
+                                            "ms_per_step": round(t * 1e3 / steps, 3)}
+    if "conv3x3_halo_c128_kernel" in fam:   # 128 output channels: above the ridge -> MFMA roof
+        t, fl, _ = fam["conv3x3_halo_c128_kernel"]
         out["decoder_conv_mfma_frac"] = {"measured": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "target": 0.35,
                                          "kernel": "conv3x3_halo_kernel, Cout = 128", "ms_per_step": round(t * 1e3 / steps, 3)}
     for key, name, tgt in (("msda_fwd", "msda_fwd_hbm_frac", 0.35), ("msda_bwd", "msda_bwd_hbm_frac", 0.25)):

@@ -325,6 +325,11 @@ extern "C" int du_conv3x3_halo(const void* x, int64_t ldx, const void* x2, int64
   {                // streaming strip kernel (conv_strip.hip) where it serves the shape
     const int rc = du_conv3x3_strip(x, ldx, x2, ldx2, C1, Cin, Cout, B, H, W, w, bias, y, ldy, stats_part, stream);
     if (rc != DU_ERR_UNSUPPORTED) return rc;
+    // The caller sized stats_part with du_conv3x3_halo_parts(), which knows the channel counts and the image but not the strides / byte
+    // sizes the strip kernel also declines on (a per-image input >= 1 GiB, an output >= 2 GiB).  When the strip kernel was the planned
+    // one, the tile kernel below would write B * (H / 8) * (W / 16) partial rows into a buffer of B * (H / rs) * (W / 32) and the
+    // finalize step would run with the wrong count: decline instead (the caller retries without epilogue statistics).
+    if (stats_part && du_conv3x3_halo_parts(C1, Cin, Cout, B, H, W) != B * (H / TH) * (W / TW)) return DU_ERR_UNSUPPORTED;
   }
   HaloParams P{};
   P.x = (const bf16_t*)x; P.ldx = ldx; P.x2 = (const bf16_t*)x2; P.ldx2 = ldx2; P.C1 = C1; P.Cin = Cin; P.Cout = Cout;

@@ -1431,6 +1431,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_p4_kernel(GemmParams P) {
 
 int g_p8_mode = -1;      // -1: heuristic, 0: off, 1: 256 x 256 wherever legal, 2: 256 x 128 wherever legal, 3: the 4-wave 256 x 128 kernel wherever legal
 int g_p8_sched = 1;
+int g_p8_corun = 1;      // du_set_option key 9: independent products the caller keeps in flight on different streams (the frozen ViT run as
+                         // two half-batch chains): the tile choice then counts rounds on 256 / corun CUs -- a product that fills half the chip
+                         // alone is a full round beside its twin
 int g_p8_group = 4;
 int g_p8_debug = 0;      // bit 0: skip the bf16 global stores, bit 1: skip the whole epilogue (timing ablations only)
 
@@ -1518,6 +1521,7 @@ extern "C" int du_set_option(int key, int value) {
     case 2: g_p8_group = value; return DU_OK;
     case 3: g_p8_debug = value; return DU_OK;
     case 5: g_p8_tn = value; return DU_OK;
+    case 9: g_p8_corun = value < 1 ? 1 : (value > 8 ? 8 : value); return DU_OK;
     default: return DU_ERR_BAD_ARG;
   }
 }
@@ -1573,13 +1577,14 @@ int du_gemm_p8_choice(const du_gemm_args& a) {
   const long batch = a.batch < 1 ? 1 : a.batch;
   const long tm = (a.M + 255) / 256;
   const long t256 = tm * ((a.N + 255) / 256) * batch, t128 = tm * ((a.N + 127) / 128) * batch;
-  if (t128 < 192) return 0;
+  const long cus = 256 / g_p8_corun;           // CUs this product can count on (co-running products share the chip)
+  if (t128 * g_p8_corun < 192) return 0;
   // (round 4: at K = 1024 the narrow tile's fixed costs -- prologue, exposed epilogue -- weigh more: 3 rounds of 256 x 128 tiles cost 62.8-67.6 us
   //  against 62.8-63.5 us for 2 rounds of 256 x 256 on the 8192 / 8232 x 3072 qkv product, ratio 0.66-0.72 per round, not 0.56)
-  const double c256 = (double)((t256 + 255) / 256) * 1.0, c128 = (double)((t128 + 255) / 256) * (a.K >= 1024 ? 0.68 : 0.56);
+  const double c256 = (double)((t256 + cus - 1) / cus) * 1.0, c128 = (double)((t128 + cus - 1) / cus) * (a.K >= 1024 ? 0.68 : 0.56);
   // (>= 128 tiles since round 3: the tall products of the adapter with ONE 256-wide tile column -- 43008 x {192, 256} x 1024 -- read their A
   //  operand once with the 256 x 256 tile and twice with two half-empty 128-wide columns: 31.8 / 32.6 us against 34.7 / 37.3 us)
-  if (t256 >= 128 && c256 <= c128) return 1;
+  if (t256 * g_p8_corun >= 128 && c256 <= c128) return 1;
   return 2;
 }
 bool du_gemm_p8_wants(const du_gemm_args& a) { return du_gemm_p8_choice(a) != 0; }

@@ -354,12 +354,16 @@ class DINOv3_Adapter(nn.Module):
                     tbl.div_(keep)
                 for i, m in enumerate(dps):
                     m.predrawn = tbl[i]
+        # The frozen backbone is launched FIRST (ADP:422-426): with `backbone.chains` > 1 it runs as half-batch chains on side streams and the
+        # spatial prior module below -- independent of it (ADP:412-415), HBM-bound where the ViT is MFMA-bound -- runs beside them on this
+        # stream; `vit()` joins the chains.  (chains <= 1: the backbone simply runs before the prior module; same results either way.)
+        vit = self.backbone.begin_intermediate_layers(x, n=self.interaction_indexes, return_class_token=True, dtype=dt)
         x8 = ops.nchw_to_nhwc(x, dt, 8)
         c1, c2, c3, c4 = self.spm(x8, self.level_embed, group)                              # ADP:412-413
         n2, n3 = c2.shape[1], c3.shape[1]
         c = torch.cat([c2, c3, c4], dim=1)                                                   # ADP:415
 
-        layers = self.backbone.get_intermediate_layers(x, n=self.interaction_indexes, return_class_token=True, dtype=dt)   # ADP:422-426
+        layers = vit()
 
         for i, layer in enumerate(self.interactions):                                       # ADP:444-457
             xi, _cls = layers[i]

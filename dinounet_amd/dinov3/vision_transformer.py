@@ -14,6 +14,7 @@ the arithmetic runs in libdinounet_hip.so:
 The residual stream stays fp32 in HBM, GEMM inputs are bf16 (fp32 in parity mode), accumulation fp32.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -175,6 +176,14 @@ class DinoVisionTransformer(nn.Module):
         self.mask_token = nn.Parameter(torch.empty(1, embed_dim))
         self._cache = None
         self._ws = {}
+        # Two half-batch chains on two side HIP streams (round 5).  The blocks of a frozen ViT are a strictly sequential chain of
+        # launches, each with one workgroup per CU (128-147 KB of LDS): every launch boundary drains the chip -- cold prologue burst of 256
+        # workgroups at once, a ragged last round (qkv: 1.5 rounds of 256 x 256 tiles), an exposed epilogue.  The samples of a batch are
+        # independent, so the same work as TWO chains lets the dispatcher fill the CUs one chain leaves idle with the other chain's
+        # workgroups; nothing else changes (same kernels, same arithmetic per sample).  0 / 1 = one chain on the caller's stream.
+        self.chains = int(os.environ.get("DINOUNET_VIT_CHAINS", "2"))
+        self._chain_streams = {}
+        self._chain_ws = {}
         self.init_weights()
 
     def init_weights(self):
@@ -237,6 +246,13 @@ class DinoVisionTransformer(nn.Module):
     def get_intermediate_layers(self, x, *, n, return_class_token=True, dtype=torch.bfloat16, norm=True):
         """x: (B, 3, H, W) fp32 NCHW on the GPU.  Returns [(patch tokens (B, h*w, D) in `dtype`, cls (B, D))] for the
         block indices in `n` (vision_transformer.py:265-318)."""
+        return self.begin_intermediate_layers(x, n=n, return_class_token=return_class_token, dtype=dtype, norm=norm)()
+
+    @torch.no_grad()
+    def begin_intermediate_layers(self, x, *, n, return_class_token=True, dtype=torch.bfloat16, norm=True):
+        """get_intermediate_layers in two halves: this call LAUNCHES the backbone (with `chains` > 1: as half-batch chains on side streams,
+        forked from the caller's stream) and returns a function that joins the chains back into the caller's stream and returns the
+        outputs -- the caller (DINOv3_Adapter) runs its spatial prior module, which does not depend on the ViT (ADP:412-426), in between."""
         B, _, H, W = x.shape
         D, nh = self.embed_dim, self.num_heads
         dh = D // nh
@@ -249,19 +265,17 @@ class DinoVisionTransformer(nn.Module):
         xs[:, :npre] = pk["prefix"]
         tok = ops.mm(cols, pk["pe_w"], bias=pk["pe_b"], out_dtype=torch.float32)
         xs[:, npre:] = tok.view(B, hp * wp, D)
-        x2 = xs.view(B * N, D)
         take = list(n)
-        outs = []
         sin_all, cos_all = self.rope_embed.sincos_all(hp, wp, x.device, self.training, len(pk["blocks"]))   # vision_transformer.py:271-272
         sd = self.training and self.drop_path_rate > 0.0
         k_sub = max(int(B * (1 - self.drop_path_rate)), 1)                                 # layers/block.py:92-93
         if sd:
             alpha = torch.full((1,), B / k_sub, dtype=torch.float32, device=x.device)        # residual_scale_factor
 
-        def attn_branch(xr, Bs, i, d, scale):
+        def attn_branch(xr, Bs, i, d, scale, ws):
             """xr (Bs*N, D) fp32 += [scale *] ls1(attn(norm1(xr)))   in place (layers/block.py:189-193)"""
             h, _, _ = ops.layernorm_raw(xr, d["n1w"], d["n1b"], 1e-5, dtype)
-            a = ops.qkv_attention(h, d["qkv_w"], d["qkv_b"], sin_all[i], cos_all[i], Bs, N, nh, dh, npre, self._ws)
+            a = ops.qkv_attention(h, d["qkv_w"], d["qkv_b"], sin_all[i], cos_all[i], Bs, N, nh, dh, npre, ws)
             ops.mm(a, d["proj_w"], bias=d["proj_b"], gamma=d["g1"], residual=xr, out=xr, row_scale=scale, rs_rows=xr.shape[0] if scale is not None else 0)
 
         def ffn_branch(xr, d, scale):
@@ -274,33 +288,92 @@ class DinoVisionTransformer(nn.Module):
                 u = ops.mm_swiglu(h, d["w12"], d["b12"])
                 ops.mm(u, d["w3"], bias=d["b3"], gamma=d["g2"], residual=xr, out=xr, row_scale=scale, rs_rows=rs)
 
-        for i, d in enumerate(pk["blocks"]):
-            if not sd:
-                attn_branch(x2, B, i, d, None)
-                ffn_branch(x2, d, None)
-            else:
-                # batch-subset stochastic depth (layers/block.py:126-187): each branch runs on a random subset of k_sub samples and its
-                # residual is added back scaled by B / k_sub; the subset is gathered, updated in place and scattered back
+        # tap outputs: whole-batch buffers owned by the caller's stream, every chain writes its own samples' rows
+        taps = [torch.empty((B, N, D), dtype=dtype, device=x.device) for _ in take]
+
+        def run_chain(b0, b1, ws):
+            """samples [b0, b1) through all blocks on the current stream"""
+            Bs = b1 - b0
+            xc = xs[b0:b1].view(Bs * N, D)
+            t = 0
+            for i, d in enumerate(pk["blocks"]):
+                attn_branch(xc, Bs, i, d, None, ws)
+                ffn_branch(xc, d, None)
+                if i in take:
+                    o = taps[t][b0:b1].view(Bs * N, D)
+                    if norm:
+                        ops.layernorm_raw(xc, pk["norm_w"], pk["norm_b"], 1e-5, dtype, out=o)   # vision_transformer.py:300
+                    else:
+                        o.copy_(xc)
+                    t += 1
+            assert t == len(take), f"only {t} / {len(take)} blocks found"
+
+        nch = self.chains if (x.is_cuda and not sd and ops.PROFILE is None and self.chains > 1 and B >= 2 * self.chains
+                              and dtype == torch.bfloat16) else 1
+        pending = []
+        if sd:
+            # batch-subset stochastic depth (layers/block.py:126-187): each branch runs on a random subset of k_sub samples and its
+            # residual is added back scaled by B / k_sub; the subset is gathered, updated in place and scattered back.  One chain: the
+            # subsets mix the samples.
+            x2 = xs.view(B * N, D)
+            t = 0
+            for i, d in enumerate(pk["blocks"]):
                 if self.pinned_subsets is not None:
-                    i1, i2 = (t.to(x.device) for t in self.pinned_subsets[i])
+                    i1, i2 = (t_.to(x.device) for t_ in self.pinned_subsets[i])
                 else:
                     i1 = torch.randperm(B, device=x.device)[:k_sub]
                     i2 = torch.randperm(B, device=x.device)[:k_sub]
                 xsub = ops.sample_gather(xs, i1)
-                attn_branch(xsub.view(k_sub * N, D), k_sub, i, d, alpha)
+                attn_branch(xsub.view(k_sub * N, D), k_sub, i, d, alpha, self._ws)
                 ops.sample_scatter_(xs, xsub, i1)
                 xsub = ops.sample_gather(xs, i2)
                 ffn_branch(xsub.view(k_sub * N, D), d, alpha)
                 ops.sample_scatter_(xs, xsub, i2)
-            if i in take:
-                if norm:
-                    o, _, _ = ops.layernorm_raw(x2, pk["norm_w"], pk["norm_b"], 1e-5, dtype)   # vision_transformer.py:300
-                else:
-                    o = ops.cast(x2, dtype)
-                o = o.view(B, N, D)
-                outs.append((o[:, npre:].contiguous(), o[:, 0].contiguous()))
-        assert len(outs) == len(take), f"only {len(outs)} / {len(take)} blocks found"
-        return tuple(outs) if return_class_token else tuple(o for o, _ in outs)
+                if i in take:
+                    o = taps[t].view(B * N, D)
+                    if norm:
+                        ops.layernorm_raw(x2, pk["norm_w"], pk["norm_b"], 1e-5, dtype, out=o)   # vision_transformer.py:300
+                    else:
+                        o.copy_(x2)
+                    t += 1
+            assert t == len(take), f"only {t} / {len(take)} blocks found"
+        elif nch == 1:
+            run_chain(0, B, self._ws)
+        else:
+            main = torch.cuda.current_stream()
+            key = str(x.device)
+            if key not in self._chain_streams:
+                self._chain_streams[key] = [torch.cuda.Stream(device=x.device) for _ in range(8)]
+            per = (B + nch - 1) // nch
+            ops.set_corun(nch)                      # du_gemm's tile choice: each product shares the chip with nch - 1 twins
+            try:
+                for c in range(nch):
+                    b0, b1 = c * per, min(B, (c + 1) * per)
+                    if b0 >= b1:
+                        continue
+                    st = self._chain_streams[key][c]
+                    st.wait_stream(main)                # fork: the chain starts behind patch embedding / the RoPE tables
+                    with torch.cuda.stream(st):
+                        run_chain(b0, b1, self._chain_ws.setdefault((key, c), {}))
+                    pending.append(st)
+            finally:
+                ops.set_corun(1)
+
+        # everything the chains read or update that belongs to the caller's stream stays referenced until the join: freed earlier, the caching
+        # allocator would hand the blocks to the caller's next allocations (the spatial prior module) while the chains still use them
+        keep = [xs, sin_all, cos_all, cols, tok]
+
+        def join():
+            if pending:
+                cur = torch.cuda.current_stream()
+                for st in pending:
+                    cur.wait_stream(st)
+                pending.clear()
+            keep.clear()
+            outs = [(o[:, npre:].contiguous(), o[:, 0].contiguous()) for o in taps]
+            return tuple(outs) if return_class_token else tuple(o for o, _ in outs)
+
+        return join
 
 
 def build_backbone(model_name: str) -> DinoVisionTransformer:

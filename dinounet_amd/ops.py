@@ -112,6 +112,24 @@ class KernelProfile:
 
 
 PROFILE = None
+
+
+SMALL_COLLECTIVES = None     # bench.py (N > 1 / forced reducer): list -> every small all-reduce of an eager step is bracketed by HIP events
+
+
+def _small_all_reduce(t, group, what):
+    """the step's latency-bound collectives (SyncBatchNorm statistics forward / backward, the batch-Dice sums): <= 2 KB each, on the
+    critical path.  With SMALL_COLLECTIVES set (eager steps only) each one is bracketed by events on the compute stream so the bench
+    line can say what they cost at N ranks (VERDICT r4 next #6)."""
+    rec = SMALL_COLLECTIVES is not None and t.is_cuda and not torch.cuda.is_current_stream_capturing()
+    if rec:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    torch.distributed.all_reduce(t, group=group)
+    if rec:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        SMALL_COLLECTIVES.append((what, e0, e1))
 _MODE_NAMES = {(0, 0): "linear", (0, 1): "linear_dgrad", (1, 1): "linear_wgrad", (2, 0): "conv_im2col", (1, 3): "conv_wgrad"}
 
 
@@ -183,6 +201,11 @@ def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat,
                      2.0 * M * N * K * batch, float(batch) * (M * kin * es + N * K * es + M * N * eo))
         return
     _lib.check(_lib.lib().du_gemm(C.byref(a), _st()), "du_gemm")
+
+
+def set_corun(n):
+    """tell du_gemm's tile choice how many independent products the caller keeps in flight on different streams (du_set_option key 9)"""
+    _lib.check(_lib.lib().du_set_option(9, int(n)), "du_set_option(9)")
 
 
 def _dp(t):
@@ -554,14 +577,18 @@ class WgradQueue:
     def _arm(self):
         """make sure THIS backward pass ends with _end_of_pass().  Keyed on the engine's graph-task id, not on a flag: a pass that raised
         (out of memory, KeyboardInterrupt, a failed hipGraph capture) never runs its final callbacks -- a flag would stay set and every later
-        backward() would return with unfinished gradients.  Whatever such a dead pass left queued is dropped here (its tensors belong to a
-        pass nobody will finish; launching them later could write into freed capture-pool memory)."""
+        backward() would return with unfinished gradients.  A different task id while one is armed means either that the armed pass died
+        or that this is a NESTED pass (reentrant torch.utils.checkpoint, autograd.grad inside a hook or a custom Function) and the armed one
+        is suspended, alive, with its zero-filled buffers already handed to autograd: the two cannot be told apart from here,
+        so whatever is queued is LAUNCHED now, never dropped -- for a live outer pass that completes its gradients early, for a dead one it
+        is a wasted launch into buffers the queue itself keeps alive (dY / X in `keep`, results in the groups) and nobody reads."""
         tid = torch._C._current_graph_task_id()
         if tid == -1:                      # not inside a backward pass: nothing will call back
             return False
         if self._armed_task != tid:
             if self._armed_task is not None:
-                self._drop()
+                self._armed_task = None
+                self.flush()
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
             except RuntimeError:
@@ -863,12 +890,21 @@ def conv3x3_halo(x, wp, bias, x2=None, want_stats=False):
     part = torch.empty((nparts, Cout, 2), dtype=torch.float32, device=x.device) if want_stats else None
     e0 = PROFILE.start() if PROFILE is not None else None
     rc = _lib.lib().du_conv3x3_halo(_p(x), ld, p2, ld2, C1, Cin, Cout, B, H, W, _p(wp), _p(bias), _p(y), Cout, _p(part), _st())
+    if rc == -2 and part is not None:
+        # the kernel the partial-statistics buffer was sized for declined on the tensor's byte size: same convolution without
+        # epilogue statistics (the norm layer then runs its own statistics pass)
+        part = None
+        rc = _lib.lib().du_conv3x3_halo(_p(x), ld, p2, ld2, C1, Cin, Cout, B, H, W, _p(wp), _p(bias), _p(y), Cout, None, _st())
     if rc == -2:                                  # DU_ERR_UNSUPPORTED
         return None
     _lib.check(rc, "du_conv3x3_halo")
     if PROFILE is not None:
         # <= 64 output channels: HBM-bound layers (512^2 / 256^2); 128: above the ridge (bench.py reports them against the MFMA peak)
-        PROFILE.stop(("conv3x3_halo_kernel<bf16>" if Cout <= 64 else "conv3x3_halo_c128_kernel<bf16>") + (f" {H}x{W} {Cin}->{Cout}" if PROFILE.detail else ""), e0,
+        # named by the kernel that ran: the streaming strip kernel writes one partial row per (image, segment, strip),
+        # the LDS-tiled kernel one per 8 x 16 tile -- du_conv3x3_halo_parts tells them apart without mirroring the C-side choice
+        strip = int(_lib.lib().du_conv3x3_halo_parts(C1, Cin, Cout, B, H, W)) != B * (H // 8) * (W // 16)
+        kname = "conv3x3_strip_kernel<bf16>" if strip else ("conv3x3_halo_kernel<bf16>" if Cout <= 64 else "conv3x3_halo_c128_kernel<bf16>")
+        PROFILE.stop(kname + (f" {H}x{W} {Cin}->{Cout}" if PROFILE.detail else ""), e0,
                      2.0 * B * H * W * Cin * Cout * 9, 2.0 * B * H * W * (Cin + Cout))
     return y, part
 
@@ -1468,7 +1504,7 @@ class _NormAct(torch.autograd.Function):
                 else:
                     sums, P = chan_stats(x, G)
                 sums = sums.clone()
-                torch.distributed.all_reduce(sums, group=group)   # equal per-rank batch (TRN:322-327 splits evenly)
+                _small_all_reduce(sums, group, "syncbn_fwd")   # equal per-rank batch (TRN:322-327 splits evenly)
                 count = count * torch.distributed.get_world_size(group)
                 _lib.check(L.du_norm_stats_finalize(_p(sums), count, eps, _p(mean), _p(rstd), G, Cc, rm, rv, float(momentum), _st()),
                            "du_norm_stats_finalize")
@@ -1498,7 +1534,7 @@ class _NormAct(torch.autograd.Function):
         bsr = bs
         if kind == "bn" and use_batch and group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
             bsr = bs.clone()
-            torch.distributed.all_reduce(bsr, group=group)
+            _small_all_reduce(bsr, group, "syncbn_bwd")
         dx = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device)
         _lib.check(L.du_norm_act_bwd_dx(_code(x.dtype), _p(x), ld, _p(dy), Cc, _p(dx), Cc, _p(mean), _p(rstd), _p(wf), _p(bf),
                                         _p(bsr), G, P, Cc, act, float(count or 0.0), 1 if use_batch else 0, _st()),
@@ -1533,7 +1569,7 @@ class _SyncBNMulti(torch.autograd.Function):
             wsb, nws = _reduce_ws(x.dtype, 1, B * H * W, Cc, x.device)
             _lib.check(L.du_chan_stats(_code(x.dtype), _p(x), ld, C.c_void_p(flat.data_ptr() + 4 * o), 1, B * H * W, Cc, _p(wsb), nws, _st()),
                        "du_chan_stats")
-        torch.distributed.all_reduce(flat, group=group)
+        _small_all_reduce(flat, group, "syncbn_fwd")
         ys, saved = [], []
         for j, (x, (B, H, W, Cc, ld), o) in enumerate(zip(xs, geo, offs)):
             eps, rm, rv, mom = mods[j]
@@ -1571,7 +1607,7 @@ class _SyncBNMulti(torch.autograd.Function):
             db = torch.empty(Cc, dtype=torch.float32, device=dev)
             _lib.check(L.du_norm_param_grads(bsj, _p(dw), _p(db), 1, Cc, _st()), "du_norm_param_grads")    # local sums: DDP averages them
             dws.append(dw); dbs.append(db)
-        torch.distributed.all_reduce(flat, group=group)
+        _small_all_reduce(flat, group, "syncbn_bwd")
         dxs = []
         for j in range(n):
             x, mean, rstd, wf, bf = sv[5 * j:5 * j + 5]
@@ -1591,9 +1627,13 @@ def sync_bn_multi(xs, bns, act, group):
     return list(_SyncBNMulti.apply(group, act, n, *xs, *[bn.weight for bn in bns], *[bn.bias for bn in bns], mods))
 
 
-def layernorm_raw(x2d, w, b, eps, out_dtype, want_stats=False):
+def layernorm_raw(x2d, w, b, eps, out_dtype, want_stats=False, out=None):
     rows, D, ld = _rows2d(x2d)
-    y = torch.empty((rows, D), dtype=out_dtype, device=x2d.device)
+    if out is None:
+        y = torch.empty((rows, D), dtype=out_dtype, device=x2d.device)
+    else:                                    # caller-owned rows (the ViT's tap outputs, written by two half-batch chains)
+        y = out
+        assert y.shape == (rows, D) and y.dtype == out_dtype and y.is_contiguous()
     mean = rstd = None
     if want_stats:
         mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
@@ -2015,7 +2055,7 @@ class _DiceCE(torch.autograd.Function):
         _lib.check(L.du_dice_ce_sums(_p(logits), _p(tgt), _p(sums), B, K, HW, _p(ws), n, _st()), "du_dice_ce_sums")
         mult = 1.0
         if group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
-            torch.distributed.all_reduce(sums[1:], group=group)
+            _small_all_reduce(sums[1:], group, "dice_sums")
             mult = float(torch.distributed.get_world_size(group))
         loss = torch.empty(1, dtype=torch.float32, device=logits.device)
         coef = torch.empty(2 * (K - 1), dtype=torch.float32, device=logits.device)

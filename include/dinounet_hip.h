@@ -442,7 +442,9 @@ int du_device_ok(void); /* 1 if the current device is gfx950 */
    key 1: its pinned issue order on (1, default) / off (0);  key 2: its tile band height (default 4);
    key 3: epilogue ablations of those kernels (timing only);  key 4: attention tile-program ablation bits (0 = the product kernel; tools/attn_ablate.py);
    key 5: weight gradients (contraction-major operands, split-K) on the multi-phase kernel: 1 where it pays (default), 2 wherever legal,
-          0 never (the 128 x 128 kernel). */
+          0 never (the 128 x 128 kernel);
+   key 9: number of independent products the caller keeps in flight on DIFFERENT streams (default 1; dinounet_amd runs the frozen ViT as
+          two half-batch chains): du_gemm's tile choice then counts workgroup rounds on 256 / value CUs. */
 int du_set_option(int key, int value);
 /* tuning aid: the 8 per-segment cycle sums of the last probed attention launch (du_set_option(4, bits | 64), tools/attn_ablate.py) */
 int du_debug_attn_probe(uint64_t* host8);

@@ -124,8 +124,12 @@ def layer_norm_res(x, w, b, eps):
     return layer_norm(x, w, b, eps), x
 
 
-def layernorm_raw(x2d, w, b, eps, out_dtype, want_stats=False):
-    return F.layer_norm(x2d.float(), (x2d.shape[-1],), w, b, eps).to(out_dtype), None, None
+def layernorm_raw(x2d, w, b, eps, out_dtype, want_stats=False, out=None):
+    y = F.layer_norm(x2d.float(), (x2d.shape[-1],), w, b, eps).to(out_dtype)
+    if out is not None:
+        out.copy_(y)
+        y = out
+    return y, None, None
 
 
 def msda_prep(raw, ref, Lq, M, P, Hs, Ws):

@@ -513,6 +513,15 @@ def test_conv3x3_kernel_choice_host_logic_without_gpu():
     import ctypes as C
     args = (None, C.c_int64(128), None, C.c_int64(0), 128, 128, 128, 8, 128, 128, None, None, None, C.c_int64(128), None, None)
     assert int(L.du_conv3x3_strip(*args)) == -2                                      # DU_ERR_UNSUPPORTED, before any pointer is looked at
+    # a 32-channel slice of a 512-channel-wide tensor at 1024^2 is a strip-kernel SHAPE (the partial-statistics buffer is sized
+    # for strips) but a per-image input of 1 GiB, which the strip kernel declines on.  du_conv3x3_halo must then decline as a whole when
+    # statistics are asked for -- the LDS-tiled kernel would write B * (H / 8) * (W / 16) rows into the smaller strip-sized buffer --
+    # and it must do so before anything is launched (fake aligned addresses, no device here).
+    assert parts(32, 32, 32, 2, 1024, 1024) != 2 * (1024 // 8) * (1024 // 16)
+    big = (C.c_void_p(0x100000), C.c_int64(512), None, C.c_int64(0), 32, 32, 32, 2, 1024, 1024, C.c_void_p(0x200000), None,
+           C.c_void_p(0x300000), C.c_int64(32), C.c_void_p(0x400000), None)
+    assert int(L.du_conv3x3_strip(*big)) == -2
+    assert int(L.du_conv3x3_halo(*big)) == -2
 
 
 def test_bench_roofline_reads_pmc_summaries_only_for_matching_kernel_sources(monkeypatch):

@@ -129,8 +129,9 @@ def test_a_complete_contribution_flushes_what_is_pending_for_that_parameter(queu
 
 def test_a_backward_pass_that_raised_does_not_disarm_the_queue(queue):
     """the engine does not run final callbacks when a pass raises; a boolean 'armed' flag would stay set and every later
-    backward() would return with unfinished gradients.  Arming is keyed on the graph task: the next pass drops what the dead one left
-    queued and arms itself."""
+    backward() would return with unfinished gradients.  Arming is keyed on the graph task: the next pass launches what the dead one left
+    queued (a nested pass looks the same from here and MUST NOT lose the outer pass's jobs, ADVICE r4 -- the leftovers of a dead pass go
+    into buffers only the queue still holds) and arms itself."""
     q, fake = queue
 
     class _Boom(torch.autograd.Function):
@@ -153,9 +154,44 @@ def test_a_backward_pass_that_raised_does_not_disarm_the_queue(queue):
     assert q.jobs and q._armed_task is not None and not fake.launched      # the dead pass left its job behind
     w.grad = None
     w2 = torch.nn.Parameter(torch.ones(4, 3))
-    _Lin.apply(x, w2).sum().backward()         # a healthy pass: the leftovers are dropped, its own gradient is complete on return
-    assert fake.launched == [(4, 3, 0)] and not q.jobs and not q.keep and q._armed_task is None
+    _Lin.apply(x, w2).sum().backward()         # a healthy pass: the leftovers are launched out of the way, its own gradient is complete on return
+    assert fake.launched == [(2, 3, 0), (4, 3, 0)] and not q.jobs and not q.keep and q._armed_task is None and not q.state and not q.groups
     assert torch.equal(w2.grad, torch.full((4, 3), 4.5)) and w.grad is None
+
+
+def test_a_nested_backward_pass_does_not_lose_the_outer_passes_jobs(queue):
+    """a backward pass started INSIDE a node of another pass (reentrant checkpointing, autograd.grad in a hook or a custom
+    Function) has its own graph-task id.  The outer pass is alive and has already handed its zero-filled buffers to autograd: its queued
+    jobs must be launched, not dropped, and both passes' gradients must be complete when the outer backward() returns."""
+    q, fake = queue
+    w_in = torch.nn.Parameter(torch.ones(6, 3))
+    inner_grads = []
+
+    class _Nested(torch.autograd.Function):
+        """backward runs a whole inner pass (with a deferred product of its own) through autograd.grad"""
+
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            with torch.enable_grad():
+                xi = torch.ones(5, requires_grad=True)
+                yi = _Lin.apply(xi, w_in).sum()
+            inner_grads.append(torch.autograd.grad(yi, [w_in])[0])
+            return g
+
+    w_out, w_out2 = torch.nn.Parameter(torch.ones(2, 3)), torch.nn.Parameter(torch.ones(4, 3))
+    x = torch.ones(5, requires_grad=True)
+    # backward order: last applied first -> _Lin(w_out) queues, THEN the nested pass runs, then _Lin(w_out2) queues in the outer pass again
+    y = _Lin.apply(_Nested.apply(_Lin.apply(x, w_out2)), w_out)
+    y.sum().backward()
+    assert not q.jobs and not q.keep and q._armed_task is None and not q.state and not q.groups
+    assert torch.equal(w_out.grad, torch.full((2, 3), 2.5)), w_out.grad            # the outer job queued BEFORE the nested pass survived it
+    assert torch.equal(w_out2.grad, torch.full((4, 3), 4.5)), w_out2.grad          # ... and the outer pass re-armed itself afterwards
+    assert len(inner_grads) == 1 and torch.equal(inner_grads[0], torch.full((6, 3), 6.5))
+    assert sorted(fake.launched) == [(2, 3, 0), (4, 3, 0), (6, 3, 0)]
 
 
 def test_slice_views_of_a_parameter_are_not_deferred(queue):

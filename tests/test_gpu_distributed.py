@@ -161,9 +161,16 @@ def test_single_rank_rccl_reducer_inside_the_captured_step_bench():
     assert len(c["bucket_timeline"]) == c["gradient_allreduces_per_step"], c
     for t in c["bucket_timeline"]:
         assert 0.0 < t["ready_ms"] <= t["allreduce_start_ms"] <= t["allreduce_done_ms"] <= c["gradients_installed_ms"] + 1e-3, (t, c)
+        # `done` is recorded on the side stream BEHIND Work.wait() (parallel.py: after the collective itself, not after its enqueue).  One rank's
+        # in-place all-reduce is at most a copy of the bucket: a duration beyond 1 ms + bytes at 50 GB/s would mean the event trails
+        # something else (e.g. the compute stream) -- what a meaningful N > 1 timeline must not do either
+        dur = t["allreduce_done_ms"] - t["allreduce_start_ms"]
+        assert 0.0 <= dur <= 1.0 + 4.0 * t["elems"] / 50e9 * 1e3, (t, c)
     # the first bucket (decoder + FAPM) must be on the wire well before the backward pass ends: its all-reduce overlaps the adapter's backward
     assert c["bucket_timeline"][0]["allreduce_start_ms"] < 0.8 * c["gradients_installed_ms"], c
     assert sum(forced["comm"]["gradient_buckets_elems"]) > 15_000_000          # the ~20 M trainable gradients of dinounet_l
+    # one rank: no SyncBatchNorm / Dice collectives are issued (the fields exist and say so); N > 1 fills them from the eager steps
+    assert c["small_collectives_per_step"] == {} and c["small_collectives_ms_per_step"] is None, c
     ratio = forced["value"] / plain["value"]
     print(f"single-rank RCCL reducer in the captured step: {forced['value']:.1f} vs {plain['value']:.1f} slices/s (ratio {ratio:.3f}); comm {forced['comm']}")
     assert ratio > 0.95, (forced["value"], plain["value"])
