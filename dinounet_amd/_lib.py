@@ -87,6 +87,11 @@ def lib():
             fn.restype = ret
             fn.argtypes = types
         _lib = l
+        # A-B aids (tools/ab_bench.py): library options from the environment, e.g. DINOUNET_LIB_OPTIONS="10=1,9=2" -> du_set_option(10, 1), (9, 2)
+        for kv in os.environ.get("DINOUNET_LIB_OPTIONS", "").split(","):
+            if "=" in kv:
+                k, v = kv.split("=", 1)
+                l.du_set_option(int(k), int(v))
     return _lib
 
 

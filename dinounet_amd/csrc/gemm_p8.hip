@@ -1429,11 +1429,342 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_p4_kernel(GemmParams P) {
   pass(IC<1>{});
 }
 
+// ================================================================================================================================
+// PERSISTENT 256 x 128 kernel (round 5): one workgroup per CU walks a LIST of tiles; the K-tile ring never stops.
+//
+// Why: at K = 1024 a tile of the kernels above is 16 K-steps between a cold prologue (every workgroup of the launch asks for its first
+// 96-128 KB at once) and an exposed epilogue (bias / GELU / bf16 pack / LDS-staged row stores with the matrix pipe idle): 9-17 us of a
+// 36-83 us launch (profiles/r04_gemm_p8_table_v3.txt, "noepi" columns), twice per launch where a CU runs two rounds.  Two workgroups per
+// CU did not hide it.  Here a workgroup keeps going:
+//   * the K-tiles of tile i + 1 are requested by the last two K-steps of tile i -- the staging stream (LDS-DMA, counted vmcnt(6), three
+//     48 KB buffers, the phase program of gemm_nt_p8n_kernel unchanged) does not know about tile borders; only the FIRST tile of a
+//     workgroup has a prologue.  Operand rows past M / N and every request past the workgroup's last tile carry an out-of-range
+//     voffset (zeros, no traffic), so the wait counts hold everywhere and there is no tail variant of the K-step;
+//   * the finished accumulators (64 registers: the 256 x 128 kernel leaves 80 free) move to a second register set -- half of them in
+//     the MFMA shadow of the tile's last phase, the other half in the first phase of the next tile -- and the first K-step of the next
+//     tile starts its accumulators from the constant 0 (the MFMA's C operand): no zeroing pass;
+//   * that second set is DRAINED in the MFMA shadows of the next tile's first four K-steps, one 32 x 16 piece per phase: bias from a
+//     128-float LDS image of the tile's bias slice (LDS-DMA by waves 0 / 1 a tile ahead, two slots), erf-GELU polynomial, bf16 pack, two
+//     v_permlane32_swap (lanes 0-31 then hold 8 consecutive columns of their row, lanes 32-63 the 8 behind the next 8: the strip
+//     convolution's store), ONE 16-byte buffer store per lane -- no staging tile, no barrier, nothing after the last MFMA
+//     of a tile but the register move.  Only the workgroup's LAST tile drains in the open.
+// Stores sit in the same vmcnt queue as the LDS-DMA: the counted waits are left as they are (a store among the six youngest operations
+// only makes a wait stricter; a store the descriptor's range check drops retires at once, DESIGN 6.49, and is equally harmless here).
+// Tiles are dealt out statically: workgroup w (XCD-contiguous index) takes tiles w, w + G, w + 2 G, ... of the banded tile order, so
+// the G tiles in flight at any time are the ones a non-persistent launch would run in one round.
+// Served: bf16 result, epilogue = bias (+ GELU), plain store, K >= 512 (the drain is spread over four K-steps; shorter products
+// keep the kernels above).  Results are bit-identical to gemm_nt_p8n_kernel (same K order, same epilogue arithmetic).
+// ================================================================================================================================
+constexpr int PP_BIAS_OFF = P8N_LDS;              // two slots x 128 floats behind the three K-tile buffers
+constexpr int PP_LDS = P8N_LDS + 2 * 128 * 4;     // 148 480 B
+constexpr unsigned PP_OOR = 0x80000000u;          // a voffset past every descriptor's range (the range check ignores the scalar offset)
+
+__device__ __forceinline__ void pp_swap_halves(unsigned& a, unsigned& b) {      // a's lanes 32-63 <-> b's lanes 0-31
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// (free functions: an asm operand that is a local captured by a generic lambda does not compile)
+__device__ __forceinline__ void pp_lds_read2(f32x4& a, f32x4& b, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64" : "=&v"(a), "=&v"(b) : "v"(addr));
+}
+__device__ __forceinline__ void pp_wait_lds(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
+
+template <int ACT, int SCHED>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<bf16_t>(P, smem); return; }
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int G = P.main_wgs;                       // persistent workgroups of this launch
+  int lin;
+  {
+    const int bid = blockIdx.x, q = G >> 3, r = G & 7, xcd = bid & 7, idx = bid >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int ntiles = P.tiles_m * P.tiles_n;
+  const int nk = P.K / PBK;
+  auto coords = [&](int tile, int& m0, int& n0) {
+    int tm, tn;
+    if (P.group_m > 1) {
+      const int band = P.group_m * P.tiles_n;
+      const int g = tile / band, l = tile - g * band;
+      const int first = g * P.group_m;
+      const int gsz = min(P.tiles_m - first, P.group_m);
+      tn = l / gsz; tm = first + (l - tn * gsz);
+    } else {
+      tm = tile / P.tiles_n; tn = tile - tm * P.tiles_n;
+    }
+    m0 = tm * PBM; n0 = tn * NBN;
+  };
+
+  // whole-matrix descriptors (the host checked every extent against 2^31 bytes); the tile's first row travels in the scalar offset
+  const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)P.a.p, 0, (int)((((long)P.M - 1) * P.a.ld + P.K) * 2), 0x00020000);
+  const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)P.b.p, 0, (int)((((long)P.N - 1) * P.b.ld + P.K) * 2), 0x00020000);
+  const auto rc = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, (int)((((long)P.M - 1) * P.ldc + P.N) * 2), 0x00020000);
+  const auto rbias = __builtin_amdgcn_make_buffer_rsrc(P.bias ? (void*)P.bias : P.C, 0, P.bias ? P.N * 4 : 0, 0x00020000);
+
+  // staging: piece (round r, wave w) of a half = tile rows (r*8 + w)*8 .. +8, lane l -> row + l/8, physical 16-byte chunk l%8 holds
+  // logical chunk (l%8) ^ ((row >> 1) & 7) (as gemm_nt_p8n_kernel)
+  const int lc = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
+  int srow[2];                    // this lane's tile row of round r (A half 1: + 128)
+  unsigned va0[2][2], vb0[2];     // voffsets relative to the tile's first row
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    srow[r] = (r * 8 + wave) * 8 + (lane >> 3);
+    va0[0][r] = (unsigned)srow[r] * (unsigned)(P.a.ld * 2) + lc * 16;
+    va0[1][r] = (unsigned)(128 + srow[r]) * (unsigned)(P.a.ld * 2) + lc * 16;
+    vb0[r] = (unsigned)srow[r] * (unsigned)(P.b.ld * 2) + lc * 16;
+  }
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned va_s[2][2], vb_s[2];   // ... of the tile being STAGED, out of range for rows past M / N and past the last tile
+  unsigned sa_base = 0, sb_base = 0;
+  // the tile whose K-tiles are requested from now on; its bias slice -> LDS slot `slot` (waves 0 / 1, one 4-byte LDS-DMA each)
+  auto set_stage_tile = [&](int tile, int slot) {
+    if (tile < ntiles) {
+      int m0, n0;
+      coords(tile, m0, n0);
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        va_s[0][r] = m0 + srow[r] < P.M ? va0[0][r] : PP_OOR;
+        va_s[1][r] = m0 + 128 + srow[r] < P.M ? va0[1][r] : PP_OOR;
+        vb_s[r] = n0 + srow[r] < P.N ? vb0[r] : PP_OOR;
+      }
+      sa_base = (unsigned)m0 * (unsigned)(P.a.ld * 2);
+      sb_base = (unsigned)n0 * (unsigned)(P.b.ld * 2);
+      if (wave < 2) {
+        // inline asm: behind an LDS-DMA builtin the compiler waits vmcnt(0) in front of every read of the bias image (it cannot tell the
+        // slots apart) -- once per phase of the drain.  Unseen, the image is ordered by distance: it is read a whole tile later, behind
+        // >= 30 counted waits and barriers.  M0 saved / restored (the compiler's own LDS-DMA keeps its destination there).
+        const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_base + PP_BIAS_OFF + slot * 512 + wave * 256);
+        const unsigned voff = (unsigned)(n0 + wave * 64 + lane) * 4u;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(rbias), "s"(lds_dst) : "memory");
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 2; r++) { va_s[0][r] = PP_OOR; va_s[1][r] = PP_OOR; vb_s[r] = PP_OOR; }
+    }
+  };
+  // which: 0 = A-half0, 1 = A-half1, 2 = B of the staged tile's K-tile at byte offset kofs, into the buffer at byte offset bo
+  auto stage = [&](auto which_c, int bo, unsigned kofs) {
+    constexpr int which = decltype(which_c)::value;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      unsigned char* dst = smem + bo + which * HALF_B + (r * 8 + wave) * 1024;
+      if constexpr (which < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, va_s[which][r], sa_base + kofs, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)dst, 16, vb_s[r], sb_base + kofs, 0, 0);
+    }
+  };
+  int L[4];
+  {
+    const int x = hi ^ ((lane >> 1) & 7);
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) L[kk] = (lane & 31) * 128 + ((x ^ (2 * kk)) << 4);
+  }
+  const int aoff = wm * 32 * 128, boff = 2 * HALF_B + wn * 64 * 128;
+
+  bf16x8 Af[2][4];        // [set = A half][kk]
+  bf16x8 Bf[2][2][4];     // [set][column block][kk]
+  f32x16 acc[2][2];       // [i = A half][column block]: the tile being computed
+  f32x16 prev[2][2];      // the finished tile, being stored
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) prev[i][c][r] = 0.f;
+  auto readA = [&](auto set_c, int bo) {
+    constexpr int set = decltype(set_c)::value;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) Af[set][kk] = *(const bf16x8*)(smem + bo + set * HALF_B + aoff + L[kk]);
+  };
+  auto readB = [&](auto set_c, int bo) {
+    constexpr int set = decltype(set_c)::value;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) Bf[set][c][kk] = *(const bf16x8*)(smem + bo + boff + c * 4096 + L[kk]);
+  };
+  // FIRST: the tile's first K-step -- the accumulators start from the MFMA's constant C operand
+  auto mma = [&](auto i_c, auto bset_c, auto first_c) {
+    constexpr int i = decltype(i_c)::value, bset = decltype(bset_c)::value;
+    constexpr bool FIRST = decltype(first_c)::value;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        if constexpr (FIRST) {
+          if (kk == 0) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[bset][c][kk], Af[i][kk], z, 0, 0, 0);
+            continue;
+          }
+        }
+        acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf[bset][c][kk], Af[i][kk], acc[i][c], 0, 0, 0);
+      }
+  };
+  auto pin = [&](auto nrd_c, auto ndma_c) {
+    constexpr int nrd = decltype(nrd_c)::value, ndma = decltype(ndma_c)::value;
+    if constexpr (SCHED == 1) {
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (m < 4) __builtin_amdgcn_sched_group_barrier(0x100, nrd / 4, 0);
+        else if (m - 4 < ndma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM READ: the LDS-DMA, not the drain's store
+      }
+    }
+  };
+  // ---- drain of the finished tile: unit u = (i, c, h2), the 32 rows x 16 columns {8 h2 .. + 7} u {16 + 8 h2 .. + 7} of block (i, c) ----
+  const int nlim = (P.dbg & 1) ? 0 : P.N;    // (du_set_option key 3 bit 0: no stores -- timing ablation)
+  unsigned pbias = lds_base + PP_BIAS_OFF + (unsigned)((wn * 64 + 4 * hi) * 4);     // this lane's corner of the finished tile's bias image
+  unsigned crow[2] = {PP_OOR, PP_OOR};   // byte offset of this lane's row of A half i, at its first column (wave's 64 + 16 hi), in C
+  int pcol = 0;                   // that first column
+  auto set_prev_tile = [&](int tile, int slot) {
+    int m0, n0;
+    coords(tile, m0, n0);
+    pcol = n0 + wn * 64 + hi * 16;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int m = m0 + i * 128 + wm * 32 + (lane & 31);
+      crow[i] = m < P.M ? (unsigned)(((long)m * P.ldc + pcol) * 2) : PP_OOR;
+    }
+  };
+  // The bias of a unit is fetched ONE PHASE AHEAD by an inline-asm ds_read pair the compiler does not see: behind the LDS-DMA builtins it
+  // puts s_waitcnt vmcnt(0) in front of any read of the bias image (it cannot tell the image from the K-tile ring), which drains the
+  // ring once per phase.  The phase-end wait (lgkmcnt(0), naming the two destinations so they stay opaque until then) retires the pair.
+  f32x4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](auto u_c, unsigned base) {           // columns (c*32 + 8 g + 4 hi + e), g = h2 and h2 + 2, of the image at `base`
+    constexpr int u = decltype(u_c)::value;
+    if constexpr (u >= 0) {
+      constexpr int c = (u >> 1) & 1, h2 = u & 1;
+      const unsigned addr = base + (unsigned)((c * 32 + 8 * h2) * 4);
+      pp_lds_read2(bq0, bq1, addr);
+    }
+  };
+  auto drain = [&](auto u_c) {
+    constexpr int u = decltype(u_c)::value;
+    if constexpr (u >= 0) {
+      constexpr int i = u >> 2, c = (u >> 1) & 1, h2 = u & 1;
+      // (no "is there a finished tile" branch: before the first one `prev` holds zeros and crow is out of range -- the store is dropped;
+      //  a branch would end the phase's scheduling region in front of the drain and push it behind the MFMAs)
+      const f32x16& a = prev[i][c];
+      f32x2 o00 = {a[4 * h2] + bq0[0], a[4 * h2 + 1] + bq0[1]}, o01 = {a[4 * h2 + 2] + bq0[2], a[4 * h2 + 3] + bq0[3]};
+      f32x2 o10 = {a[4 * (h2 + 2)] + bq1[0], a[4 * (h2 + 2) + 1] + bq1[1]}, o11 = {a[4 * (h2 + 2) + 2] + bq1[2], a[4 * (h2 + 2) + 3] + bq1[3]};
+      if constexpr (ACT == DU_ACT_GELU) { o00 = gelu_pk(o00); o01 = gelu_pk(o01); o10 = gelu_pk(o10); o11 = gelu_pk(o11); }
+      const bf16x2 t0 = {(bf16_t)o00.x, (bf16_t)o00.y}, t1 = {(bf16_t)o01.x, (bf16_t)o01.y};
+      const bf16x2 t4 = {(bf16_t)o10.x, (bf16_t)o10.y}, t5 = {(bf16_t)o11.x, (bf16_t)o11.y};
+      unsigned k0 = __builtin_bit_cast(unsigned, t0), k1 = __builtin_bit_cast(unsigned, t1);
+      unsigned k4 = __builtin_bit_cast(unsigned, t4), k5 = __builtin_bit_cast(unsigned, t5);
+      pp_swap_halves(k0, k4);        // lanes 0-31: (own group h2 | partner's group h2) = columns 8 h2 .. + 7;
+      pp_swap_halves(k1, k5);        // lanes 32-63: (partner's group h2 + 2 | own) = columns 16 + 8 h2 .. + 7
+      const u32x4_t v = {k0, k1, k4, k5};
+      const unsigned off = pcol + c * 32 + 8 * h2 < nlim ? crow[i] + (unsigned)((c * 32 + 8 * h2) * 2) : PP_OOR;
+      __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
+    }
+  };
+  auto finish6 = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    pp_wait_lds(bq0, bq1);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // one K-step.  p: fragment set of this K-tile's B; kofs: byte offset (inside the operand rows) of the K-tile requested now (the staged
+  // tile's); D0 / D1: drain unit of the two phases (-1: none), F0 / F1: unit whose bias is fetched at the end of phase 0 / 1 (for the
+  // next phase) from the image at fbase; CP1: prev[1] <- acc[1] in phase 0 (first K-step of a tile, before its phase 1 restarts acc[1]);
+  // CP0: prev[0] <- acc[0] in phase 1 (last K-step of a tile: acc[0] is final after phase 0)
+  auto kstep = [&](auto par_c, auto first_c, auto d0_c, auto d1_c, auto f0_c, auto f1_c, auto cp1_c, auto cp0_c, int bc, int bn, int bnn, unsigned kofs,
+                   unsigned fbase) {
+    constexpr int p = decltype(par_c)::value;
+    // phase 0
+    readA(IC<1>{}, bc);
+    stage(IC<0>{}, bnn, kofs); stage(IC<2>{}, bnn, kofs);
+    if constexpr (decltype(cp1_c)::value) { prev[1][0] = acc[1][0]; prev[1][1] = acc[1][1]; }
+    mma(IC<0>{}, IC<p>{}, first_c);
+    drain(d0_c);
+    pin(IC<4>{}, IC<4>{});
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(f0_c, fbase);
+    finish6();
+    // phase 1
+    readA(IC<0>{}, bn); readB(IC<1 - p>{}, bn);
+    stage(IC<1>{}, bnn, kofs);
+    if constexpr (decltype(cp0_c)::value) { prev[0][0] = acc[0][0]; prev[0][1] = acc[0][1]; }
+    mma(IC<1>{}, IC<p>{}, first_c);
+    drain(d1_c);
+    pin(IC<12>{}, IC<2>{});
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(f1_c, fbase);
+    finish6();
+  };
+  using T_ = IC<1>; using F_ = IC<0>; using N_ = IC<-1>;
+
+  // ---- this workgroup's first tile: the only prologue (K-tiles 0 and 1) ----
+  int tile = lin;
+  if (tile >= ntiles) return;
+  set_stage_tile(tile, 0);
+  stage(IC<0>{}, 0, 0u); stage(IC<2>{}, 0, 0u); stage(IC<1>{}, 0, 0u);
+  stage(IC<0>{}, NBUF_B, 128u); stage(IC<2>{}, NBUF_B, 128u); stage(IC<1>{}, NBUF_B, 128u);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // K-tile 0 landed
+  __builtin_amdgcn_s_barrier();
+  readA(IC<0>{}, 0);
+  readB(IC<0>{}, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  int bc = 0, bn = NBUF_B, bnn = 2 * NBUF_B;
+  int slot = 0;
+  auto rot2 = [&]() { const int o = bc; bc = bnn; bnn = bn; bn = o; };      // advance two K-tiles: (bc, bn, bnn) <- (bnn, bc, bn)
+  for (;;) {
+    // K-steps 0 .. 3: the previous tile drains (unit 0's bias was fetched by the last phase of that tile)
+    kstep(IC<0>{}, T_{}, IC<0>{}, IC<1>{}, IC<1>{}, IC<2>{}, T_{}, F_{}, bc, bn, bnn, 2u * 128u, pbias);
+    kstep(IC<1>{}, F_{}, IC<2>{}, IC<3>{}, IC<3>{}, IC<4>{}, F_{}, F_{}, bn, bnn, bc, 3u * 128u, pbias);
+    rot2();
+    kstep(IC<0>{}, F_{}, IC<4>{}, IC<5>{}, IC<5>{}, IC<6>{}, F_{}, F_{}, bc, bn, bnn, 4u * 128u, pbias);
+    kstep(IC<1>{}, F_{}, IC<6>{}, IC<7>{}, IC<7>{}, N_{}, F_{}, F_{}, bn, bnn, bc, 5u * 128u, pbias);
+    rot2();
+    int t = 4;
+    for (; t + 2 < nk; t += 2) {
+      kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, (unsigned)(t + 2) * 128u, 0u);
+      kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bn, bnn, bc, (unsigned)(t + 3) * 128u, 0u);
+      rot2();
+    }
+    // the last two K-steps request K-tiles 0 and 1 of the NEXT tile (out of range behind the last one); the very last phase fetches the
+    // bias of drain unit 0 of THIS tile (its image: slot `slot`)
+    const int next = tile + G;
+    set_stage_tile(next, slot ^ 1);
+    pbias = lds_base + PP_BIAS_OFF + (unsigned)(slot * 512 + (wn * 64 + 4 * hi) * 4);
+    kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, 0u, 0u);
+    kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, IC<0>{}, F_{}, T_{}, bn, bnn, bc, 128u, pbias);
+    rot2();
+    set_prev_tile(tile, slot);
+    slot ^= 1;
+    tile = next;
+    if (tile >= ntiles) break;
+  }
+  // ---- the last tile drains in the open ----
+  prev[1][0] = acc[1][0]; prev[1][1] = acc[1][1];
+  if (P.dbg & 2) return;
+  auto last = [&](auto u_c) {          // unit u (its bias is in flight or landed), then the fetch of unit u + 1
+    pp_wait_lds(bq0, bq1);
+    __builtin_amdgcn_sched_barrier(0);
+    drain(u_c);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(IC<(decltype(u_c)::value < 7 ? decltype(u_c)::value + 1 : -1)>{}, pbias);
+  };
+  last(IC<0>{}); last(IC<1>{}); last(IC<2>{}); last(IC<3>{}); last(IC<4>{}); last(IC<5>{}); last(IC<6>{}); last(IC<7>{});
+}
+
 int g_p8_mode = -1;      // -1: heuristic, 0: off, 1: 256 x 256 wherever legal, 2: 256 x 128 wherever legal, 3: the 4-wave 256 x 128 kernel wherever legal
 int g_p8_sched = 1;
 int g_p8_corun = 1;      // du_set_option key 9: independent products the caller keeps in flight on different streams (the frozen ViT run as
                          // two half-batch chains): the tile choice then counts rounds on 256 / corun CUs -- a product that fills half the chip
                          // alone is a full round beside its twin
+int g_p8_persist = 0;    // du_set_option key 10: 0 = never, 1 = the persistent 256 x 128 kernel where its epilogue / shape rules hold and a CU gets
+                         // >= 2 tiles, 2 = wherever legal
 int g_p8_group = 4;
 int g_p8_debug = 0;      // bit 0: skip the bf16 global stores, bit 1: skip the whole epilogue (timing ablations only)
 
@@ -1459,6 +1790,32 @@ int launch_p8(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
     attr_set = true;
   }
   hipLaunchKernelGGL(kfn, grid, dim3(512), LDS_BYTES, st, P);
+  return du_check_launch();
+}
+
+// persistent 256 x 128 kernel: G = min(tiles, CUs this product can count on) workgroups, each walks tiles w, w + G, ...
+template <int SCHED>
+int launch_pp(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
+  GemmParams P = make_params(a, DU_PLAIN_ROW, DU_PLAIN_ROW, PBM, NBN, PBK);
+  P.tiles_m = (a.M + PBM - 1) / PBM;
+  P.group_m = g_p8_group;
+  P.dbg = g_p8_debug;
+  const long ntiles = (long)P.tiles_m * P.tiles_n;
+  const long cus = 256 / g_p8_corun;
+  P.main_wgs = (int)(ntiles < cus ? ntiles : cus);
+  dim3 grid(P.main_wgs, 1);
+  if (tail_rows > 0) {
+    P.tail_rows = tail_rows;
+    grid.x += (a.N + SK_BN - 1) / SK_BN;
+  }
+  void (*kfn)(GemmParams) = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, SCHED> : gemm_nt_pp_kernel<DU_ACT_NONE, SCHED>;
+  static bool attr_set[2] = {false, false};
+  const int ai = a.act == DU_ACT_GELU ? 1 : 0;
+  if (!attr_set[ai]) {
+    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess) return DU_ERR_LAUNCH;
+    attr_set[ai] = true;
+  }
+  hipLaunchKernelGGL(kfn, grid, dim3(512), PP_LDS, st, P);
   return du_check_launch();
 }
 
@@ -1522,6 +1879,7 @@ extern "C" int du_set_option(int key, int value) {
     case 3: g_p8_debug = value; return DU_OK;
     case 5: g_p8_tn = value; return DU_OK;
     case 9: g_p8_corun = value < 1 ? 1 : (value > 8 ? 8 : value); return DU_OK;
+    case 10: g_p8_persist = value; return DU_OK;
     default: return DU_ERR_BAD_ARG;
   }
 }
@@ -1564,13 +1922,24 @@ static bool p8_legal(const du_gemm_args& a) {
   return true;
 }
 
-// 0: not served by gemm_p8.hip, 1: 256 x 256 tiles, 2: 256 x 128 tiles (8 waves, one workgroup per CU), 3: 256 x 128 tiles on 4 waves, two workgroups per CU
+// the persistent 256 x 128 kernel: bf16 result with a bias (+ GELU) epilogue, plain store, K >= 512, every extent below 2^31 bytes
+static bool pp_legal(const du_gemm_args& a) {
+  if (!p8_legal(a) || a.out_dtype != DU_BF16 || a.store_mode != DU_STORE_PLAIN || a.batch > 1) return false;
+  if (a.residual || a.gamma || a.row_scale || a.alpha != 1.0f || (a.act != DU_ACT_NONE && a.act != DU_ACT_GELU)) return false;
+  if (a.K < 512 || a.N % 8 || a.ldc % 8 || (((uintptr_t)a.C) & 15)) return false;
+  const long lim = 0x7fffffffL;
+  return ((long)a.M * a.lda + a.K) * 2 < lim && ((long)a.N * a.ldb + a.K) * 2 < lim && ((long)a.M * a.ldc + a.N) * 2 < lim;
+}
+
+// 0: not served by gemm_p8.hip, 1: 256 x 256 tiles, 2: 256 x 128 tiles (8 waves, one workgroup per CU), 3: 256 x 128 tiles on 4 waves, two workgroups per CU,
+// 4: 256 x 128 tiles, persistent workgroups
 int du_gemm_p8_choice(const du_gemm_args& a) {
   if (g_p8_mode != 0 && g_p8_tn && p8_gather_legal(a))      // ConvT data gradient: 256 x 256 tiles once they fill most of the CUs
     return (g_p8_mode > 0 || (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 192) ? 1 : 0;
   if (g_p8_mode == 0 || !p8_legal(a)) return 0;
   if (a.store_mode == DU_STORE_QKV_ROPE) return 2;
   if (g_p8_mode == 3) return a.act == DU_ACT_SWIGLU ? 2 : 3;
+  if (g_p8_mode == 4) return pp_legal(a) ? 4 : 2;
   if (g_p8_mode > 0) return g_p8_mode == 2 ? 2 : 1;
   // rounds of workgroups on the 256 CUs (one 8-wave workgroup per CU) x cost per workgroup (a 256 x 128 tile costs ~0.56 of a
   // 256 x 256 one: half the MFMAs at a lower operand reuse); measured crossovers: tools/gemm_p8_bench.py
@@ -1579,6 +1948,7 @@ int du_gemm_p8_choice(const du_gemm_args& a) {
   const long t256 = tm * ((a.N + 255) / 256) * batch, t128 = tm * ((a.N + 127) / 128) * batch;
   const long cus = 256 / g_p8_corun;           // CUs this product can count on (co-running products share the chip)
   if (t128 * g_p8_corun < 192) return 0;
+  if (g_p8_persist && pp_legal(a) && (g_p8_persist > 1 || t128 >= 2 * cus)) return 4;
   // (round 4: at K = 1024 the narrow tile's fixed costs -- prologue, exposed epilogue -- weigh more: 3 rounds of 256 x 128 tiles cost 62.8-67.6 us
   //  against 62.8-63.5 us for 2 rounds of 256 x 256 on the 8192 / 8232 x 3072 qkv product, ratio 0.66-0.72 per round, not 0.56)
   const double c256 = (double)((t256 + cus - 1) / cus) * 1.0, c128 = (double)((t128 + cus - 1) / cus) * (a.K >= 1024 ? 0.68 : 0.56);
@@ -1600,6 +1970,7 @@ int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st, int tail_rows) {
   if (a.a_mode == DU_IM2COL_ROW) return g_p8_sched ? launch_p8<bf16_t, 1, false, true>(a, st) : launch_p8<bf16_t, 0, false, true>(a, st);
   const bool bf = a.out_dtype == DU_BF16;
   const int tr = tail_rows;
+  if (c == 4) return g_p8_sched ? launch_pp<1>(a, st, tr) : launch_pp<0>(a, st, tr);
   if (c == 3) return bf ? launch_p4<bf16_t>(a, st, tr) : launch_p4<float>(a, st, tr);
   if (c == 1) {
     if (bf) return g_p8_sched ? launch_p8<bf16_t, 1, false>(a, st, tr) : launch_p8<bf16_t, 0, false>(a, st, tr);

@@ -358,6 +358,9 @@ class DINOv3_Adapter(nn.Module):
         # spatial prior module below -- independent of it (ADP:412-415), HBM-bound where the ViT is MFMA-bound -- runs beside them on this
         # stream; `vit()` joins the chains.  (chains <= 1: the backbone simply runs before the prior module; same results either way.)
         vit = self.backbone.begin_intermediate_layers(x, n=self.interaction_indexes, return_class_token=True, dtype=dt)
+        if not getattr(self.backbone, "overlap_prior", True):
+            vit_out = vit()                                 # (A-B aid: join at once, the prior module runs behind the backbone)
+            vit = lambda: vit_out
         x8 = ops.nchw_to_nhwc(x, dt, 8)
         c1, c2, c3, c4 = self.spm(x8, self.level_embed, group)                              # ADP:412-413
         n2, n3 = c2.shape[1], c3.shape[1]

@@ -182,6 +182,7 @@ class DinoVisionTransformer(nn.Module):
         # independent, so the same work as TWO chains lets the dispatcher fill the CUs one chain leaves idle with the other chain's
         # workgroups; nothing else changes (same kernels, same arithmetic per sample).  0 / 1 = one chain on the caller's stream.
         self.chains = int(os.environ.get("DINOUNET_VIT_CHAINS", "2"))
+        self.overlap_prior = os.environ.get("DINOUNET_VIT_OVERLAP_PRIOR", "1") != "0"     # the adapter's prior module beside the chains
         self._chain_streams = {}
         self._chain_ws = {}
         self.init_weights()

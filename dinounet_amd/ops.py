@@ -133,7 +133,8 @@ def _small_all_reduce(t, group, what):
 _MODE_NAMES = {(0, 0): "linear", (0, 1): "linear_dgrad", (1, 1): "linear_wgrad", (2, 0): "conv_im2col", (1, 3): "conv_wgrad"}
 
 
-_ROUTE_NAMES = {0: "gemm_kernel", 1: "gemm_bf16_kernel", 2: "gemm_nt_glds_kernel", 3: "gemm_nt_p8_kernel", 4: "gemm_nt_p8n_kernel", 5: "gemm_tn_p8_kernel"}
+_ROUTE_NAMES = {0: "gemm_kernel", 1: "gemm_bf16_kernel", 2: "gemm_nt_glds_kernel", 3: "gemm_nt_p8_kernel", 4: "gemm_nt_p8n_kernel", 5: "gemm_tn_p8_kernel",
+                6: "gemm_nt_pp_kernel"}
 
 
 _WGRAD_COLSUM = os.environ.get("DINOUNET_WGRAD_COLSUM", "1") == "1"     # bias gradients inside the weight-gradient kernels (A-B aid)

@@ -35,7 +35,9 @@ def check():
     cases = [(256, 256, 256, bf, 0), (512, 512, 256, torch.float32, 0), (768, 640, 384, bf, 0), (1000, 516, 512, torch.float32, 1),
              (8232, 3072, 1024, bf, 0), (8232, 1024, 1024, torch.float32, 2), (8232, 4096, 1024, bf, 3), (8232, 1024, 4096, torch.float32, 2),
              (2048, 384, 1536, bf, 0), (8192, 3072, 1024, bf, 2), (8192, 3072, 1024, torch.float32, 0), (4096, 4096, 512, bf, 0),
-             (8232, 1280, 256, bf, 3), (8232, 1000, 512, torch.float32, 1)]
+             (8232, 1280, 256, bf, 3), (8232, 1000, 512, torch.float32, 1),
+             # persistent kernel: several tiles per workgroup with ragged last tile rows / columns, K at its lower limit, bias and GELU
+             (70000, 264, 512, bf, 1), (33000, 1000, 640, bf, 3), (43008, 1024, 512, bf, 1), (5000, 136, 2048, bf, 0)]
     for M, N, K, od, epi in cases:
         x, w = rnd(M, K).to(bf), (rnd(N, K) * 0.05).to(bf)
         bias = rnd(N) if epi else None
@@ -55,7 +57,7 @@ def check():
         y_old = run(x, w, od, bias, gamma, res, act).float()
         scale = ref.abs().max().item()
         e_old = (y_old - ref).abs().max().item() / scale
-        for mode, tag in ((1, "256x256"), (2, "256x128"), (3, "256x128 4-wave")):
+        for mode, tag in ((1, "256x256"), (2, "256x128"), (3, "256x128 4-wave"), (4, "256x128 persistent")):
             opt(mode=mode)
             y_new = run(x, w, od, bias, gamma, res, act).float()
             e_new = (y_new - ref).abs().max().item() / scale
@@ -85,9 +87,10 @@ def time_variants(rounds):
     rnd = lambda *s: torch.randn(*s, generator=g).to(dev).to(bf)
     variants = [("old128", dict(mode=0)), ("256x256", dict(mode=1)), ("256 nostore", dict(mode=1, debug=1)), ("256 noepi", dict(mode=1, debug=2)),
                 ("256x128", dict(mode=2)), ("128 nostore", dict(mode=2, debug=1)), ("128 noepi", dict(mode=2, debug=2)), ("128 nopre", dict(mode=2, debug=4)),
-                ("4wave", dict(mode=3)), ("4w noepi", dict(mode=3, debug=2)), ("auto", dict(mode=-1))]
+                ("4wave", dict(mode=3)), ("4w noepi", dict(mode=3, debug=2)), ("persist", dict(mode=4)), ("pp nostore", dict(mode=4, debug=1)),
+                ("auto", dict(mode=-1))]
     if "--quick" in sys.argv:
-        variants = [v for v in variants if v[0] in ("256x256", "256x128", "4wave", "4w noepi", "auto")]
+        variants = [v for v in variants if v[0] in ("256x256", "256x128", "256 noepi", "128 noepi", "persist", "pp nostore", "auto")]
     shapes = [(8232, 3072, 1024, bf, "qkv"), (8232, 4096, 1024, bf, "fc1"), (8232, 1024, 4096, torch.float32, "fc2"),
               (8232, 1024, 1024, torch.float32, "proj"), (8192, 3072, 1024, bf, "qkv8192"), (8192, 4096, 1024, bf, "fc1_8192"),
               (4096, 4096, 4096, bf, "4096^3"), (8192, 8192, 8192, bf, "8192^3"), (8232, 2304, 768, bf, "qkv_b"), (8232, 3072, 768, bf, "fc1_b"),
