@@ -1445,8 +1445,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_p4_kernel(GemmParams P) {
 //     tile starts its accumulators from the constant 0 (the MFMA's C operand): no zeroing pass;
 //   * that second set is DRAINED in the MFMA shadows of the next tile's first four K-steps, one 32 x 16 piece per phase: bias from a
 //     128-float LDS image of the tile's bias slice (LDS-DMA by waves 0 / 1 a tile ahead, two slots), erf-GELU polynomial, bf16 pack, two
-//     v_permlane32_swap (lanes 0-31 then hold 8 consecutive columns of their row, lanes 32-63 the 8 behind the next 8: the strip
-//     convolution's store), ONE 16-byte buffer store per lane -- no staging tile, no barrier, nothing after the last MFMA
+//     v_permlane32_swap (lanes 0-31 then hold 8 consecutive columns of their row, lanes 32-63 the next 8 -- the strip convolution's
+//     store, DESIGN 6.48, with adjacent accumulator groups paired so that a row's two lanes write 32 contiguous bytes), ONE 16-byte buffer
+//     store per lane -- no staging tile, no barrier, nothing after the last MFMA
 //     of a tile but the register move.  Only the workgroup's LAST tile drains in the open.
 // Stores sit in the same vmcnt queue as the LDS-DMA: the counted waits are left as they are (a store among the six youngest operations
 // only makes a wait stricter; a store the descriptor's range check drops retires at once, DESIGN 6.49, and is equally harmless here).
@@ -1464,12 +1465,11 @@ __device__ __forceinline__ void pp_swap_halves(unsigned& a, unsigned& b) {      
 }
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // (free functions: an asm operand that is a local captured by a generic lambda does not compile)
-__device__ __forceinline__ void pp_lds_read2(f32x4& a, f32x4& b, unsigned addr) {
-  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64" : "=&v"(a), "=&v"(b) : "v"(addr));
-}
+__device__ __forceinline__ void pp_lds_read1(f32x4& a, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=&v"(a) : "v"(addr)); }
 __device__ __forceinline__ void pp_wait_lds(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
+__device__ __forceinline__ void pp_wait_lds1(f32x4& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory"); }
 
-template <int ACT, int SCHED>
+template <int ACT, int SPREAD>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<bf16_t>(P, smem); return; }
@@ -1607,100 +1607,118 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   };
   auto pin = [&](auto nrd_c, auto ndma_c) {
     constexpr int nrd = decltype(nrd_c)::value, ndma = decltype(ndma_c)::value;
-    if constexpr (SCHED == 1) {
 #pragma unroll
-      for (int m = 0; m < 8; m++) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (m < 4) __builtin_amdgcn_sched_group_barrier(0x100, nrd / 4, 0);
-        else if (m - 4 < ndma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM READ: the LDS-DMA, not the drain's store
-      }
+    for (int m = 0; m < 8; m++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (m < 4) __builtin_amdgcn_sched_group_barrier(0x100, nrd / 4, 0);
+      else if (m - 4 < ndma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM READ: the LDS-DMA, not the drain's store
     }
   };
-  // ---- drain of the finished tile: unit u = (i, c, h2), the 32 rows x 16 columns {8 h2 .. + 7} u {16 + 8 h2 .. + 7} of block (i, c) ----
+  // ---- drain of the finished tile.  Unit u = (i, c, h2): the 32 rows x 16 columns 16 h2 .. + 15 of block (i, c), one 16-byte store per
+  // lane (a row's two lanes store adjacent pieces: 32 contiguous bytes per row and instruction).  A unit is two HALVES (h = 2 u + part):
+  // part 0 = accumulator group g = 2 h2 (4 values per lane: bias, activation, bf16 pair x 2, kept in two registers), part 1 = group
+  // 2 h2 + 1, then the two v_permlane32_swap and the store.  SPREAD = K-steps the 16
+  // halves are dealt over: 4 (both halves of a unit in one phase; K >= 512) or 8 (one half per phase; K >= 768) -- the erf-GELU of fc1 is
+  // ~530 VALU issue cycles per unit and wave against 512 matrix-pipe cycles per phase and SIMD: bunched into 8 phases it paced them. ----
   const int nlim = (P.dbg & 1) ? 0 : P.N;    // (du_set_option key 3 bit 0: no stores -- timing ablation)
   unsigned pbias = lds_base + PP_BIAS_OFF + (unsigned)((wn * 64 + 4 * hi) * 4);     // this lane's corner of the finished tile's bias image
-  unsigned crow[2] = {PP_OOR, PP_OOR};   // byte offset of this lane's row of A half i, at its first column (wave's 64 + 16 hi), in C
+  unsigned crow[2] = {PP_OOR, PP_OOR};   // byte offset of this lane's row of A half i, at its first column (wave's 64 + 8 hi), in C
   int pcol = 0;                   // that first column
-  auto set_prev_tile = [&](int tile, int slot) {
+  auto set_prev_tile = [&](int tile) {
     int m0, n0;
     coords(tile, m0, n0);
-    pcol = n0 + wn * 64 + hi * 16;
+    pcol = n0 + wn * 64 + hi * 8;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int m = m0 + i * 128 + wm * 32 + (lane & 31);
       crow[i] = m < P.M ? (unsigned)(((long)m * P.ldc + pcol) * 2) : PP_OOR;
     }
   };
-  // The bias of a unit is fetched ONE PHASE AHEAD by an inline-asm ds_read pair the compiler does not see: behind the LDS-DMA builtins it
+  // The bias quad of a half is fetched ONE PHASE AHEAD by an inline-asm ds_read the compiler does not see: behind the LDS-DMA builtins it
   // puts s_waitcnt vmcnt(0) in front of any read of the bias image (it cannot tell the image from the K-tile ring), which drains the
-  // ring once per phase.  The phase-end wait (lgkmcnt(0), naming the two destinations so they stay opaque until then) retires the pair.
-  f32x4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = {0.f, 0.f, 0.f, 0.f};
-  auto fetch = [&](auto u_c, unsigned base) {           // columns (c*32 + 8 g + 4 hi + e), g = h2 and h2 + 2, of the image at `base`
-    constexpr int u = decltype(u_c)::value;
-    if constexpr (u >= 0) {
-      constexpr int c = (u >> 1) & 1, h2 = u & 1;
-      const unsigned addr = base + (unsigned)((c * 32 + 8 * h2) * 4);
-      pp_lds_read2(bq0, bq1, addr);
+  // ring once per phase.  The phase-end wait (lgkmcnt(0), naming the destinations so they stay opaque until then) retires the reads.
+  f32x4 bqa = {0.f, 0.f, 0.f, 0.f}, bqb = {0.f, 0.f, 0.f, 0.f};     // bias of the next phase's first / second half
+  unsigned keep0 = 0u, keep1 = 0u;                                  // packed group of the unit in progress (part 0)
+  auto fetch = [&](auto h_c, f32x4& bq, unsigned base) {            // columns c*32 + 8 g + 4 hi + e of the image at `base`
+    constexpr int h = decltype(h_c)::value;
+    if constexpr (h >= 0) {
+      constexpr int u = h >> 1, c = (u >> 1) & 1, g = 2 * (u & 1) + (h & 1);
+      pp_lds_read1(bq, base + (unsigned)((c * 32 + 8 * g) * 4));
     }
   };
-  auto drain = [&](auto u_c) {
-    constexpr int u = decltype(u_c)::value;
-    if constexpr (u >= 0) {
-      constexpr int i = u >> 2, c = (u >> 1) & 1, h2 = u & 1;
+  auto half = [&](auto h_c, const f32x4& bq) {
+    constexpr int h = decltype(h_c)::value;
+    if constexpr (h >= 0) {
+      constexpr int u = h >> 1, part = h & 1, i = u >> 2, c = (u >> 1) & 1, h2 = u & 1, g = 2 * h2 + part;
       // (no "is there a finished tile" branch: before the first one `prev` holds zeros and crow is out of range -- the store is dropped;
       //  a branch would end the phase's scheduling region in front of the drain and push it behind the MFMAs)
       const f32x16& a = prev[i][c];
-      f32x2 o00 = {a[4 * h2] + bq0[0], a[4 * h2 + 1] + bq0[1]}, o01 = {a[4 * h2 + 2] + bq0[2], a[4 * h2 + 3] + bq0[3]};
-      f32x2 o10 = {a[4 * (h2 + 2)] + bq1[0], a[4 * (h2 + 2) + 1] + bq1[1]}, o11 = {a[4 * (h2 + 2) + 2] + bq1[2], a[4 * (h2 + 2) + 3] + bq1[3]};
-      if constexpr (ACT == DU_ACT_GELU) { o00 = gelu_pk(o00); o01 = gelu_pk(o01); o10 = gelu_pk(o10); o11 = gelu_pk(o11); }
-      const bf16x2 t0 = {(bf16_t)o00.x, (bf16_t)o00.y}, t1 = {(bf16_t)o01.x, (bf16_t)o01.y};
-      const bf16x2 t4 = {(bf16_t)o10.x, (bf16_t)o10.y}, t5 = {(bf16_t)o11.x, (bf16_t)o11.y};
-      unsigned k0 = __builtin_bit_cast(unsigned, t0), k1 = __builtin_bit_cast(unsigned, t1);
-      unsigned k4 = __builtin_bit_cast(unsigned, t4), k5 = __builtin_bit_cast(unsigned, t5);
-      pp_swap_halves(k0, k4);        // lanes 0-31: (own group h2 | partner's group h2) = columns 8 h2 .. + 7;
-      pp_swap_halves(k1, k5);        // lanes 32-63: (partner's group h2 + 2 | own) = columns 16 + 8 h2 .. + 7
-      const u32x4_t v = {k0, k1, k4, k5};
-      const unsigned off = pcol + c * 32 + 8 * h2 < nlim ? crow[i] + (unsigned)((c * 32 + 8 * h2) * 2) : PP_OOR;
-      __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
+      f32x2 o0 = {a[4 * g] + bq[0], a[4 * g + 1] + bq[1]}, o1 = {a[4 * g + 2] + bq[2], a[4 * g + 3] + bq[3]};
+      // (packed fp32: a one-element-at-a-time form on plain v_fma_f32 -- the micro-architecture guide prices a packed operation beside MFMAs
+      //  at +22 cycles -- measured SLOWER here, 87.0 vs 84.5 us on the fc1 product, profiles/r05_gemm_p8_table_v3.txt: 11 instead of 7
+      //  instructions per element at two waves per SIMD)
+      if constexpr (ACT == DU_ACT_GELU) { o0 = gelu_pk(o0); o1 = gelu_pk(o1); }
+      const bf16x2 t0 = {(bf16_t)o0.x, (bf16_t)o0.y}, t1 = {(bf16_t)o1.x, (bf16_t)o1.y};
+      if constexpr (part == 0) {
+        keep0 = __builtin_bit_cast(unsigned, t0); keep1 = __builtin_bit_cast(unsigned, t1);
+      } else {
+        unsigned k4 = __builtin_bit_cast(unsigned, t0), k5 = __builtin_bit_cast(unsigned, t1);
+        pp_swap_halves(keep0, k4);     // lanes 0-31: (own group 2 h2 | partner's group 2 h2) = columns 16 h2 .. + 7;
+        pp_swap_halves(keep1, k5);     // lanes 32-63: (partner's group 2 h2 + 1 | own) = columns 16 h2 + 8 .. + 15: 32 contiguous bytes per row
+        const u32x4_t v = {keep0, keep1, k4, k5};
+        const unsigned off = pcol + c * 32 + 16 * h2 < nlim ? crow[i] + (unsigned)((c * 32 + 16 * h2) * 2) : PP_OOR;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rc, off, 0, 0);
+      }
     }
   };
   auto finish6 = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    pp_wait_lds(bq0, bq1);
+    if constexpr (SPREAD == 4) pp_wait_lds(bqa, bqb); else pp_wait_lds1(bqa);      // (SPREAD 8 has one half per phase: bqb does not exist)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
 
   // one K-step.  p: fragment set of this K-tile's B; kofs: byte offset (inside the operand rows) of the K-tile requested now (the staged
-  // tile's); D0 / D1: drain unit of the two phases (-1: none), F0 / F1: unit whose bias is fetched at the end of phase 0 / 1 (for the
-  // next phase) from the image at fbase; CP1: prev[1] <- acc[1] in phase 0 (first K-step of a tile, before its phase 1 restarts acc[1]);
-  // CP0: prev[0] <- acc[0] in phase 1 (last K-step of a tile: acc[0] is final after phase 0)
-  auto kstep = [&](auto par_c, auto first_c, auto d0_c, auto d1_c, auto f0_c, auto f1_c, auto cp1_c, auto cp0_c, int bc, int bn, int bnn, unsigned kofs,
-                   unsigned fbase) {
+  // tile's); HA0 / HB0 (HA1 / HB1): the halves drained in phase 0 (1), -1 = none; the bias of the NEXT phase's halves is fetched at the end
+  // of a phase (phase 1 fetches NA / NB = the following K-step's phase-0 halves) from the image at fbase; CP1: prev[1] <- acc[1] in phase
+  // 0 (first K-step of a tile, before its phase 1 restarts acc[1]); CP0: prev[0] <- acc[0] in phase 1 (last K-step: acc[0] is final)
+  auto kstep = [&](auto par_c, auto first_c, auto ha0, auto hb0, auto ha1, auto hb1, auto na, auto nb, auto cp1_c, auto cp0_c, int bc, int bn,
+                   int bnn, unsigned kofs, unsigned fbase) {
     constexpr int p = decltype(par_c)::value;
     // phase 0
     readA(IC<1>{}, bc);
     stage(IC<0>{}, bnn, kofs); stage(IC<2>{}, bnn, kofs);
     if constexpr (decltype(cp1_c)::value) { prev[1][0] = acc[1][0]; prev[1][1] = acc[1][1]; }
     mma(IC<0>{}, IC<p>{}, first_c);
-    drain(d0_c);
+    half(ha0, bqa); half(hb0, bqb);
     pin(IC<4>{}, IC<4>{});
     __builtin_amdgcn_sched_barrier(0);
-    fetch(f0_c, fbase);
+    fetch(ha1, bqa, fbase); fetch(hb1, bqb, fbase);
     finish6();
     // phase 1
     readA(IC<0>{}, bn); readB(IC<1 - p>{}, bn);
     stage(IC<1>{}, bnn, kofs);
     if constexpr (decltype(cp0_c)::value) { prev[0][0] = acc[0][0]; prev[0][1] = acc[0][1]; }
     mma(IC<1>{}, IC<p>{}, first_c);
-    drain(d1_c);
+    half(ha1, bqa); half(hb1, bqb);
     pin(IC<12>{}, IC<2>{});
     __builtin_amdgcn_sched_barrier(0);
-    fetch(f1_c, fbase);
+    fetch(na, bqa, fbase); fetch(nb, bqb, fbase);
     finish6();
   };
   using T_ = IC<1>; using F_ = IC<0>; using N_ = IC<-1>;
+  // drain K-step j of the schedule: SPREAD 4 -> phase 0 halves (4 j, 4 j + 1), phase 1 (4 j + 2, 4 j + 3); SPREAD 8 -> (2 j), (2 j + 1)
+  auto dstep = [&](auto j_c, auto par_c, int bc_, int bn_, int bnn_, unsigned kofs) {
+    constexpr int j = decltype(j_c)::value;
+    constexpr int last = SPREAD - 1;
+    if constexpr (SPREAD == 4)
+      kstep(par_c, IC<(j == 0)>{}, IC<4 * j>{}, IC<4 * j + 1>{}, IC<4 * j + 2>{}, IC<4 * j + 3>{}, IC<(j < last ? 4 * j + 4 : -1)>{},
+            IC<(j < last ? 4 * j + 5 : -1)>{}, IC<(j == 0)>{}, F_{}, bc_, bn_, bnn_, kofs, pbias);
+    else
+      kstep(par_c, IC<(j == 0)>{}, IC<2 * j>{}, N_{}, IC<2 * j + 1>{}, N_{}, IC<(j < last ? 2 * j + 2 : -1)>{}, N_{}, IC<(j == 0)>{}, F_{}, bc_, bn_,
+            bnn_, kofs, pbias);
+  };
 
   // ---- this workgroup's first tile: the only prologue (K-tiles 0 and 1) ----
   int tile = lin;
@@ -1719,28 +1737,36 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   int slot = 0;
   auto rot2 = [&]() { const int o = bc; bc = bnn; bnn = bn; bn = o; };      // advance two K-tiles: (bc, bn, bnn) <- (bnn, bc, bn)
   for (;;) {
-    // K-steps 0 .. 3: the previous tile drains (unit 0's bias was fetched by the last phase of that tile)
-    kstep(IC<0>{}, T_{}, IC<0>{}, IC<1>{}, IC<1>{}, IC<2>{}, T_{}, F_{}, bc, bn, bnn, 2u * 128u, pbias);
-    kstep(IC<1>{}, F_{}, IC<2>{}, IC<3>{}, IC<3>{}, IC<4>{}, F_{}, F_{}, bn, bnn, bc, 3u * 128u, pbias);
+    // K-steps 0 .. SPREAD - 1: the previous tile drains (the bias of its first halves was fetched by the last phase of that tile)
+    dstep(IC<0>{}, IC<0>{}, bc, bn, bnn, 2u * 128u);
+    dstep(IC<1>{}, IC<1>{}, bn, bnn, bc, 3u * 128u);
     rot2();
-    kstep(IC<0>{}, F_{}, IC<4>{}, IC<5>{}, IC<5>{}, IC<6>{}, F_{}, F_{}, bc, bn, bnn, 4u * 128u, pbias);
-    kstep(IC<1>{}, F_{}, IC<6>{}, IC<7>{}, IC<7>{}, N_{}, F_{}, F_{}, bn, bnn, bc, 5u * 128u, pbias);
+    dstep(IC<2>{}, IC<0>{}, bc, bn, bnn, 4u * 128u);
+    dstep(IC<3>{}, IC<1>{}, bn, bnn, bc, 5u * 128u);
     rot2();
-    int t = 4;
+    if constexpr (SPREAD == 8) {
+      dstep(IC<4>{}, IC<0>{}, bc, bn, bnn, 6u * 128u);
+      dstep(IC<5>{}, IC<1>{}, bn, bnn, bc, 7u * 128u);
+      rot2();
+      dstep(IC<6>{}, IC<0>{}, bc, bn, bnn, 8u * 128u);
+      dstep(IC<7>{}, IC<1>{}, bn, bnn, bc, 9u * 128u);
+      rot2();
+    }
+    int t = SPREAD;
     for (; t + 2 < nk; t += 2) {
-      kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, (unsigned)(t + 2) * 128u, 0u);
-      kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bn, bnn, bc, (unsigned)(t + 3) * 128u, 0u);
+      kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, (unsigned)(t + 2) * 128u, 0u);
+      kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bn, bnn, bc, (unsigned)(t + 3) * 128u, 0u);
       rot2();
     }
     // the last two K-steps request K-tiles 0 and 1 of the NEXT tile (out of range behind the last one); the very last phase fetches the
-    // bias of drain unit 0 of THIS tile (its image: slot `slot`)
+    // bias of the first halves of THIS tile (its image: slot `slot`)
     const int next = tile + G;
     set_stage_tile(next, slot ^ 1);
     pbias = lds_base + PP_BIAS_OFF + (unsigned)(slot * 512 + (wn * 64 + 4 * hi) * 4);
-    kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, 0u, 0u);
-    kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, IC<0>{}, F_{}, T_{}, bn, bnn, bc, 128u, pbias);
+    kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, 0u, 0u);
+    kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, IC<0>{}, IC<(SPREAD == 4 ? 1 : -1)>{}, F_{}, T_{}, bn, bnn, bc, 128u, pbias);
     rot2();
-    set_prev_tile(tile, slot);
+    set_prev_tile(tile);
     slot ^= 1;
     tile = next;
     if (tile >= ntiles) break;
@@ -1748,14 +1774,20 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   // ---- the last tile drains in the open ----
   prev[1][0] = acc[1][0]; prev[1][1] = acc[1][1];
   if (P.dbg & 2) return;
-  auto last = [&](auto u_c) {          // unit u (its bias is in flight or landed), then the fetch of unit u + 1
-    pp_wait_lds(bq0, bq1);
+  auto last = [&](auto h_c) {          // half h (its bias is in bqa when h is even or SPREAD == 8, else bqb), then the fetch of the half after the next
+    constexpr int h = decltype(h_c)::value;
+    if constexpr (SPREAD == 4) pp_wait_lds(bqa, bqb); else pp_wait_lds1(bqa);
     __builtin_amdgcn_sched_barrier(0);
-    drain(u_c);
+    if constexpr (SPREAD == 4 && (h & 1)) half(h_c, bqb); else half(h_c, bqa);
     __builtin_amdgcn_sched_barrier(0);
-    fetch(IC<(decltype(u_c)::value < 7 ? decltype(u_c)::value + 1 : -1)>{}, pbias);
+    if constexpr (SPREAD == 4) {
+      if constexpr (h & 1) { fetch(IC<(h + 1 < 16 ? h + 1 : -1)>{}, bqa, pbias); fetch(IC<(h + 2 < 16 ? h + 2 : -1)>{}, bqb, pbias); }
+    } else {
+      fetch(IC<(h + 1 < 16 ? h + 1 : -1)>{}, bqa, pbias);
+    }
   };
   last(IC<0>{}); last(IC<1>{}); last(IC<2>{}); last(IC<3>{}); last(IC<4>{}); last(IC<5>{}); last(IC<6>{}); last(IC<7>{});
+  last(IC<8>{}); last(IC<9>{}); last(IC<10>{}); last(IC<11>{}); last(IC<12>{}); last(IC<13>{}); last(IC<14>{}); last(IC<15>{});
 }
 
 int g_p8_mode = -1;      // -1: heuristic, 0: off, 1: 256 x 256 wherever legal, 2: 256 x 128 wherever legal, 3: the 4-wave 256 x 128 kernel wherever legal
@@ -1763,8 +1795,9 @@ int g_p8_sched = 1;
 int g_p8_corun = 1;      // du_set_option key 9: independent products the caller keeps in flight on different streams (the frozen ViT run as
                          // two half-batch chains): the tile choice then counts rounds on 256 / corun CUs -- a product that fills half the chip
                          // alone is a full round beside its twin
-int g_p8_persist = 0;    // du_set_option key 10: 0 = never, 1 = the persistent 256 x 128 kernel where its epilogue / shape rules hold and a CU gets
-                         // >= 2 tiles, 2 = wherever legal
+int g_p8_persist = 1;    // du_set_option key 10: 0 = never, 1 = the persistent 256 x 128 kernel where its epilogue / shape rules hold and a CU gets
+                         // >= 2 tiles (default), 2 = wherever legal
+int g_p8_pp_full = 0;    // du_set_option key 11 (A-B aid): 1 = the persistent kernel always launches min(tiles, 256) workgroups, co-running or not
 int g_p8_group = 4;
 int g_p8_debug = 0;      // bit 0: skip the bf16 global stores, bit 1: skip the whole epilogue (timing ablations only)
 
@@ -1794,21 +1827,23 @@ int launch_p8(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
 }
 
 // persistent 256 x 128 kernel: G = min(tiles, CUs this product can count on) workgroups, each walks tiles w, w + G, ...
-template <int SCHED>
 int launch_pp(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
   GemmParams P = make_params(a, DU_PLAIN_ROW, DU_PLAIN_ROW, PBM, NBN, PBK);
   P.tiles_m = (a.M + PBM - 1) / PBM;
   P.group_m = g_p8_group;
   P.dbg = g_p8_debug;
   const long ntiles = (long)P.tiles_m * P.tiles_n;
-  const long cus = 256 / g_p8_corun;
+  const long cus = g_p8_pp_full ? 256 : 256 / g_p8_corun;
   P.main_wgs = (int)(ntiles < cus ? ntiles : cus);
   dim3 grid(P.main_wgs, 1);
   if (tail_rows > 0) {
     P.tail_rows = tail_rows;
     grid.x += (a.N + SK_BN - 1) / SK_BN;
   }
-  void (*kfn)(GemmParams) = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, SCHED> : gemm_nt_pp_kernel<DU_ACT_NONE, SCHED>;
+  // drain schedule: the 16 half-units of a finished tile over 8 K-steps where the tile has them to spare (K >= 768), else over 4
+  // (SPREAD = 8, one half-unit per phase over eight K-steps, was built for the GELU drain and measured the same as 4 -- 77.8 vs 77.6 us on
+  //  fc1, profiles/r05_gemm_p8_table_v2.txt -- at 256 registers; only the 4-K-step schedule is instantiated)
+  void (*kfn)(GemmParams) = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, 4> : gemm_nt_pp_kernel<DU_ACT_NONE, 4>;
   static bool attr_set[2] = {false, false};
   const int ai = a.act == DU_ACT_GELU ? 1 : 0;
   if (!attr_set[ai]) {
@@ -1880,6 +1915,7 @@ extern "C" int du_set_option(int key, int value) {
     case 5: g_p8_tn = value; return DU_OK;
     case 9: g_p8_corun = value < 1 ? 1 : (value > 8 ? 8 : value); return DU_OK;
     case 10: g_p8_persist = value; return DU_OK;
+    case 11: g_p8_pp_full = value; return DU_OK;
     default: return DU_ERR_BAD_ARG;
   }
 }
@@ -1948,12 +1984,22 @@ int du_gemm_p8_choice(const du_gemm_args& a) {
   const long t256 = tm * ((a.N + 255) / 256) * batch, t128 = tm * ((a.N + 127) / 128) * batch;
   const long cus = 256 / g_p8_corun;           // CUs this product can count on (co-running products share the chip)
   if (t128 * g_p8_corun < 192) return 0;
-  if (g_p8_persist && pp_legal(a) && (g_p8_persist > 1 || t128 >= 2 * cus)) return 4;
   // (round 4: at K = 1024 the narrow tile's fixed costs -- prologue, exposed epilogue -- weigh more: 3 rounds of 256 x 128 tiles cost 62.8-67.6 us
   //  against 62.8-63.5 us for 2 rounds of 256 x 256 on the 8192 / 8232 x 3072 qkv product, ratio 0.66-0.72 per round, not 0.56)
   const double c256 = (double)((t256 + cus - 1) / cus) * 1.0, c128 = (double)((t128 + cus - 1) / cus) * (a.K >= 1024 ? 0.68 : 0.56);
   // (>= 128 tiles since round 3: the tall products of the adapter with ONE 256-wide tile column -- 43008 x {192, 256} x 1024 -- read their A
   //  operand once with the 256 x 256 tile and twice with two half-empty 128-wide columns: 31.8 / 32.6 us against 34.7 / 37.3 us)
+  // (round 5) the persistent kernel walks ceil(t128 / CUs) narrow tiles per workgroup and pays prologue / epilogue once: a tile costs it
+  // 0.53 of what a ROUND of 256 x 256 tiles costs the kernels above (0.49 against their exposed GELU epilogue, 0.45 at K <= 512 where the
+  // fixed costs weigh more) -- qkv 3 tiles against 2 rounds (56.9 vs 62.7 us), fc1 4 against 2 (77.8 vs 81.3), the adapter's 43008 x 1024
+  // x 512 six against three (56.3 vs 66.8); FAPM's 131072 x 512 x 1024 (8 tiles against 4 full rounds: 161 vs 141 us) and the big
+  // square / 7B products stay on the wide tile (profiles/r05_gemm_p8_table_v2.txt)
+  if (g_p8_persist && pp_legal(a)) {
+    const double r = a.K <= 512 ? 0.45 : (a.act == DU_ACT_GELU ? 0.49 : 0.53);
+    const double cpp = (double)((t128 + cus - 1) / cus) * r;
+    const double best = (t256 * g_p8_corun >= 128 && c256 <= c128) ? c256 : c128;
+    if (g_p8_persist > 1 || (t128 >= 2 * cus && cpp < best)) return 4;
+  }
   if (t256 * g_p8_corun >= 128 && c256 <= c128) return 1;
   return 2;
 }
@@ -1970,7 +2016,7 @@ int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st, int tail_rows) {
   if (a.a_mode == DU_IM2COL_ROW) return g_p8_sched ? launch_p8<bf16_t, 1, false, true>(a, st) : launch_p8<bf16_t, 0, false, true>(a, st);
   const bool bf = a.out_dtype == DU_BF16;
   const int tr = tail_rows;
-  if (c == 4) return g_p8_sched ? launch_pp<1>(a, st, tr) : launch_pp<0>(a, st, tr);
+  if (c == 4) return launch_pp(a, st, tr);
   if (c == 3) return bf ? launch_p4<bf16_t>(a, st, tr) : launch_p4<float>(a, st, tr);
   if (c == 1) {
     if (bf) return g_p8_sched ? launch_p8<bf16_t, 1, false>(a, st, tr) : launch_p8<bf16_t, 0, false>(a, st, tr);
@@ -1984,7 +2030,10 @@ int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st, int tail_rows) {
 // rows put every load of the tail on the same few memory channels, gemm_skinny.hip), plain store, no gate epilogue
 bool du_gemm_p8_tail_ok(const du_gemm_args& whole, int r) {
   static const bool off = getenv("DU_P8_NO_TAIL") != nullptr;      // debugging / A-B aid
-  static const int kmax = getenv("DU_SKINNY_FUSE_KMAX") ? atoi(getenv("DU_SKINNY_FUSE_KMAX")) : 2048;
+  // (round 5: 4096 -- fc2's 40 tail rows inside its launch instead of the partial + finish kernel pair: +0.6 % step rate on one box, three
+  //  interleaved rounds, profiles/r05_ab_tail_fuse_v1.txt; alone the fused K = 4096 tail is slower than the pair, 21 vs 14 us, but here it
+  //  runs beside the stragglers of the tile grid and two ~5 us launch slots per block go away)
+  static const int kmax = getenv("DU_SKINNY_FUSE_KMAX") ? atoi(getenv("DU_SKINNY_FUSE_KMAX")) : 4096;
   if (off || r < 1 || r > 64 || whole.K > kmax || whole.K % SK_CHUNK || whole.N % 4 || whole.batch > 1) return false;
   if (whole.store_mode != DU_STORE_PLAIN || whole.act == DU_ACT_SWIGLU || whole.a_mode != DU_PLAIN_ROW || whole.b_mode != DU_PLAIN_ROW) return false;
   return 8 * 64 * (SK_BN + 1) * 4 <= P8_LDS;

@@ -357,16 +357,21 @@ class DINOv3_Adapter(nn.Module):
         # The frozen backbone is launched FIRST (ADP:422-426): with `backbone.chains` > 1 it runs as half-batch chains on side streams and the
         # spatial prior module below -- independent of it (ADP:412-415), HBM-bound where the ViT is MFMA-bound -- runs beside them on this
         # stream; `vit()` joins the chains.  (chains <= 1: the backbone simply runs before the prior module; same results either way.)
-        vit = self.backbone.begin_intermediate_layers(x, n=self.interaction_indexes, return_class_token=True, dtype=dt)
-        if not getattr(self.backbone, "overlap_prior", True):
-            vit_out = vit()                                 # (A-B aid: join at once, the prior module runs behind the backbone)
-            vit = lambda: vit_out
+        chained = getattr(self.backbone, "chains", 1) > 1
+        if chained:
+            vit = self.backbone.begin_intermediate_layers(x, n=self.interaction_indexes, return_class_token=True, dtype=dt)
+            if not getattr(self.backbone, "overlap_prior", True):
+                vit_out = vit()                             # (A-B aid: join at once, the prior module runs behind the backbone)
+                vit = lambda: vit_out
         x8 = ops.nchw_to_nhwc(x, dt, 8)
         c1, c2, c3, c4 = self.spm(x8, self.level_embed, group)                              # ADP:412-413
         n2, n3 = c2.shape[1], c3.shape[1]
         c = torch.cat([c2, c3, c4], dim=1)                                                   # ADP:415
 
-        layers = vit()
+        if chained:
+            layers = vit()
+        else:       # one chain on this stream: the reference's order (prior module, then the backbone, ADP:412-426)
+            layers = self.backbone.get_intermediate_layers(x, n=self.interaction_indexes, return_class_token=True, dtype=dt)
 
         for i, layer in enumerate(self.interactions):                                       # ADP:444-457
             xi, _cls = layers[i]

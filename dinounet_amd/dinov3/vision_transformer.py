@@ -176,12 +176,15 @@ class DinoVisionTransformer(nn.Module):
         self.mask_token = nn.Parameter(torch.empty(1, embed_dim))
         self._cache = None
         self._ws = {}
-        # Two half-batch chains on two side HIP streams (round 5).  The blocks of a frozen ViT are a strictly sequential chain of
+        # Half-batch chains on side HIP streams (round 5).  The blocks of a frozen ViT are a strictly sequential chain of
         # launches, each with one workgroup per CU (128-147 KB of LDS): every launch boundary drains the chip -- cold prologue burst of 256
         # workgroups at once, a ragged last round (qkv: 1.5 rounds of 256 x 256 tiles), an exposed epilogue.  The samples of a batch are
         # independent, so the same work as TWO chains lets the dispatcher fill the CUs one chain leaves idle with the other chain's
-        # workgroups; nothing else changes (same kernels, same arithmetic per sample).  0 / 1 = one chain on the caller's stream.
-        self.chains = int(os.environ.get("DINOUNET_VIT_CHAINS", "2"))
+        # workgroups; nothing else changes (same kernels, same arithmetic per sample).  Measured (profiles/r05_ab_*): the backbone alone
+        # 9.21 -> 8.68 ms, the train step + 1.2 % -- the same + 1 % the persistent GEMM kernel (gemm_nt_pp_kernel) brings by removing the
+        # per-launch costs at the source, and the two do not add (two half-chip persistent launches side by side lose).  The kernel route
+        # ships; the chains stay available: DINOUNET_VIT_CHAINS=2, or `backbone.chains = 2`.  0 / 1 = one chain on the caller's stream.
+        self.chains = int(os.environ.get("DINOUNET_VIT_CHAINS", "1"))
         self.overlap_prior = os.environ.get("DINOUNET_VIT_OVERLAP_PRIOR", "1") != "0"     # the adapter's prior module beside the chains
         self._chain_streams = {}
         self._chain_ws = {}

@@ -451,7 +451,7 @@ def test_gemm_dispatch_host_logic_without_gpu():
     from dinounet_amd._lib import (DU_BF16, DU_F32, IM2COL_COL, IM2COL_ROW, PLAIN_COL, PLAIN_ROW, ConvGeom, GemmArgs)
     L = _lib.lib()
 
-    def route(M, N, K, am=PLAIN_ROW, bm=PLAIN_ROW, dt=DU_BF16, od=DU_BF16, split=1, geom=None, lda=None, ldb=None, row_scale=False):
+    def route(M, N, K, am=PLAIN_ROW, bm=PLAIN_ROW, dt=DU_BF16, od=DU_BF16, split=1, geom=None, lda=None, ldb=None, row_scale=False, act=0):
         a = GemmArgs()
         a.dtype, a.out_dtype, a.a_mode, a.b_mode = dt, od, am, bm
         a.M, a.N, a.K = M, N, K
@@ -460,20 +460,30 @@ def test_gemm_dispatch_host_logic_without_gpu():
         a.ldb = ldb or (K if bm == PLAIN_ROW else N)
         a.ldc = N
         a.batch, a.split_k, a.alpha = 1, split, 1.0
+        a.act = act
         if row_scale:
             a.row_scale, a.rs_rows = 0x400000, 5376
         if geom is not None:
             a.geom = geom
         return int(L.du_gemm_route(C.byref(a))), int(L.du_gemm_ws_elems(C.byref(a)))
 
-    # frozen ViT-L, M = 8 * 1029 tokens: 256 x 128 tiles for proj / fc2, 256 x 256 for fc1 and (round 4: 2 rounds of wide tiles beat 3 of
-    # narrow ones at K = 1024, tools/gemm_p8_bench.py) qkv; K = 768 keeps the narrow tile; the 40 ragged rows leave the tile grid
-    assert route(8232, 3072, 1024)[0] == 3 and route(8232, 4096, 1024)[0] == 3 and route(8232, 2304, 768)[0] == 4
+    # frozen ViT-L, M = 8 * 1029 tokens: 256 x 128 tiles for proj / fc2 (fp32 result + residual: one tile per CU); round 5: the PERSISTENT
+    # 256 x 128 kernel (6) for the bf16 products whose narrow tiles come out at >= 2 per CU and cheaper than rounds of wide tiles -- qkv
+    # (3 tiles against 2 rounds), fc1 with its GELU (4 against 2), ViT-B's K = 768 products; without the GELU the 8232 x 4096 x 1024 product
+    # keeps 2 rounds of 256 x 256 tiles (3), and so do the big square products; the 40 ragged rows leave the tile grid
+    ACT_GELU = 1
+    assert route(8232, 3072, 1024)[0] == 6 and route(8232, 4096, 1024, act=ACT_GELU)[0] == 6 and route(8232, 2304, 768)[0] == 6
+    assert route(8232, 4096, 1024)[0] == 3 and route(4096, 4096, 4096)[0] == 3 and route(131072, 512, 1024)[0] == 3
     assert route(8232, 1024, 4096, od=DU_F32)[0] == 4 and route(8232, 1024, 1024, od=DU_F32)[0] == 4
     assert route(8232, 3072, 1024)[1] > 0 and route(8192, 3072, 1024)[1] == 0
+    try:                      # du_set_option(10, 0): the round-4 choice
+        L.du_set_option(10, 0)
+        assert route(8232, 3072, 1024)[0] == 3 and route(8232, 4096, 1024, act=ACT_GELU)[0] == 3 and route(8232, 2304, 768)[0] == 4
+    finally:
+        L.du_set_option(10, 1)
     # adapter / FAPM linears: K = 192 is not a multiple of 128 -> direct-to-LDS 128 x 128; few tiles -> not the multi-phase kernels
     assert route(43008, 1024, 192)[0] == 2 and route(2048, 256, 256)[0] == 2
-    assert route(43008, 1024, 512)[0] in (3, 4) and route(131072, 512, 1024)[0] == 3
+    assert route(43008, 1024, 512)[0] == 6 and route(43008, 1024, 256)[0] == 3 and route(43008, 192, 1024)[0] == 3
     # weight gradients: short splits stay on the 128 x 128 engine (atomics per workgroup), long ones go to the multi-phase TN form;
     # a DropPath row scale on the contraction rows is implemented by the 128 x 128 engine only
     assert route(1024, 512, 43008, PLAIN_COL, PLAIN_COL, od=DU_F32, split=16)[0] == 1

@@ -76,14 +76,20 @@ def test_gemm_plain_epilogues(dt, M, N, K):
     assert rel(y, (x @ w.t() + b) * gam + res) < TOL[dt]
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 4])
 @pytest.mark.parametrize("M,N,K,f32out,epi", [(8232, 3072, 1024, False, "bias"), (8232, 4096, 1024, False, "gelu"),
                                               (8232, 1024, 4096, True, "ls_res"), (8232, 1024, 1024, True, "ls_res"),
-                                              (1000, 516, 512, True, "bias"), (768, 640, 384, False, "none"), (2048, 384, 1536, False, "rs")])
+                                              (1000, 516, 512, True, "bias"), (768, 640, 384, False, "none"), (2048, 384, 1536, False, "rs"),
+                                              # the persistent kernel's own corners (mode 4; the other modes run them as ordinary shapes): several
+                                              # tiles per workgroup with ragged last tile rows AND columns, K at its lower limit (drain over 4
+                                              # K-steps) and above 768 with GELU (drain over 8), no bias, one tile per workgroup
+                                              (70000, 264, 512, False, "bias"), (33000, 1000, 896, False, "gelu"), (33000, 1000, 640, False, "gelu"),
+                                              (43008, 1024, 512, False, "none"), (5000, 136, 2048, False, "bias")])
 def test_gemm_multiphase_nt(mode, M, N, K, f32out, epi):
-    """256 x 256 (mode 1) and 256 x 128 (mode 2) multi-phase NT kernels (gemm_p8.hip) forced through du_set_option, on the ViT-L
-    products and ragged shapes: full-matrix check against the fp32 product of the same bf16 operands, every epilogue the ViT uses, and
-    a repeat-run screen (the kernels are deterministic: a run-to-run difference is a pipeline race)."""
+    """256 x 256 (mode 1), 256 x 128 (mode 2) and persistent 256 x 128 (mode 4, round 5; where its epilogue rules do not hold the library
+    runs the mode-2 kernel) multi-phase NT kernels (gemm_p8.hip) forced through du_set_option, on the ViT-L products and ragged shapes:
+    full-matrix check against the fp32 product of the same bf16 operands, every epilogue the ViT uses, and a repeat-run screen (the
+    kernels are deterministic: a run-to-run difference is a pipeline race)."""
     from dinounet_amd import ops, _lib
     from dinounet_amd._lib import ACT_GELU
     d = dev()
@@ -121,6 +127,15 @@ def test_gemm_multiphase_nt(mode, M, N, K, f32out, epi):
     assert rel(outs[0], ref) < (2e-4 if f32out and epi != "ls_res" else TOL[bf])
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), "run-to-run difference: pipeline race"
+    if mode == 4 and not f32out and epi in ("bias", "none"):
+        # same K order, same epilogue arithmetic: the persistent kernel's tiles are bit-identical to the 256 x 128 kernel's (the ragged rows
+        # behind the last full tile take the same K-parallel tail program in both)
+        try:
+            L.du_set_option(0, 2)
+            ref2 = ops.mm(x, w, out=torch.empty((M, N), dtype=od, device=d), **kw).float()
+        finally:
+            L.du_set_option(0, -1)
+        assert torch.equal(outs[0], ref2)
 
 
 @pytest.mark.parametrize("N,K", [(1024, 1024), (3072, 1024), (1024, 4096)])

@@ -87,7 +87,7 @@ def time_variants(rounds):
     rnd = lambda *s: torch.randn(*s, generator=g).to(dev).to(bf)
     variants = [("old128", dict(mode=0)), ("256x256", dict(mode=1)), ("256 nostore", dict(mode=1, debug=1)), ("256 noepi", dict(mode=1, debug=2)),
                 ("256x128", dict(mode=2)), ("128 nostore", dict(mode=2, debug=1)), ("128 noepi", dict(mode=2, debug=2)), ("128 nopre", dict(mode=2, debug=4)),
-                ("4wave", dict(mode=3)), ("4w noepi", dict(mode=3, debug=2)), ("persist", dict(mode=4)), ("pp nostore", dict(mode=4, debug=1)),
+                ("4wave", dict(mode=3)), ("4w noepi", dict(mode=3, debug=2)), ("persist", dict(mode=4)), ("pp nostore", dict(mode=4, debug=1)), 
                 ("auto", dict(mode=-1))]
     if "--quick" in sys.argv:
         variants = [v for v in variants if v[0] in ("256x256", "256x128", "256 noepi", "128 noepi", "persist", "pp nostore", "auto")]
