@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdinounet_hip.so")
-SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_glds.hip", "gemm_p8.hip", "gemm_skinny.hip", "conv_halo.hip", "conv_strip.hip", "attention.hip", "norm.hip", "msda.hip", "elementwise.hip", "loss.hip", "optim.hip", "augment.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_glds.hip", "gemm_p8.hip", "gemm_rk.hip", "gemm_skinny.hip", "conv_halo.hip", "conv_strip.hip", "attention.hip", "norm.hip", "msda.hip", "elementwise.hip", "loss.hip", "optim.hip", "augment.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc"]
 # per-source extras.  attention.hip: MFMA results straight into VGPRs (the softmax reads every S^T accumulator with VALU ops; in the
 # accumulator half of the register file each one costs a v_accvgpr_read and a second register: 194 -> 166 registers, 2 -> 3 waves / SIMD)
@@ -15,7 +15,7 @@ EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "conv_stri
 # kernels of these files must not use scratch: a register spill in a GEMM / attention / conv main loop or epilogue is a silent multi-ms
 # regression (seen: an address helper inlined into every epilogue put 576 bytes per lane of the 256 x 256 kernel on the stack, +7 ms per
 # step, all tests green).  The build reads hipcc's resource-usage remarks and fails on ScratchSize > 0 there.
-NO_SCRATCH = ("gemm_bf16.hip", "gemm_glds.hip", "gemm_p8.hip", "gemm_skinny.hip", "conv_halo.hip", "conv_strip.hip", "attention.hip")
+NO_SCRATCH = ("gemm_bf16.hip", "gemm_glds.hip", "gemm_p8.hip", "gemm_rk.hip", "gemm_skinny.hip", "conv_halo.hip", "conv_strip.hip", "attention.hip")
 REMARK = "-Rpass-analysis=kernel-resource-usage"
 # timing-ablation and cycle-probe instantiations of the attention kernel (tools/attn_ablate.py) may spill: they never run in the product
 import re as _re

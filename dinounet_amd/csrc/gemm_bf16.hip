@@ -441,6 +441,8 @@ bool du_gemm_p8_tail_ok(const du_gemm_args& whole, int r);
 bool du_gemm_p8_wants(const du_gemm_args& a);
 int du_gemm_p8_choice(const du_gemm_args& a);
 bool du_gemm_glds_serves(const du_gemm_args& a);              // gemm_glds.hip
+bool du_gemm_rk_serves(const du_gemm_args& a);                // gemm_rk.hip (short contractions, weights resident in LDS)
+int du_gemm_nt_rk(const du_gemm_args& a, hipStream_t st);
 int du_gemm_tn_p8(const du_gemm_args& a, hipStream_t st);     // gemm_p8.hip (weight gradients)
 int du_gemm_tn_p8_splits(const du_gemm_args& a);
 
@@ -500,6 +502,10 @@ int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
     int rc = du_gemm_tn_p8(a, st);
     if (rc != DU_ERR_UNSUPPORTED) return rc;
   }
+  if (du_gemm_rk_serves(a)) {        // K <= 256, tall M: the streaming kernel (any M: rows past the last full block are masked)
+    int rc = du_gemm_nt_rk(a, st);
+    if (rc != DU_ERR_UNSUPPORTED) return rc;
+  }
   {
     const int r = du_gemm_ragged_rows(a);
     if (r > 0 && a.ws && a.ws_elems >= du_gemm_skinny_ws_elems(a.N, a.K)) {
@@ -541,11 +547,13 @@ int du_gemm_bf16_fast(const du_gemm_args& a, hipStream_t st) {
 
 // which kernel family du_gemm runs for the bulk of this product (measurement tools name the kernel from this, not from a mirror of the
 // dispatch): 0 generic (gemm.hip), 1 bf16 tile engine (this file), 2 128 x 128 direct-to-LDS (gemm_glds.hip), 3 / 4 the 256 x 256 /
-// 256 x 128 multi-phase kernels (gemm_p8.hip), 5 the multi-phase weight-gradient kernel (gemm_p8.hip, TN form)
+// 256 x 128 multi-phase kernels (gemm_p8.hip), 5 the multi-phase weight-gradient kernel (gemm_p8.hip, TN form), 6 the persistent 256 x 128
+// kernel (gemm_p8.hip), 7 the resident-weights streaming kernel for K <= 256 (gemm_rk.hip)
 int du_gemm_route_bf16(const du_gemm_args& a) {
   if (a.dtype != DU_BF16) return 0;
   if (a.N % 4 || a.ldc % 4 || (((uintptr_t)a.C) & 15)) return 0;
   if (a.a_mode == DU_PLAIN_COL && du_gemm_tn_p8_splits(a)) return 5;
+  if (du_gemm_rk_serves(a)) return 7;
   du_gemm_args head = a;
   const int r = du_gemm_ragged_rows(a);
   if (r > 0) head.M = a.M - r;

@@ -1901,6 +1901,7 @@ int launch_p8_tn(const du_gemm_args& a, int splits, hipStream_t st) {
 // debugging / A-B knobs (within-process variant switching for tools/gemm_p8_bench.py); not part of the hot-path contract
 extern int g_attn_w;      // attention.hip
 extern int g_attn_impl, g_attn_thresh_log2, g_attn_var;
+extern int g_rk_mode;     // gemm_rk.hip
 
 extern "C" int du_set_option(int key, int value) {
   switch (key) {
@@ -1916,6 +1917,7 @@ extern "C" int du_set_option(int key, int value) {
     case 9: g_p8_corun = value < 1 ? 1 : (value > 8 ? 8 : value); return DU_OK;
     case 10: g_p8_persist = value; return DU_OK;
     case 11: g_p8_pp_full = value; return DU_OK;
+    case 12: g_rk_mode = value; return DU_OK;
     default: return DU_ERR_BAD_ARG;
   }
 }

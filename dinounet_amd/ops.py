@@ -134,7 +134,7 @@ _MODE_NAMES = {(0, 0): "linear", (0, 1): "linear_dgrad", (1, 1): "linear_wgrad",
 
 
 _ROUTE_NAMES = {0: "gemm_kernel", 1: "gemm_bf16_kernel", 2: "gemm_nt_glds_kernel", 3: "gemm_nt_p8_kernel", 4: "gemm_nt_p8n_kernel", 5: "gemm_tn_p8_kernel",
-                6: "gemm_nt_pp_kernel"}
+                6: "gemm_nt_pp_kernel", 7: "gemm_nt_rk_kernel"}
 
 
 _WGRAD_COLSUM = os.environ.get("DINOUNET_WGRAD_COLSUM", "1") == "1"     # bias gradients inside the weight-gradient kernels (A-B aid)
@@ -910,6 +910,20 @@ def conv3x3_halo(x, wp, bias, x2=None, want_stats=False):
     return y, part
 
 
+_CONV_SPLITK = os.environ.get("DINOUNET_CONV_SPLITK", "1") == "1"
+
+
+def _im2col_split(M, N, K):
+    """K splits for an implicit-GEMM convolution whose tile grid leaves most of the chip idle (the SPM's low-resolution stride-2 layers,
+    dinov3_adapter.py:259-277: 2048 x 256 x 2304 is 32 tiles of 128 x 128 with 36 serial K-steps each -- 79 us for 2.4 GFLOP).  The generic
+    engine's split-K form adds fp32 partial tiles into a zeroed buffer (no bias / activation: those layers have none); the caller converts
+    to bf16.  0 = leave the product alone."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if not _CONV_SPLITK or tiles > 128 or K < 1024:
+        return 0
+    return max(2, min(8, 256 // tiles, K // 256))
+
+
 def conv_fwd(x, wp, bias, KH, KW, stride, pad, x2=None, out=None, act=ACT_NONE):
     _req(x, wp)
     if KH == 3 and KW == 3 and stride == 1 and pad == 1 and out is None and act == ACT_NONE:
@@ -925,6 +939,13 @@ def conv_fwd(x, wp, bias, KH, KW, stride, pad, x2=None, out=None, act=ACT_NONE):
     if out is None:
         out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
     _, _, _, _, ldc = _nhwc(out)
+    sk = _im2col_split(B * Ho * Wo, Cout, Kc) if (x.dtype == torch.bfloat16 and bias is None and act == ACT_NONE and out.is_contiguous()) else 0
+    if sk:
+        acc = ZEROS.zeros((B * Ho * Wo, Cout), x.device)
+        gemm_raw(dtype=DU_BF16, out_dtype=DU_F32, a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * Ho * Wo, N=Cout, K=Kc, A=x.data_ptr(), lda=ld,
+                 B=wp.data_ptr(), ldb=ldb, Cmat=acc.data_ptr(), ldc=Cout, split_k=sk, geom=g)
+        _lib.check(_lib.lib().du_cast(DU_F32, DU_BF16, _p(acc), _p(out), acc.numel(), _st()), "du_cast")
+        return out
     gemm_raw(dtype=_code(x.dtype), out_dtype=_code(out.dtype), a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * Ho * Wo, N=Cout,
              K=Kc, A=x.data_ptr(), lda=ld, B=wp.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=ldc, bias=_dp(bias), act=act,
              geom=g)
@@ -940,6 +961,13 @@ def conv_dgrad(dy, wd, KH, KW, stride, pad, Hin, Win, out=None):
     if out is None:
         out = torch.empty((B, Hin, Win, Cin), dtype=dy.dtype, device=dy.device)
     _, _, _, _, ldc = _nhwc(out)
+    sk = _im2col_split(B * Hin * Win, Cin, Kc) if (dy.dtype == torch.bfloat16 and out.is_contiguous()) else 0
+    if sk:
+        acc = ZEROS.zeros((B * Hin * Win, Cin), dy.device)
+        gemm_raw(dtype=DU_BF16, out_dtype=DU_F32, a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * Hin * Win, N=Cin, K=Kc, A=dy.data_ptr(), lda=ld,
+                 B=wd.data_ptr(), ldb=ldb, Cmat=acc.data_ptr(), ldc=Cin, split_k=sk, geom=g)
+        _lib.check(_lib.lib().du_cast(DU_F32, DU_BF16, _p(acc), _p(out), acc.numel(), _st()), "du_cast")
+        return out
     gemm_raw(dtype=_code(dy.dtype), out_dtype=_code(out.dtype), a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * Hin * Win, N=Cin,
              K=Kc, A=dy.data_ptr(), lda=ld, B=wd.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=ldc, geom=g)
     return out

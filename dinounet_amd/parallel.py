@@ -167,12 +167,13 @@ class GradAllReducer:
                 if rec:
                     ev[1].record()
                 self.works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                # ProcessGroupNCCL runs an asynchronous collective on its OWN internal stream: an event recorded on `side` right after
-                # the call marks the end of the enqueue, not of the all-reduce (the round-4 timeline showed start -> done =
-                # 13 us for a 30 MB bucket).  Work.wait() is a stream-level dependency (no host block, capturable): `side` now trails the
-                # collective, so the "done" event below -- and finish()'s wait_stream(side) -- see its real end.
-                self.works[bi].wait()
                 if rec:
+                    # ProcessGroupNCCL runs an asynchronous collective on its OWN internal stream: an event recorded on `side` right
+                    # after the call marks the end of the enqueue, not of the all-reduce (the round-4 timeline showed start ->
+                    # done = 13 us for a 30 MB bucket).  Work.wait() is a stream-level dependency (no host block): `side` then trails
+                    # the collective and the "done" event sees its real end.  Only on the eager timeline steps: inside a hipGraph
+                    # capture the extra cross-stream edge made capture_end() fault (round 5), and finish() waits for the work anyway.
+                    self.works[bi].wait()
                     ev[2].record()
                     self.timeline.append((bi, ev))
         else:

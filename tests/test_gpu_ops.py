@@ -406,23 +406,33 @@ def nhwc(t):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("cfg", [dict(B=2, H=24, W=16, Cin=64, Cout=32, s=1), dict(B=1, H=32, W=32, Cin=8, Cout=64, s=2),
-                                 dict(B=2, H=17, W=9, Cin=128, Cout=256, s=2), dict(B=1, H=64, W=64, Cin=32, Cout=32, s=1)])
+                                 dict(B=2, H=17, W=9, Cin=128, Cout=256, s=2), dict(B=1, H=64, W=64, Cin=32, Cout=32, s=1),
+                                 # round 5: the SPM's low-resolution stride-2 layers (K = 9 Cin >= 1024 on a small tile grid) take the split-K
+                                 # form of the implicit GEMM (fp32 partial sums + a cast) in forward and data gradient
+                                 dict(B=2, H=32, W=32, Cin=256, Cout=256, s=2, nobias=True), dict(B=8, H=32, W=32, Cin=128, Cout=256, s=2, nobias=True)])
 def test_conv3x3_fwd_bwd(dt, cfg):
     from dinounet_amd import ops
     d = dev()
     B, H, W, Cin, Cout, s = (cfg[k] for k in ("B", "H", "W", "Cin", "Cout", "s"))
     x, w, b = q(gen(B, Cin, H, W, seed=1), dt), gen(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5), gen(Cout, seed=3)
+    if cfg.get("nobias"):                         # the SPM's convolutions are bias-free (dinov3_adapter.py:243-270)
+        b = torch.zeros_like(b)
     xr, wr, br = x.clone().requires_grad_(True), q(w, dt).requires_grad_(True), b.clone().requires_grad_(True)
     yr = F.conv2d(xr, wr, br, s, 1)
     go = q(gen(*yr.shape, seed=4), dt)
     gr = torch.autograd.grad(yr, (xr, wr, br), go)
     xg, wg, bg = nhwc(x).to(d, dt).requires_grad_(True), w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
-    y = ops.conv2d(xg, wg, bg, stride=s, pad=1)
-    gg = torch.autograd.grad(y, (xg, wg, bg), nhwc(go).to(d, dt))
+    if cfg.get("nobias"):
+        y = ops.conv2d(xg, wg, None, stride=s, pad=1)
+        gg = torch.autograd.grad(y, (xg, wg), nhwc(go).to(d, dt))
+    else:
+        y = ops.conv2d(xg, wg, bg, stride=s, pad=1)
+        gg = torch.autograd.grad(y, (xg, wg, bg), nhwc(go).to(d, dt))
     assert rel(y.permute(0, 3, 1, 2), yr) < TOL[dt]
     assert rel(gg[0].permute(0, 3, 1, 2), gr[0]) < TOL[dt]
     assert rel(gg[1], gr[1]) < TOL[dt]
-    assert rel(gg[2], gr[2]) < TOL[dt]
+    if not cfg.get("nobias"):
+        assert rel(gg[2], gr[2]) < TOL[dt]
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -1543,3 +1553,78 @@ def test_vit_half_batch_chains_on_side_streams_match_one_chain():
     for (pr, cr), (pg, cg) in zip(ref2, cap):
         assert rel(pg, pr) < 2e-2 and rel(cg, cr) < 2e-2
     del junk
+
+
+@pytest.mark.parametrize("M,N,K,form", [(5000, 96, 64, "nt"), (4100, 288, 32, "nt_relu"), (9000, 1024, 192, "nt"), (4096, 512, 256, "nt"), (6000, 160, 128, "nt_nobias"),
+                                        (7000, 256, 32, "dgrad"), (4500, 64, 256, "dgrad"), (131072, 256, 64, "nt")])
+def test_gemm_resident_weights_streaming_kernel(M, N, K, form):
+    """gemm_nt_rk_kernel (csrc/gemm_rk.hip, round 5): tall bf16 products with K <= 256 -- the weights' slice resident in LDS, A fragments
+    from global memory into registers, the result stored from registers.  Forced wherever legal (du_set_option(12, 3); the default rule
+    takes products of >= 2^24 output elements): ragged M, column chunks of unequal size, every K, W as [N][K] and as [K][N], bias /
+    activation, against the fp32 product of the same bf16 operands and bit for bit against the kernel it replaces."""
+    from dinounet_amd import ops, _lib
+    from dinounet_amd._lib import ACT_RELU
+    d = dev()
+    bf = torch.bfloat16
+    L = _lib.lib()
+    if form == "dgrad":
+        dy, w = q(gen(M, K, seed=1), bf).to(d, bf), q(gen(K, N, seed=2, scale=K ** -0.5), bf).to(d, bf)
+        fn = lambda: ops.mm_dgrad(dy, w)
+        ref = dy.float() @ w.float()
+    else:
+        x, w = q(gen(M, K, seed=1), bf).to(d, bf), q(gen(N, K, seed=2, scale=K ** -0.5), bf).to(d, bf)
+        b = None if form == "nt_nobias" else gen(N, seed=3).to(d)
+        act = ACT_RELU if form == "nt_relu" else 0
+        fn = lambda: ops.mm(x, w, bias=b, act=act)
+        ref = x.float() @ w.float().t()
+        if b is not None:
+            ref = ref + b
+        if act:
+            ref = F.relu(ref)
+    try:
+        L.du_set_option(12, 0)
+        ops.TRACK_ROUTE = True
+        y_old = fn().float()
+        L.du_set_option(12, 3)
+        y_new = fn().float()
+        assert ops.LAST_GEMM_ROUTE == 7, ops.LAST_GEMM_ROUTE           # the streaming kernel ran
+        again = [fn().float() for _ in range(4)]
+    finally:
+        ops.TRACK_ROUTE = False
+        L.du_set_option(12, 1)
+    assert rel(y_new, ref) < TOL[bf]
+    assert torch.equal(y_new, y_old)            # same fp32 accumulation order over k, same epilogue arithmetic
+    for o in again:
+        assert torch.equal(o, y_new)
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 64, 64, 32, 32), (1, 96, 64, 64, 32), (4, 32, 32, 128, 64), (5, 40, 24, 64, 64)])
+def test_conv_transpose2x2_on_the_streaming_kernel(B, H, W, Ci, Co):
+    """ConvTranspose2d k2 s2 (dinounet_training.py:255-264,558) through gemm_nt_rk_kernel: the forward's pixel-shuffle store (a 32-column
+    block inside one tap) and the data gradient's 2 x 2 patch gather as the A operand (a k-step inside one tap), forced with
+    du_set_option(12, 3), against torch's conv_transpose2d / its gradient in fp32."""
+    from dinounet_amd import ops, _lib
+    d = dev()
+    bf = torch.bfloat16
+    L = _lib.lib()
+    x = q(gen(B, H, W, Ci, seed=1), bf)
+    w, b = gen(Ci, Co, 2, 2, seed=2, scale=Ci ** -0.5), gen(Co, seed=3)
+    go = q(gen(B, 2 * H, 2 * W, Co, seed=4), bf)
+    xr, wr = x.clone().requires_grad_(True), q(w, bf).clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr.permute(0, 3, 1, 2), wr, b, stride=2).permute(0, 2, 3, 1)
+    yr.backward(go)
+    xg, wg, bg = x.to(d, bf).requires_grad_(True), w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    try:
+        L.du_set_option(12, 3)
+        ops.TRACK_ROUTE = True
+        ops.ROUTES.clear()
+        y = ops.conv_transpose2x2(xg, wg, bg)
+        y.backward(go.to(d, bf))
+        routes = [r for _, _, r in ops.ROUTES]
+    finally:
+        ops.TRACK_ROUTE = False
+        L.du_set_option(12, 1)
+    assert routes.count(7) >= (2 if 4 * Co <= 256 else 1), routes          # forward and data gradient both took the streaming kernel
+    assert rel(y, yr) < TOL[bf]
+    assert rel(xg.grad, xr.grad) < TOL[bf]
+    assert rel(wg.grad, wr.grad) < TOL[bf] and rel(bg.grad, b * 0 + go.float().sum((0, 1, 2))) < TOL[bf]
