@@ -9,6 +9,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdinounet_hip.so")
 SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_glds.hip", "gemm_p8.hip", "gemm_rk.hip", "gemm_skinny.hip", "conv_halo.hip", "conv_strip.hip", "attention.hip", "norm.hip", "msda.hip", "elementwise.hip", "loss.hip", "optim.hip", "augment.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-gpu-rdc"]
+# the measurement tools' build: environment knobs (DU_CONV_STRIP, DU_SKINNY_FUSE_KMAX, ...) compiled in; the release library has none (csrc/common.h)
+if os.environ.get("DINOUNET_DEBUG_KNOBS") == "1":
+    FLAGS.append("-DDU_DEBUG_KNOBS")
 # per-source extras.  attention.hip: MFMA results straight into VGPRs (the softmax reads every S^T accumulator with VALU ops; in the
 # accumulator half of the register file each one costs a v_accvgpr_read and a second register: 194 -> 166 registers, 2 -> 3 waves / SIMD)
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "conv_strip.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}

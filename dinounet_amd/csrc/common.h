@@ -13,6 +13,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DU_WAVE 64
 
+// Debugging / A-B knobs read from the environment exist only in builds made with -DDU_DEBUG_KNOBS (DINOUNET_DEBUG_KNOBS=1 python -m
+// dinounet_amd._build: the measurement tools' build).  The release library has none: every default below is what ships and no test or
+// deployment can change kernel selection through the environment (tests/test_cpu_oracle_and_boundary.py checks the
+// binary).  Run-time switching that the product itself needs goes through du_set_option.
+#include <stdlib.h>
+#ifdef DU_DEBUG_KNOBS
+#define DU_GETENV(name) getenv(name)
+#else
+#define DU_GETENV(name) ((const char*)nullptr)
+#endif
+
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int VEC = 4; static constexpr int DT = DU_F32; };
 template <> struct Elem<bf16_t> { static constexpr int VEC = 8; static constexpr int DT = DU_BF16; };

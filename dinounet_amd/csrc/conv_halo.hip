@@ -336,7 +336,7 @@ extern "C" int du_conv3x3_halo(const void* x, int64_t ldx, const void* x2, int64
   P.B = B; P.H = H; P.W = W; P.w = (const bf16_t*)w; P.bias = bias; P.y = (bf16_t*)y; P.ldy = ldy; P.stats_part = stats_part;
   P.tilesX = W / TW; P.tilesY = H / TH; P.ntiles = B * P.tilesX * P.tilesY;
   // channel chunk: 64 when both sources split on 64-channel boundaries, else 32
-  static const bool ck32 = getenv("DU_HALO_CK32") != nullptr;     // A-B aid: 32-channel chunks for the 64-output layers too (2 workgroups / CU)
+  static const bool ck32 = DU_GETENV("DU_HALO_CK32") != nullptr;     // A-B aid: 32-channel chunks for the 64-output layers too (2 workgroups / CU)
   const bool c64 = Cin % 64 == 0 && C1 % 64 == 0;
   const bool c32 = Cin % 32 == 0 && C1 % 32 == 0;
   if (Cout == 32) { if (c64) return launch<64, 1>(P, st); if (c32) return launch<32, 1>(P, st); }
@@ -549,7 +549,7 @@ extern "C" int du_conv3x3_wgrad_halo_blocks(int C1, int Cin, int Cout, int B, in
   // slab traffic of the finalize (<= 2 x 75 MB) and hide that latency.  DU_HALO_WGRAD_BLOCKS overrides (A-B aid).
   // measured (bench A-B, round 3): 512^2 64->32 257 -> 168 us, 32->32 138 -> 93 us with 512 workgroups; the 64-output layers at 256^2
   // (147-295 KB slabs) lose 10 % to the doubled finalize traffic: two per CU only while a slab stays under 80 KB
-  static const int cap_env = getenv("DU_HALO_WGRAD_BLOCKS") ? atoi(getenv("DU_HALO_WGRAD_BLOCKS")) : 0;
+  static const int cap_env = DU_GETENV("DU_HALO_WGRAD_BLOCKS") ? atoi(DU_GETENV("DU_HALO_WGRAD_BLOCKS")) : 0;
   const int cap = cap_env > 0 ? cap_env : ((long)Cout * 9 * Cin * 4 <= 80L * 1024 ? 512 : 256);
   return ntiles < cap ? ntiles : cap;
 }

@@ -410,7 +410,7 @@ int strip_rows(int B, int H, int W, int want) {
   return rs;
 }
 bool strip_off() {
-  static const bool off = getenv("DU_CONV_STRIP") && atoi(getenv("DU_CONV_STRIP")) == 0;
+  static const bool off = DU_GETENV("DU_CONV_STRIP") && atoi(DU_GETENV("DU_CONV_STRIP")) == 0;
   return off;
 }
 // which instantiation serves (C1, Cin, Cout): 0 = none, else NP * 10 + NCO
@@ -445,7 +445,7 @@ extern "C" int du_conv3x3_strip(const void* x, int64_t ldx, const void* x2, int6
   StripParams P{};
   P.x = (const bf16_t*)x; P.ldx = ldx; P.x2 = (const bf16_t*)x2; P.ldx2 = ldx2; P.w = (const bf16_t*)w; P.bias = bias;
   P.y = (bf16_t*)y; P.ldy = ldy; P.stats_part = stats_part;
-  static const int dbg = getenv("DU_STRIP_DEBUG") ? atoi(getenv("DU_STRIP_DEBUG")) : 0;
+  static const int dbg = DU_GETENV("DU_STRIP_DEBUG") ? atoi(DU_GETENV("DU_STRIP_DEBUG")) : 0;
   P.dbg = dbg;
   P.Cout = Cout; P.B = B; P.H = H; P.W = W; P.RS = rs; P.nseg = H / rs; P.strips = W / 32;
   hipStream_t st = (hipStream_t)stream;

@@ -885,7 +885,7 @@ extern "C" int du_dwconv3x3_bwd_data(int dtype, const void* dy, int64_t lddy, in
 
 // the row forms (4 consecutive pixels of a row per thread) need every grid of the token pyramid -- widths 2W, W, W / 2 -- to be a multiple of 4
 static inline bool dwconv_row4_ok(int W) {
-  static const bool off = getenv("DU_DWCONV_NO_ROW4") != nullptr;      // debugging / A-B aid
+  static const bool off = DU_GETENV("DU_DWCONV_NO_ROW4") != nullptr;      // debugging / A-B aid
   return !off && W % 8 == 0;
 }
 

@@ -302,13 +302,13 @@ int du_gemm_route_bf16(const du_gemm_args& a);                       // gemm_bf1
 
 extern "C" int du_gemm_route(const du_gemm_args* pa) {
   if (!pa) return DU_ERR_BAD_ARG;
-  static const bool generic = getenv("DU_GEMM_GENERIC") != nullptr;
+  static const bool generic = DU_GETENV("DU_GEMM_GENERIC") != nullptr;
   return generic ? 0 : du_gemm_route_bf16(*pa);
 }
 
 extern "C" int64_t du_gemm_ws_elems(const du_gemm_args* pa) {
   if (!pa) return 0;
-  static const bool generic = getenv("DU_GEMM_GENERIC") != nullptr;
+  static const bool generic = DU_GETENV("DU_GEMM_GENERIC") != nullptr;
   if (generic) return 0;
   return du_gemm_ragged_rows(*pa) > 0 ? du_gemm_skinny_ws_elems(pa->N, pa->K) : 0;
 }
@@ -343,18 +343,18 @@ extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
   // tile engine implements it, and only for K tiles that lie inside one sample
   const bool k_scale = a.row_scale && a.a_mode == DU_PLAIN_COL;
   if (k_scale) {
-    const int route = a.dtype == DU_BF16 && !getenv("DU_GEMM_GENERIC") ? du_gemm_route_bf16(a) : 0;
+    const int route = a.dtype == DU_BF16 && !DU_GETENV("DU_GEMM_GENERIC") ? du_gemm_route_bf16(a) : 0;
     if (route != 1 || a.rs_rows <= 0 || a.rs_rows % 64 || a.bias || a.act || a.gamma || a.residual || a.store_mode) return DU_ERR_UNSUPPORTED;
   }
   if (a.split_k > 1 && (a.out_dtype != DU_F32 || a.bias || a.act || a.gamma || (a.row_scale && !k_scale) || a.residual || a.store_mode)) return DU_ERR_BAD_ARG;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && a.residual && a.ldc % 1) return DU_ERR_BAD_ARG;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && (a.ps_C <= 0 || a.N != 4 * a.ps_C || a.M % (a.ps_H * a.ps_W))) return DU_ERR_BAD_ARG;
   if (a.b_colsum) {                      // ConvT bias gradient from the gathered dY operand: bf16 weight-gradient kernels only
-    const int route = a.dtype == DU_BF16 && a.a_mode == DU_PLAIN_COL && a.b_mode == DU_IM2COL_COL && !getenv("DU_GEMM_GENERIC") ? du_gemm_route_bf16(a) : 0;
+    const int route = a.dtype == DU_BF16 && a.a_mode == DU_PLAIN_COL && a.b_mode == DU_IM2COL_COL && !DU_GETENV("DU_GEMM_GENERIC") ? du_gemm_route_bf16(a) : 0;
     if ((route != 1 && route != 5) || a.geom.C <= 0 || a.N % a.geom.C) return DU_ERR_UNSUPPORTED;
   }
   if (a.a_colsum) {                      // bias-gradient side sum: only the bf16 weight-gradient kernels accumulate it
-    const int route = a.dtype == DU_BF16 && a.a_mode == DU_PLAIN_COL && !getenv("DU_GEMM_GENERIC") ? du_gemm_route_bf16(a) : 0;
+    const int route = a.dtype == DU_BF16 && a.a_mode == DU_PLAIN_COL && !DU_GETENV("DU_GEMM_GENERIC") ? du_gemm_route_bf16(a) : 0;
     if (route != 1 && route != 5) return DU_ERR_UNSUPPORTED;
   }
   if (a.store_mode == DU_STORE_QKV_ROPE) {       // fused RoPE + head split: the 256 x 128 multi-phase kernel or nothing
@@ -366,7 +366,7 @@ extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
     return du_gemm_nt_p8(a, st);
   }
   if (a.dtype == DU_BF16) {
-    static const bool generic_only = getenv("DU_GEMM_GENERIC") != nullptr;   // debugging aid: force the generic kernel
+    static const bool generic_only = DU_GETENV("DU_GEMM_GENERIC") != nullptr;   // debugging aid: force the generic kernel
     if (!generic_only) {
       int rc = du_gemm_bf16_fast(a, st);
       if (rc != DU_ERR_UNSUPPORTED) return rc;

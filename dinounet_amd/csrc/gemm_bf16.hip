@@ -392,7 +392,7 @@ int launch_cfg(const du_gemm_args& a, hipStream_t st) {
   constexpr int LDS_BYTES = MAIN_BYTES > STG_BYTES ? MAIN_BYTES : STG_BYTES;
   GemmParams P = make_params(a, AMODE, BMODE, BM, BN, BK);
   P.tiles_m = (a.M + BM - 1) / BM;
-  static const int group_env = getenv("DU_GEMM_GROUP_M") ? atoi(getenv("DU_GEMM_GROUP_M")) : 8;    // 0 / 1: row-major tile order
+  static const int group_env = DU_GETENV("DU_GEMM_GROUP_M") ? atoi(DU_GETENV("DU_GEMM_GROUP_M")) : 8;    // 0 / 1: row-major tile order
   P.group_m = group_env;
   dim3 grid(P.tiles_m * P.tiles_n, (a.batch < 1 ? 1 : a.batch) * P.split_k);
   if constexpr (AMODE == DU_PLAIN_COL && !KSCALE) {
@@ -454,7 +454,7 @@ int du_gemm_tn_p8_splits(const du_gemm_args& a);
 //    three rounds (qkv) 82 -> 85 us and four (fc1) no penalty to remove: the ragged tiles hide behind the spread of finish times).
 // 0 = leave the product alone.
 int du_gemm_ragged_rows(const du_gemm_args& a) {
-  static const bool off = getenv("DU_GEMM_NO_RAGGED_SPLIT") != nullptr;      // debugging / A-B aid
+  static const bool off = DU_GETENV("DU_GEMM_NO_RAGGED_SPLIT") != nullptr;      // debugging / A-B aid
   if (off || a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.store_mode != DU_STORE_PLAIN) return 0;
   if (a.act == DU_ACT_SWIGLU) return 0;      // the skinny kernels have no gate epilogue: the multi-phase kernel keeps the ragged rows
   if (a.batch > 1 || a.split_k > 1 || a.K % 64 || a.N < 96 || a.N % 4 || a.M < 1024 || a.lda % 8 || a.ldb % 8) return 0;

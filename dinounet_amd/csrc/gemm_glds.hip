@@ -239,7 +239,7 @@ int launch(const du_gemm_args& a, hipStream_t st) {
   constexpr int LDS_BYTES = MAIN_BYTES > STG_BYTES ? MAIN_BYTES : STG_BYTES;
   GemmParams P = make_params(a, DU_PLAIN_ROW, DU_PLAIN_ROW, BM, BN, BK);
   P.tiles_m = (a.M + BM - 1) / BM;
-  static const int group_env = getenv("DU_GLDS_GROUP_M") ? atoi(getenv("DU_GLDS_GROUP_M")) : 8;   // 0 / 1: row-major tile order
+  static const int group_env = DU_GETENV("DU_GLDS_GROUP_M") ? atoi(DU_GETENV("DU_GLDS_GROUP_M")) : 8;   // 0 / 1: row-major tile order
   P.group_m = group_env;
   dim3 grid(P.tiles_m * P.tiles_n, a.batch < 1 ? 1 : a.batch);
   auto kfn = gemm_nt_glds_kernel<TC, BK, NST, WNW>;
@@ -257,14 +257,14 @@ int launch(const du_gemm_args& a, hipStream_t st) {
 bool du_gemm_glds_serves(const du_gemm_args& a) {
   if (a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.dtype != DU_BF16) return false;
   if (a.K % 64 || a.split_k > 1 || a.N < 96 || a.M < 64) return false;
-  static const bool off = getenv("DU_GEMM_NO_GLDS") != nullptr;   // debugging / A-B aid
+  static const bool off = DU_GETENV("DU_GEMM_NO_GLDS") != nullptr;   // debugging / A-B aid
   return !off;
 }
 
 // returns DU_ERR_UNSUPPORTED when the shape / mode is not served by this kernel (caller falls back to gemm_bf16.hip)
 int du_gemm_nt_glds(const du_gemm_args& a, hipStream_t st) {
   if (!du_gemm_glds_serves(a)) return DU_ERR_UNSUPPORTED;
-  static const char* var = getenv("DU_GLDS_VARIANT");             // "3": force the 3-stage BK=32 ring, "2": force the 2-stage BK=64 kernel
+  static const char* var = DU_GETENV("DU_GLDS_VARIANT");             // "3": force the 3-stage BK=32 ring, "2": force the 2-stage BK=64 kernel
   // measured (tools/gemm_bench.py): the 3-stage BK=32 ring wins for short contractions (K <= 512: +8..20 %, more workgroups per
   // CU and a deeper DMA queue), the 2-stage BK=64 kernel for K >= 1024 (fewer barriers per flop)
   const bool ring = var ? var[0] == '3' : a.K <= 512;
@@ -272,7 +272,7 @@ int du_gemm_nt_glds(const du_gemm_args& a, hipStream_t st) {
     if (a.out_dtype == DU_BF16) return launch<bf16_t, 32, 3, 2>(a, st);
     return launch<float, 32, 3, 2>(a, st);
   }
-  static const char* wide_env = getenv("DU_GLDS_WIDE");            // "1": 128 x 256 tiles (8 waves) for N >= 256, "0": never
+  static const char* wide_env = DU_GETENV("DU_GLDS_WIDE");            // "1": 128 x 256 tiles (8 waves) for N >= 256, "0": never
   const bool wide = wide_env ? (wide_env[0] == '1' && a.N >= 256) : false;
   if (wide) {
     if (a.out_dtype == DU_BF16) return launch<bf16_t, 64, 2, 4>(a, st);

@@ -2031,11 +2031,11 @@ int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st, int tail_rows) {
 // the ragged tail of `whole` (rows M - r .. M) may ride in the head's launch: the single-launch skinny form serves it (K <= 2048: longer
 // rows put every load of the tail on the same few memory channels, gemm_skinny.hip), plain store, no gate epilogue
 bool du_gemm_p8_tail_ok(const du_gemm_args& whole, int r) {
-  static const bool off = getenv("DU_P8_NO_TAIL") != nullptr;      // debugging / A-B aid
+  static const bool off = DU_GETENV("DU_P8_NO_TAIL") != nullptr;      // debugging / A-B aid
   // (round 5: 4096 -- fc2's 40 tail rows inside its launch instead of the partial + finish kernel pair: +0.6 % step rate on one box, three
   //  interleaved rounds, profiles/r05_ab_tail_fuse_v1.txt; alone the fused K = 4096 tail is slower than the pair, 21 vs 14 us, but here it
   //  runs beside the stragglers of the tile grid and two ~5 us launch slots per block go away)
-  static const int kmax = getenv("DU_SKINNY_FUSE_KMAX") ? atoi(getenv("DU_SKINNY_FUSE_KMAX")) : 4096;
+  static const int kmax = DU_GETENV("DU_SKINNY_FUSE_KMAX") ? atoi(DU_GETENV("DU_SKINNY_FUSE_KMAX")) : 4096;
   if (off || r < 1 || r > 64 || whole.K > kmax || whole.K % SK_CHUNK || whole.N % 4 || whole.batch > 1) return false;
   if (whole.store_mode != DU_STORE_PLAIN || whole.act == DU_ACT_SWIGLU || whole.a_mode != DU_PLAIN_ROW || whole.b_mode != DU_PLAIN_ROW) return false;
   return 8 * 64 * (SK_BN + 1) * 4 <= P8_LDS;
@@ -2101,15 +2101,15 @@ extern "C" int du_gemm_tn_group_legal(const du_tn_job* job) { return (job && g_p
 
 template <int GG>
 static int tn_group_launch(const du_tn_job* const* jobs, int njobs, hipStream_t st) {
-  static const int target_units = getenv("DU_TN_GROUP_UNITS") ? atoi(getenv("DU_TN_GROUP_UNITS")) : 256;   // one 8-wave workgroup per CU
-  static const int min_pairs = getenv("DU_TN_GROUP_MINPAIRS") ? atoi(getenv("DU_TN_GROUP_MINPAIRS")) : 8;  // >= 1024 contraction rows per split
+  static const int target_units = DU_GETENV("DU_TN_GROUP_UNITS") ? atoi(DU_GETENV("DU_TN_GROUP_UNITS")) : 256;   // one 8-wave workgroup per CU
+  static const int min_pairs = DU_GETENV("DU_TN_GROUP_MINPAIRS") ? atoi(DU_GETENV("DU_TN_GROUP_MINPAIRS")) : 8;  // >= 1024 contraction rows per split
   void (*kfn)(TnGroupArgs) = g_p8_sched ? gemm_tn_group_kernel<1, GG> : gemm_tn_group_kernel<0, GG>;
   static bool attr_set[2] = {false, false};
   if (!attr_set[g_p8_sched ? 1 : 0]) {
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS) != hipSuccess) return DU_ERR_LAUNCH;
     attr_set[g_p8_sched ? 1 : 0] = true;
   }
-  static const int max_jobs = getenv("DU_TN_GROUP_MAXJOBS") ? std::max(1, std::min(TN_GROUP_MAX, atoi(getenv("DU_TN_GROUP_MAXJOBS")))) : TN_GROUP_MAX;
+  static const int max_jobs = DU_GETENV("DU_TN_GROUP_MAXJOBS") ? std::max(1, std::min(TN_GROUP_MAX, atoi(DU_GETENV("DU_TN_GROUP_MAXJOBS")))) : TN_GROUP_MAX;
   int i0 = 0;
   while (i0 < njobs) {
     // one launch: consecutive jobs while their tiles fit one round of workgroups

@@ -188,7 +188,7 @@ int rk_launch(const RkParams& P, hipStream_t st, size_t lds) {
 
 }  // namespace
 
-int g_rk_mode = 1;       // du_set_option key 12: 0 = never, 1 = K <= 192 where it pays (default), 2 = K = 256 too, 3 = wherever legal (tests)
+int g_rk_mode = 1;       // du_set_option key 12: 0 = never, 1 = where it pays (default: K <= 192, K = 256 up to 512 columns), 2 = every K = 256 too, 3 = wherever legal (tests)
 
 // the ConvTranspose2d k2 s2 data gradient as a gathered A operand (as gemm_p8.hip's convt_gather_geom, any channel count that is a power of two >= 16)
 static bool rk_gather_ok(const du_gemm_args& a) {
@@ -204,12 +204,13 @@ bool du_gemm_rk_serves(const du_gemm_args& a) {
   if (a.a_mode != DU_PLAIN_ROW && !(a.a_mode == DU_IM2COL_ROW && rk_gather_ok(a))) return false;
   if (a.b_mode != DU_PLAIN_ROW && a.b_mode != DU_PLAIN_COL) return false;
   if (a.K != 32 && a.K != 64 && a.K != 128 && a.K != 192 && a.K != 256) return false;
-  if (a.K == 256 && g_rk_mode < 2) return false;
+  // K = 256: up to 512 columns (two chunks); at N = 1024 the four column chunks read A four times and the multi-phase kernel ties
+  // (43008 x 1024 x 256: 43.9 vs 47.0 us alone, no difference in the step, profiles/r05_ab_rk_splitk_v1.txt)
+  if (a.K == 256 && g_rk_mode < 2 && a.N > 512) return false;
   if (a.N < 32 || a.N % 32 || a.M < 4096 || a.batch > 1 || a.split_k > 1) return false;
-  // where it pays (profiles/r05_gemm_rk_table_v1.txt): streams of >= 2^24 output elements -- below that the weight fill and the first
-  // rows' latency are most of the launch (32768 x 256 x 64: 22.8 us against 13.6 on the 128 x 128 kernel) -- and not the N = 32, long-K
-  // data gradients (one 32-column block per block of rows: all A reads, 23.5 us against 17.4)
-  if (g_rk_mode < 3 && ((long)a.M * a.N < (1L << 24) || (a.N < 64 && a.K > 64))) return false;
+  // where it pays (profiles/r05_gemm_rk_table_v2.txt): streams of >= 2^24 output elements -- below that the weight fill and the first
+  // rows' latency are most of the launch (32768 x 256 x 64: 15.1 us against 13.6 on the 128 x 128 kernel, 8192 x 128 x 128: 11.6 against 10.6)
+  if (g_rk_mode < 3 && (long)a.M * a.N < (1L << 24)) return false;
   if (a.alpha != 1.0f || a.gamma || a.row_scale || a.residual || a.act == DU_ACT_SWIGLU) return false;
   if (a.store_mode != DU_STORE_PLAIN && !(a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && a.ps_C > 0 && a.ps_C % 32 == 0 && a.N == 4 * a.ps_C &&
                                          a.ps_H > 0 && a.ps_W > 0 && a.M % (a.ps_H * a.ps_W) == 0)) return false;

@@ -206,16 +206,16 @@ int du_gemm_skinny(const du_gemm_args& a, hipStream_t st) {
   SkinnyEpi E{};
   E.C = a.C; E.ldc = a.ldc; E.residual = a.residual; E.ldr = a.ldr; E.bias = a.bias; E.gamma = a.gamma; E.row_scale = a.row_scale;
   E.alpha = a.alpha; E.act = a.act; E.rs_rows = a.rs_rows > 0 ? a.rs_rows : 1; E.out_bf16 = a.out_dtype == DU_BF16;
-  static const bool no_fuse = getenv("DU_SKINNY_NO_FUSE") != nullptr;     // A-B aid
+  static const bool no_fuse = DU_GETENV("DU_SKINNY_NO_FUSE") != nullptr;     // A-B aid
   // K > 2048 (fc2 of the ViT, K = 4096): a fragment load touches 32 rows at the SAME column offset, 8 KB apart -- every request of the
   // launch lands on the same few memory channels and the fused form (all workgroups walk K in step) takes 21 us against 14 us for the
   // split-K pair below, whose slices sit at different column offsets (tools/gemm_ragged.py)
-  static const int fuse_kmax = getenv("DU_SKINNY_FUSE_KMAX") ? atoi(getenv("DU_SKINNY_FUSE_KMAX")) : 2048;      // A-B aid
+  static const int fuse_kmax = DU_GETENV("DU_SKINNY_FUSE_KMAX") ? atoi(DU_GETENV("DU_SKINNY_FUSE_KMAX")) : 2048;      // A-B aid
   if (!no_fuse && a.K <= fuse_kmax) {
     // one launch: every workgroup runs the whole contraction of its 32 columns (4 waves x K/4) and applies the epilogue itself.  The
     // split-K pair below costs two launches + a partial round trip (12 us for 40 rows, 96 times per dinounet_l step)
     // waves per workgroup: enough that a wave walks at most ~4 chunks (K = 1024: 16 waves x 1 chunk, 4096: 16 x 4)
-    static const int nw_env = getenv("DU_SKINNY_WAVES") ? atoi(getenv("DU_SKINNY_WAVES")) : 0;      // A-B aid: 4 / 8 / 16
+    static const int nw_env = DU_GETENV("DU_SKINNY_WAVES") ? atoi(DU_GETENV("DU_SKINNY_WAVES")) : 0;      // A-B aid: 4 / 8 / 16
     const int chunks = a.K / SK_CHUNK;
     const int nw = nw_env ? nw_env : (chunks >= 16 ? 16 : chunks >= 8 ? 8 : 4);
     if (nw >= 16) return launch_skinny_fused<16>(a, E, st);

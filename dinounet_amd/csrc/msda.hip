@@ -988,7 +988,7 @@ __global__ __launch_bounds__(MP_THREADS) void msda_bwd_plane_kernel(const bf16_t
 
 // the plane kernels serve: bf16, one level, 4 points, 32 channels per head, an even number of heads, the two-head plane within 128 KB
 static bool plane_serves(int N, int S, int M, int D, int L, int P, int Lq) {
-  static const bool off = getenv("DU_MSDA_NO_PLANE") != nullptr;      // debugging / A-B aid
+  static const bool off = DU_GETENV("DU_MSDA_NO_PLANE") != nullptr;      // debugging / A-B aid
   return !off && L == 1 && P == 4 && D == 32 && M % 2 == 0 && (long)S * 128 <= 128 * 1024 && Lq >= 64;
 }
 // query chunks per (image, head pair): one workgroup per CU with room to spare, slots (image x chunk) in multiples of 8
@@ -1002,13 +1002,13 @@ static int plane_chunks(int N, int M, int Lq) {
 int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 // threads per workgroup of the MFMA grad_value kernel: 512 (256-pixel tiles, two workgroups per CU) unless DU_MSDA_GV_THREADS=1024
 static int gv_threads() {
-  static const int nt = (getenv("DU_MSDA_GV_THREADS") && atoi(getenv("DU_MSDA_GV_THREADS")) == 1024) ? 1024 : 512;
+  static const int nt = (DU_GETENV("DU_MSDA_GV_THREADS") && atoi(DU_GETENV("DU_MSDA_GV_THREADS")) == 1024) ? 1024 : 512;
   return nt;
 }
 
 // the round-3 fast kernels serve: bf16, 4 points, D / 8 in {4, 8, 16}, value < 2 GB (32-bit byte offsets), < 2^24 pixels and row bytes
 static bool q8_serves(int N, int S, int M, int D, int P) {
-  static const bool off = getenv("DU_MSDA_NO_Q8") != nullptr;      // debugging / A-B aid
+  static const bool off = DU_GETENV("DU_MSDA_NO_Q8") != nullptr;      // debugging / A-B aid
   if (off || P != 4 || D % 8) return false;
   const int lpp = D / 8;
   if (lpp != 4 && lpp != 8 && lpp != 16) return false;
@@ -1079,7 +1079,7 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
   if (blocks > 65535 * 8) blocks = 65535 * 8;
   const int LP = L * P;
   const size_t plane = (size_t)S * D * sizeof(float);
-  static const bool no_mfma = getenv("DU_MSDA_NO_MFMA") != nullptr;  // debugging / A-B aid
+  static const bool no_mfma = DU_GETENV("DU_MSDA_NO_MFMA") != nullptr;  // debugging / A-B aid
   if constexpr (sizeof(T) == 2) {
     if (!no_mfma && L == 1 && P == 4 && D <= 32 && LP <= 4) {
       // (1) gather-only pass: grad_sampling_loc / grad_attn_weight (no atomics)
@@ -1124,7 +1124,7 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
         // rows table of the query blocks (behind the chunk partials in the workspace); without room for it every block is walked
         const int nblk_all = (Lq + GV_KQ - 1) / GV_KQ;
         const long tab_off = nchunk > 1 ? (long)nchunk * plane_all : 0, tab_n = (long)N * M * nblk_all;
-        static const bool no_skip = getenv("DU_MSDA_GV_NO_SKIP") != nullptr;      // debugging / A-B aid
+        static const bool no_skip = DU_GETENV("DU_MSDA_GV_NO_SKIP") != nullptr;      // debugging / A-B aid
         unsigned* rows = (!no_skip && M <= 64 && ws && ws_elems >= tab_off + tab_n) ? (unsigned*)(ws + tab_off) : nullptr;
         if (rows)
           hipLaunchKernelGGL(msda_gv_rows_kernel, dim3((unsigned)(N * nblk_all)), dim3(256), 0, st, shapes, loc, rows, N, M, Lq, nblk_all);
@@ -1144,7 +1144,7 @@ int bwd_launch(const void* value, const int64_t* shapes, const int64_t* lsi, con
     }
   }
   if (gv_bf16) return DU_ERR_UNSUPPORTED;                            // only the MFMA grad_value path above writes the activation dtype
-  static const bool no_lds = getenv("DU_MSDA_NO_LDS") != nullptr;   // debugging aid: force the global-atomics kernel
+  static const bool no_lds = DU_GETENV("DU_MSDA_NO_LDS") != nullptr;   // debugging aid: force the global-atomics kernel
   if (!no_lds && plane <= 144 * 1024 && LP <= 8 && LPP <= 64) {
     int nchunk, qpc;
     lds_chunking(N, M, Lq, LPP, &nchunk, &qpc);
@@ -1356,7 +1356,7 @@ extern "C" int du_msda_backward_bf16gv(const void* value, const int64_t* shapes,
   if (!value || !shapes || !lsi || !loc || !attn || !gout || !gv_bf16 || !gl || !ga || N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 ||
       Lq <= 0 || P <= 0)
     return DU_ERR_BAD_ARG;
-  static const bool no_mfma = getenv("DU_MSDA_NO_MFMA") != nullptr;
+  static const bool no_mfma = DU_GETENV("DU_MSDA_NO_MFMA") != nullptr;
   if (no_mfma || !(L == 1 && P == 4 && D <= 32 && D % 4 == 0)) return DU_ERR_UNSUPPORTED;
   return bwd_launch<bf16_t, 4>(value, shapes, lsi, loc, attn, gout, (float*)gv_bf16, gl, ga, N, S, M, D, L, Lq, P, ws, ws_elems, st, 1);
 }

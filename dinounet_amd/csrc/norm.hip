@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(const T* __res
 static inline int pick_strip(int G, long P, int C, int vec) {
   const int cvb = (C / vec) < 256 ? (C / vec) : 256;
   const int np = 256 / (cvb > 0 ? cvb : 1);
-  static const long tmax = getenv("DU_STRIP_TARGET") ? atol(getenv("DU_STRIP_TARGET")) : 512;    // tuning aid (2048: +10 % time in the step)
+  static const long tmax = DU_GETENV("DU_STRIP_TARGET") ? atol(DU_GETENV("DU_STRIP_TARGET")) : 512;    // tuning aid (2048: +10 % time in the step)
   long target = 65536L * 8 / C;              // wide rows: fewer, longer strips keep the partial buffer (strips x C x 2) small
   if (target > tmax) target = tmax;
   if (target < 256) target = 256;
@@ -555,8 +555,8 @@ __global__ __launch_bounds__(256) void norm_act_bwd_dx_kernel(const T* __restric
 static inline int norm_slots(int G, long P, int C, int vec, bool bwd = false) {
   // measured in the step (rocprofv3, tools/_normsweep.sh): the forward kernel (1 load + 1 store per pixel) is best with many short
   // workgroups, the backward-dx kernel (2 loads + 1 store, 6 channel constants per thread) with few long ones: 42 -> 31 us average
-  static const long total_f = getenv("DU_NORM_SLOTS") ? atol(getenv("DU_NORM_SLOTS")) : 4096;     // tuning aids
-  static const long total_b = getenv("DU_NORM_SLOTS_BWD") ? atol(getenv("DU_NORM_SLOTS_BWD")) : 512;
+  static const long total_f = DU_GETENV("DU_NORM_SLOTS") ? atol(DU_GETENV("DU_NORM_SLOTS")) : 4096;     // tuning aids
+  static const long total_b = DU_GETENV("DU_NORM_SLOTS_BWD") ? atol(DU_GETENV("DU_NORM_SLOTS_BWD")) : 512;
   const long total = bwd ? total_b : total_f;
   const int cvb = (C / vec) < 256 ? (C / vec) : 256;
   const int np = 256 / (cvb > 0 ? cvb : 1);
@@ -749,7 +749,7 @@ int ln_bwd_dispatch(const void* x, const void* dy, const float* w, const float* 
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   {
     // one pass (dx + the weight / bias gradient partials) when the scratch for the partials is there and a lane's columns fit in registers
-    static const bool off = getenv("DU_LN_BWD_FUSED") && atoi(getenv("DU_LN_BWD_FUSED")) == 0;
+    static const bool off = DU_GETENV("DU_LN_BWD_FUSED") && atoi(DU_GETENV("DU_LN_BWD_FUSED")) == 0;
     const int STRIP = pick_strip(1, rows, D, Elem<T>::VEC);
     const long strips = (rows + STRIP - 1) / STRIP;
     const size_t lds = (size_t)3 * D * 2 * sizeof(float);
@@ -906,7 +906,7 @@ extern "C" int du_norm_act_bwd_stats(int dtype, const void* x, int64_t ldx, cons
   dim3 grid((unsigned)(G * strips)), block(256);
   if (dtype != DU_BF16 && dtype != DU_F32) return DU_ERR_BAD_ARG;
   return strip_launch(bsums, ws, ws_elems, G, strips, C, st, [&](float* part) {
-    static const int deep = getenv("DU_NORM_BWD_UNROLL") ? atoi(getenv("DU_NORM_BWD_UNROLL")) : 4;     // A-B aid: 2 = the round-2 loop
+    static const int deep = DU_GETENV("DU_NORM_BWD_UNROLL") ? atoi(DU_GETENV("DU_NORM_BWD_UNROLL")) : 4;     // A-B aid: 2 = the round-2 loop
     if (dtype == DU_BF16) {
       if (deep >= 4) hipLaunchKernelGGL((norm_act_bwd_stats_kernel<bf16_t, 4>), grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, part);
       else hipLaunchKernelGGL((norm_act_bwd_stats_kernel<bf16_t, 2>), grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, part);
@@ -971,7 +971,7 @@ extern "C" int du_norm_act_bwd_stats_grads(int dtype, const void* x, int64_t ldx
   const long strips = (P + STRIP - 1) / STRIP;
   if (!ws || ws_elems < (long)G * strips * C * 2) return DU_ERR_BAD_ARG;
   dim3 grid((unsigned)(G * strips)), block(256);
-  static const int deep = getenv("DU_NORM_BWD_UNROLL") ? atoi(getenv("DU_NORM_BWD_UNROLL")) : 4;     // A-B aid: 2 = the round-2 loop
+  static const int deep = DU_GETENV("DU_NORM_BWD_UNROLL") ? atoi(DU_GETENV("DU_NORM_BWD_UNROLL")) : 4;     // A-B aid: 2 = the round-2 loop
   if (dtype == DU_BF16) {
     if (deep >= 4) hipLaunchKernelGGL((norm_act_bwd_stats_kernel<bf16_t, 4>), grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, ws);
     else hipLaunchKernelGGL((norm_act_bwd_stats_kernel<bf16_t, 2>), grid, block, 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, mean, rstd, w, b, bsums, G, P, C, act, STRIP, ws);

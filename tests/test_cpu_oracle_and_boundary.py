@@ -149,6 +149,24 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"gfx950" in _lib.lib().du_version()
 
 
+def test_release_library_reads_no_environment_knobs():
+    """the debugging / A-B knobs of csrc/*.hip (DU_CONV_STRIP, DU_P8_NO_TAIL, DU_SKINNY_FUSE_KMAX, ...) are compiled
+    in only with -DDU_DEBUG_KNOBS (DINOUNET_DEBUG_KNOBS=1 at build time, the measurement tools' build).  The library the product and the
+    driver build must not contain a single one of those names: what ships cannot be reconfigured through the environment."""
+    import re
+    from dinounet_amd import _build
+    if os.environ.get("DINOUNET_DEBUG_KNOBS") == "1":
+        pytest.skip("debug-knob build")
+    names = set()
+    for f in os.listdir(_build.CSRC):
+        if f.endswith(".hip"):
+            names |= set(re.findall(r'DU_GETENV\("([A-Z0-9_]+)"\)', open(os.path.join(_build.CSRC, f)).read()))
+    assert len(names) >= 25                                   # the knobs exist in the sources ...
+    blob = open(_build.build(verbose=False), "rb").read()
+    present = sorted(n for n in names if n.encode() in blob)
+    assert not present, present                              # ... and none of them in the binary
+
+
 def test_c_abi_argument_validation_without_gpu():
     """Bad arguments are rejected before any launch (DU_ERR_BAD_ARG), so this runs without a device."""
     from dinounet_amd import _lib
@@ -484,7 +502,7 @@ def test_gemm_dispatch_host_logic_without_gpu():
     # short contractions on tall products (round 5): the resident-weights streaming kernel (7) from 2^24 output elements up, K <= 192 --
     # the adapter's K = 192 data gradient, the SPM's 64 -> 1024 projection; small ones stay on the direct-to-LDS 128 x 128 kernel
     assert route(43008, 1024, 192)[0] == 7 and route(131072, 1024, 64)[0] == 7 and route(524288, 128, 64)[0] == 7
-    assert route(32768, 256, 64)[0] == 2 and route(2048, 256, 256)[0] == 2 and route(43008, 1024, 256)[0] == 3
+    assert route(32768, 256, 64)[0] == 2 and route(2048, 256, 256)[0] == 2 and route(43008, 1024, 256)[0] == 3 and route(131072, 512, 256)[0] == 7
     try:
         L.du_set_option(12, 0)
         assert route(43008, 1024, 192)[0] == 2 and route(131072, 1024, 64)[0] == 2

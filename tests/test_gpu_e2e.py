@@ -370,7 +370,7 @@ def test_train_step_pinned_randomness_vs_reference(name):
             worst = (k, err)
     print(f"[{name}] {n_cmp} gradients compared, worst rel-L2 {worst[1]:.2e} at {worst[0]}")
     assert n_cmp == len(norms)
-    assert worst[1] < 2e-2, worst
+    assert worst[1] < 1e-2, worst       # (measured: 4.5e-3 at dinounet_l 512^2 on spm.stem.4.weight, 6e-3 at dinounet_s 512^2; BASELINE.md quotes <= 1e-2)
     assert sorted(k for k, p in named.items() if p.requires_grad and p.grad is None) == meta["unused"]
 
 
