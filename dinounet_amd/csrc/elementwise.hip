@@ -1096,6 +1096,26 @@ extern "C" int du_sample_copy(const float* src, float* dst, const int64_t* idx, 
   return du_check_launch();
 }
 
+// ordered reduction of split-K slabs (DU_STORE_SLABS) + bf16 rounding: 4 outputs per thread
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ slabs, bf16_t* __restrict__ out, int splits, long n4, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 acc = *(const float4*)(slabs + 4 * i);
+    for (int s = 1; s < splits; s++) {
+      const float4 t = *(const float4*)(slabs + (long)s * n + 4 * i);
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    bf16x4 r;
+    r[0] = (bf16_t)acc.x; r[1] = (bf16_t)acc.y; r[2] = (bf16_t)acc.z; r[3] = (bf16_t)acc.w;
+    *(uint2*)(out + 4 * i) = __builtin_bit_cast(uint2, r);
+  }
+}
+
+extern "C" int du_splitk_reduce_bf16(const float* slabs, void* out, int splits, int64_t n, void* stream) {
+  if (!slabs || !out || splits < 1 || n <= 0 || n % 4) return DU_ERR_BAD_ARG;
+  hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(grid_1d(n / 4)), dim3(256), 0, (hipStream_t)stream, slabs, (bf16_t*)out, splits, (long)(n / 4), (long)n);
+  return du_check_launch();
+}
+
 extern "C" int du_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!src || !dst || n <= 0) return DU_ERR_BAD_ARG;

@@ -346,7 +346,11 @@ extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
     const int route = a.dtype == DU_BF16 && !DU_GETENV("DU_GEMM_GENERIC") ? du_gemm_route_bf16(a) : 0;
     if (route != 1 || a.rs_rows <= 0 || a.rs_rows % 64 || a.bias || a.act || a.gamma || a.residual || a.store_mode) return DU_ERR_UNSUPPORTED;
   }
-  if (a.split_k > 1 && (a.out_dtype != DU_F32 || a.bias || a.act || a.gamma || (a.row_scale && !k_scale) || a.residual || a.store_mode)) return DU_ERR_BAD_ARG;
+  if (a.split_k > 1 && (a.out_dtype != DU_F32 || a.bias || a.act || a.gamma || (a.row_scale && !k_scale) || a.residual ||
+                        (a.store_mode && a.store_mode != DU_STORE_SLABS))) return DU_ERR_BAD_ARG;
+  if (a.store_mode == DU_STORE_SLABS) {        // one slab per K range instead of atomics: the bf16 tile engine's split-K epilogue only
+    if (a.split_k <= 1 || a.dtype != DU_BF16 || a.batch > 1 || du_gemm_route_bf16(a) != 1) return DU_ERR_UNSUPPORTED;
+  }
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && a.residual && a.ldc % 1) return DU_ERR_BAD_ARG;
   if (a.store_mode == DU_STORE_PIXEL_SHUFFLE2 && (a.ps_C <= 0 || a.N != 4 * a.ps_C || a.M % (a.ps_H * a.ps_W))) return DU_ERR_BAD_ARG;
   if (a.b_colsum) {                      // ConvT bias gradient from the gathered dY operand: bf16 weight-gradient kernels only

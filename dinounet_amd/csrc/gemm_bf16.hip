@@ -308,6 +308,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
   TC* Cb = (TC*)P.C + (long)batch * P.cbs;
   // ---- split-K: fp32 atomics straight from the accumulators (lanes 0..31 = 32 consecutive columns) ----
   if (P.split_k > 1) {
+    // DU_STORE_SLABS: this split's partial tile goes to its own slab with plain stores (reduced in a fixed order afterwards): the
+    // forward / data-gradient uses of split-K must be bit-reproducible run to run, which fp32 atomics are not
+    const bool slabs = P.store_mode == DU_STORE_SLABS;
+    float* Cs = (float*)Cb + (slabs ? (long)split * P.M * P.ldc : 0L);
 #pragma unroll
     for (int j = 0; j < TN; j++) {
       const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -317,7 +321,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams P) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < P.M) atomic_add_f32((float*)Cb + (long)m * P.ldc + n, acc[i][j][r] * P.alpha);
+          if (m < P.M) {
+            if (slabs) Cs[(long)m * P.ldc + n] = acc[i][j][r] * P.alpha;
+            else atomic_add_f32(Cs + (long)m * P.ldc + n, acc[i][j][r] * P.alpha);
+          }
         }
     }
     return;

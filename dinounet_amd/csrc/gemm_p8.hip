@@ -1453,11 +1453,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_p4_kernel(GemmParams P) {
 // only makes a wait stricter; a store the descriptor's range check drops retires at once, DESIGN 6.49, and is equally harmless here).
 // Tiles are dealt out statically: workgroup w (XCD-contiguous index) takes tiles w, w + G, w + 2 G, ... of the banded tile order, so
 // the G tiles in flight at any time are the ones a non-persistent launch would run in one round.
-// Served: bf16 result, epilogue = bias (+ GELU), plain store, K >= 512 (the drain is spread over four K-steps; shorter products
-// keep the kernels above).  Results are bit-identical to gemm_nt_p8n_kernel (same K order, same epilogue arithmetic).
+// Served: bf16 result, epilogue = bias (+ GELU), plain store, K >= 384 (the drain takes four K-steps of the next tile) or K = 256 (NK4:
+// the tile is four K-steps and the drain of tile i runs under all of tile i + 1 -- the adapter's 43008 x 1024 x 256 products are ALL
+// prologue and epilogue on the kernels above).  Results are bit-identical to gemm_nt_p8n_kernel (same K order, same epilogue arithmetic).
 // ================================================================================================================================
-constexpr int PP_BIAS_OFF = P8N_LDS;              // two slots x 128 floats behind the three K-tile buffers
-constexpr int PP_LDS = P8N_LDS + 2 * 128 * 4;     // 148 480 B
+constexpr int PP_BIAS_OFF = P8N_LDS;              // bias slots (128 floats each) behind the three K-tile buffers
+constexpr int PP_LDS = P8N_LDS + 3 * 128 * 4;     // 148 992 B (three bias slots: the K = 256 form keeps an image through the next tile)
 constexpr unsigned PP_OOR = 0x80000000u;          // a voffset past every descriptor's range (the range check ignores the scalar offset)
 
 __device__ __forceinline__ void pp_swap_halves(unsigned& a, unsigned& b) {      // a's lanes 32-63 <-> b's lanes 0-31
@@ -1469,7 +1470,7 @@ __device__ __forceinline__ void pp_lds_read1(f32x4& a, unsigned addr) { asm vola
 __device__ __forceinline__ void pp_wait_lds(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
 __device__ __forceinline__ void pp_wait_lds1(f32x4& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory"); }
 
-template <int ACT, int SPREAD>
+template <int ACT, bool NK4>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<bf16_t>(P, smem); return; }
@@ -1617,9 +1618,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   // ---- drain of the finished tile.  Unit u = (i, c, h2): the 32 rows x 16 columns 16 h2 .. + 15 of block (i, c), one 16-byte store per
   // lane (a row's two lanes store adjacent pieces: 32 contiguous bytes per row and instruction).  A unit is two HALVES (h = 2 u + part):
   // part 0 = accumulator group g = 2 h2 (4 values per lane: bias, activation, bf16 pair x 2, kept in two registers), part 1 = group
-  // 2 h2 + 1, then the two v_permlane32_swap and the store.  SPREAD = K-steps the 16
-  // halves are dealt over: 4 (both halves of a unit in one phase; K >= 512) or 8 (one half per phase; K >= 768) -- the erf-GELU of fc1 is
-  // ~530 VALU issue cycles per unit and wave against 512 matrix-pipe cycles per phase and SIMD: bunched into 8 phases it paced them. ----
+  // 2 h2 + 1, then the two v_permlane32_swap and the store.  The 16 halves go over FOUR K-steps, one unit per phase (dealing them over
+  // eight K-steps, one half per phase, was built for the GELU drain and measured the same: 77.8 vs 77.6 us on fc1,
+  // profiles/r05_gemm_p8_table_v2.txt).  NK4 (K = 256): the tile IS four K-steps, so the drain of tile i runs under ALL of tile i + 1,
+  // the K-steps that request tile i + 2 included, and a bias image lives through the next tile: three slots. ----
   const int nlim = (P.dbg & 1) ? 0 : P.N;    // (du_set_option key 3 bit 0: no stores -- timing ablation)
   unsigned pbias = lds_base + PP_BIAS_OFF + (unsigned)((wn * 64 + 4 * hi) * 4);     // this lane's corner of the finished tile's bias image
   unsigned crow[2] = {PP_OOR, PP_OOR};   // byte offset of this lane's row of A half i, at its first column (wave's 64 + 8 hi), in C
@@ -1674,7 +1676,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   auto finish6 = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    if constexpr (SPREAD == 4) pp_wait_lds(bqa, bqb); else pp_wait_lds1(bqa);      // (SPREAD 8 has one half per phase: bqb does not exist)
+    pp_wait_lds(bqa, bqb);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -1684,7 +1686,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   // of a phase (phase 1 fetches NA / NB = the following K-step's phase-0 halves) from the image at fbase; CP1: prev[1] <- acc[1] in phase
   // 0 (first K-step of a tile, before its phase 1 restarts acc[1]); CP0: prev[0] <- acc[0] in phase 1 (last K-step: acc[0] is final)
   auto kstep = [&](auto par_c, auto first_c, auto ha0, auto hb0, auto ha1, auto hb1, auto na, auto nb, auto cp1_c, auto cp0_c, int bc, int bn,
-                   int bnn, unsigned kofs, unsigned fbase) {
+                   int bnn, unsigned kofs, unsigned fbase, unsigned fbase2) {
     constexpr int p = decltype(par_c)::value;
     // phase 0
     readA(IC<1>{}, bc);
@@ -1704,20 +1706,17 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
     half(ha1, bqa); half(hb1, bqb);
     pin(IC<12>{}, IC<2>{});
     __builtin_amdgcn_sched_barrier(0);
-    fetch(na, bqa, fbase); fetch(nb, bqb, fbase);
+    fetch(na, bqa, fbase2); fetch(nb, bqb, fbase2);      // (fbase2: the image the FOLLOWING K-step's halves belong to)
     finish6();
   };
   using T_ = IC<1>; using F_ = IC<0>; using N_ = IC<-1>;
-  // drain K-step j of the schedule: SPREAD 4 -> phase 0 halves (4 j, 4 j + 1), phase 1 (4 j + 2, 4 j + 3); SPREAD 8 -> (2 j), (2 j + 1)
-  auto dstep = [&](auto j_c, auto par_c, int bc_, int bn_, int bnn_, unsigned kofs) {
+  // drain K-step j (0 .. 3): phase 0 halves (4 j, 4 j + 1), phase 1 (4 j + 2, 4 j + 3).  NK4: K-step 3 is also the tile's last (CP0, and
+  // its last phase fetches the bias of the first unit of THIS tile, from the image at nbase)
+  auto dstep = [&](auto j_c, auto par_c, int bc_, int bn_, int bnn_, unsigned kofs, unsigned nbase) {
     constexpr int j = decltype(j_c)::value;
-    constexpr int last = SPREAD - 1;
-    if constexpr (SPREAD == 4)
-      kstep(par_c, IC<(j == 0)>{}, IC<4 * j>{}, IC<4 * j + 1>{}, IC<4 * j + 2>{}, IC<4 * j + 3>{}, IC<(j < last ? 4 * j + 4 : -1)>{},
-            IC<(j < last ? 4 * j + 5 : -1)>{}, IC<(j == 0)>{}, F_{}, bc_, bn_, bnn_, kofs, pbias);
-    else
-      kstep(par_c, IC<(j == 0)>{}, IC<2 * j>{}, N_{}, IC<2 * j + 1>{}, N_{}, IC<(j < last ? 2 * j + 2 : -1)>{}, N_{}, IC<(j == 0)>{}, F_{}, bc_, bn_,
-            bnn_, kofs, pbias);
+    constexpr bool wrap = NK4 && j == 3;
+    kstep(par_c, IC<(j == 0)>{}, IC<4 * j>{}, IC<4 * j + 1>{}, IC<4 * j + 2>{}, IC<4 * j + 3>{}, IC<(j < 3 ? 4 * j + 4 : (wrap ? 0 : -1))>{},
+          IC<(j < 3 ? 4 * j + 5 : (wrap ? 1 : -1))>{}, IC<(j == 0)>{}, IC<wrap>{}, bc_, bn_, bnn_, kofs, pbias, wrap ? nbase : pbias);
   };
 
   // ---- this workgroup's first tile: the only prologue (K-tiles 0 and 1) ----
@@ -1736,55 +1735,60 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   int bc = 0, bn = NBUF_B, bnn = 2 * NBUF_B;
   int slot = 0;
   auto rot2 = [&]() { const int o = bc; bc = bnn; bnn = bn; bn = o; };      // advance two K-tiles: (bc, bn, bnn) <- (bnn, bc, bn)
+  auto bias_at = [&](int sl) { return lds_base + PP_BIAS_OFF + (unsigned)(sl * 512 + (wn * 64 + 4 * hi) * 4); };
   for (;;) {
-    // K-steps 0 .. SPREAD - 1: the previous tile drains (the bias of its first halves was fetched by the last phase of that tile)
-    dstep(IC<0>{}, IC<0>{}, bc, bn, bnn, 2u * 128u);
-    dstep(IC<1>{}, IC<1>{}, bn, bnn, bc, 3u * 128u);
-    rot2();
-    dstep(IC<2>{}, IC<0>{}, bc, bn, bnn, 4u * 128u);
-    dstep(IC<3>{}, IC<1>{}, bn, bnn, bc, 5u * 128u);
-    rot2();
-    if constexpr (SPREAD == 8) {
-      dstep(IC<4>{}, IC<0>{}, bc, bn, bnn, 6u * 128u);
-      dstep(IC<5>{}, IC<1>{}, bn, bnn, bc, 7u * 128u);
-      rot2();
-      dstep(IC<6>{}, IC<0>{}, bc, bn, bnn, 8u * 128u);
-      dstep(IC<7>{}, IC<1>{}, bn, bnn, bc, 9u * 128u);
-      rot2();
-    }
-    int t = SPREAD;
-    for (; t + 2 < nk; t += 2) {
-      kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, (unsigned)(t + 2) * 128u, 0u);
-      kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bn, bnn, bc, (unsigned)(t + 3) * 128u, 0u);
-      rot2();
-    }
-    // the last two K-steps request K-tiles 0 and 1 of the NEXT tile (out of range behind the last one); the very last phase fetches the
-    // bias of the first halves of THIS tile (its image: slot `slot`)
     const int next = tile + G;
-    set_stage_tile(next, slot ^ 1);
-    pbias = lds_base + PP_BIAS_OFF + (unsigned)(slot * 512 + (wn * 64 + 4 * hi) * 4);
-    kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, 0u, 0u);
-    kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, IC<0>{}, IC<(SPREAD == 4 ? 1 : -1)>{}, F_{}, T_{}, bn, bnn, bc, 128u, pbias);
-    rot2();
-    set_prev_tile(tile);
-    slot ^= 1;
+    if constexpr (NK4) {
+      // four K-steps = the tile; the previous tile drains under all of them.  K-steps 0, 1 request this tile's K-tiles 2, 3; then the
+      // staging moves on: K-steps 2, 3 request K-tiles 0, 1 of the NEXT tile (out of range behind the last one)
+      const int nslot = slot == 2 ? 0 : slot + 1;
+      dstep(IC<0>{}, IC<0>{}, bc, bn, bnn, 2u * 128u, 0u);
+      dstep(IC<1>{}, IC<1>{}, bn, bnn, bc, 3u * 128u, 0u);
+      rot2();
+      set_stage_tile(next, nslot);
+      dstep(IC<2>{}, IC<0>{}, bc, bn, bnn, 0u, 0u);
+      dstep(IC<3>{}, IC<1>{}, bn, bnn, bc, 128u, bias_at(slot));
+      rot2();
+      pbias = bias_at(slot);
+      set_prev_tile(tile);
+      slot = nslot;
+    } else {
+      // K-steps 0 .. 3: the previous tile drains (the bias of its first unit was fetched by the last phase of that tile)
+      dstep(IC<0>{}, IC<0>{}, bc, bn, bnn, 2u * 128u, 0u);
+      dstep(IC<1>{}, IC<1>{}, bn, bnn, bc, 3u * 128u, 0u);
+      rot2();
+      dstep(IC<2>{}, IC<0>{}, bc, bn, bnn, 4u * 128u, 0u);
+      dstep(IC<3>{}, IC<1>{}, bn, bnn, bc, 5u * 128u, 0u);
+      rot2();
+      int t = 4;
+      for (; t + 2 < nk; t += 2) {
+        kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, (unsigned)(t + 2) * 128u, 0u, 0u);
+        kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bn, bnn, bc, (unsigned)(t + 3) * 128u, 0u, 0u);
+        rot2();
+      }
+      // the last two K-steps request K-tiles 0 and 1 of the NEXT tile (out of range behind the last one); the very last phase fetches the
+      // bias of the first unit of THIS tile (its image: slot `slot`)
+      set_stage_tile(next, slot ^ 1);
+      pbias = bias_at(slot);
+      kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, 0u, 0u, 0u);
+      kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, IC<0>{}, IC<1>{}, F_{}, T_{}, bn, bnn, bc, 128u, 0u, pbias);
+      rot2();
+      set_prev_tile(tile);
+      slot ^= 1;
+    }
     tile = next;
     if (tile >= ntiles) break;
   }
   // ---- the last tile drains in the open ----
   prev[1][0] = acc[1][0]; prev[1][1] = acc[1][1];
   if (P.dbg & 2) return;
-  auto last = [&](auto h_c) {          // half h (its bias is in bqa when h is even or SPREAD == 8, else bqb), then the fetch of the half after the next
+  auto last = [&](auto h_c) {          // half h (its bias is in bqa when h is even, else in bqb), then behind every unit the fetch of the next one's pair
     constexpr int h = decltype(h_c)::value;
-    if constexpr (SPREAD == 4) pp_wait_lds(bqa, bqb); else pp_wait_lds1(bqa);
+    pp_wait_lds(bqa, bqb);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SPREAD == 4 && (h & 1)) half(h_c, bqb); else half(h_c, bqa);
+    if constexpr (h & 1) half(h_c, bqb); else half(h_c, bqa);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (SPREAD == 4) {
-      if constexpr (h & 1) { fetch(IC<(h + 1 < 16 ? h + 1 : -1)>{}, bqa, pbias); fetch(IC<(h + 2 < 16 ? h + 2 : -1)>{}, bqb, pbias); }
-    } else {
-      fetch(IC<(h + 1 < 16 ? h + 1 : -1)>{}, bqa, pbias);
-    }
+    if constexpr (h & 1) { fetch(IC<(h + 1 < 16 ? h + 1 : -1)>{}, bqa, pbias); fetch(IC<(h + 2 < 16 ? h + 2 : -1)>{}, bqb, pbias); }
   };
   last(IC<0>{}); last(IC<1>{}); last(IC<2>{}); last(IC<3>{}); last(IC<4>{}); last(IC<5>{}); last(IC<6>{}); last(IC<7>{});
   last(IC<8>{}); last(IC<9>{}); last(IC<10>{}); last(IC<11>{}); last(IC<12>{}); last(IC<13>{}); last(IC<14>{}); last(IC<15>{});
@@ -1841,11 +1845,12 @@ int launch_pp(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
     grid.x += (a.N + SK_BN - 1) / SK_BN;
   }
   // drain schedule: the 16 half-units of a finished tile over 8 K-steps where the tile has them to spare (K >= 768), else over 4
-  // (SPREAD = 8, one half-unit per phase over eight K-steps, was built for the GELU drain and measured the same as 4 -- 77.8 vs 77.6 us on
-  //  fc1, profiles/r05_gemm_p8_table_v2.txt -- at 256 registers; only the 4-K-step schedule is instantiated)
-  void (*kfn)(GemmParams) = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, 4> : gemm_nt_pp_kernel<DU_ACT_NONE, 4>;
-  static bool attr_set[2] = {false, false};
-  const int ai = a.act == DU_ACT_GELU ? 1 : 0;
+  const bool nk4 = a.K == 256;
+  void (*kfn)(GemmParams);
+  if (nk4) kfn = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, true> : gemm_nt_pp_kernel<DU_ACT_NONE, true>;
+  else kfn = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, false> : gemm_nt_pp_kernel<DU_ACT_NONE, false>;
+  static bool attr_set[4] = {false, false, false, false};
+  const int ai = (a.act == DU_ACT_GELU ? 1 : 0) + (nk4 ? 2 : 0);
   if (!attr_set[ai]) {
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess) return DU_ERR_LAUNCH;
     attr_set[ai] = true;
@@ -1964,7 +1969,7 @@ static bool p8_legal(const du_gemm_args& a) {
 static bool pp_legal(const du_gemm_args& a) {
   if (!p8_legal(a) || a.out_dtype != DU_BF16 || a.store_mode != DU_STORE_PLAIN || a.batch > 1) return false;
   if (a.residual || a.gamma || a.row_scale || a.alpha != 1.0f || (a.act != DU_ACT_NONE && a.act != DU_ACT_GELU)) return false;
-  if (a.K < 512 || a.N % 8 || a.ldc % 8 || (((uintptr_t)a.C) & 15)) return false;
+  if ((a.K != 256 && a.K < 384) || a.N % 8 || a.ldc % 8 || (((uintptr_t)a.C) & 15)) return false;      // (K = 256: the four-K-step form)
   const long lim = 0x7fffffffL;
   return ((long)a.M * a.lda + a.K) * 2 < lim && ((long)a.N * a.ldb + a.K) * 2 < lim && ((long)a.M * a.ldc + a.N) * 2 < lim;
 }
@@ -1997,7 +2002,7 @@ int du_gemm_p8_choice(const du_gemm_args& a) {
   // x 512 six against three (56.3 vs 66.8); FAPM's 131072 x 512 x 1024 (8 tiles against 4 full rounds: 161 vs 141 us) and the big
   // square / 7B products stay on the wide tile (profiles/r05_gemm_p8_table_v2.txt)
   if (g_p8_persist && pp_legal(a)) {
-    const double r = a.K <= 512 ? 0.45 : (a.act == DU_ACT_GELU ? 0.49 : 0.53);
+    const double r = a.K <= 256 ? 0.40 : (a.K <= 512 ? 0.45 : (a.act == DU_ACT_GELU ? 0.49 : 0.53));
     const double cpp = (double)((t128 + cus - 1) / cus) * r;
     const double best = (t256 * g_p8_corun >= 128 && c256 <= c128) ? c256 : c128;
     if (g_p8_persist > 1 || (t128 >= 2 * cus && cpp < best)) return 4;

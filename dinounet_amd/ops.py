@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SWIGLU, DU_BF16, DU_F32, IM2COL_COL, IM2COL_ROW, PLAIN_COL,
-                   PLAIN_ROW, STORE_PIXEL_SHUFFLE2, STORE_QKV_ROPE, ConvGeom, GemmArgs)
+                   PLAIN_ROW, STORE_PIXEL_SHUFFLE2, STORE_QKV_ROPE, STORE_SLABS, ConvGeom, GemmArgs)
 
 __all__ = ["mm", "linear", "conv2d", "conv_transpose2x2", "norm_act", "layer_norm", "msda", "dwconv3x3",
            "maxpool3x3s2", "bilinear_add", "bilinear_resize", "squeeze_excite", "dice_ce_loss"]
@@ -924,6 +924,21 @@ def _im2col_split(M, N, K):
     return max(2, min(8, 256 // tiles, K // 256))
 
 
+def _conv_splitk(sk, M, N, K, a, lda, w, ldb, g, out):
+    """implicit GEMM cut into sk K ranges: every range writes its fp32 partial product to its own slab (DU_STORE_SLABS: plain stores, no
+    zero fill, no atomics) and du_splitk_reduce_bf16 adds the slabs in order -- the result does not depend on the order in which the
+    workgroups finish (a forward pass whose bits changed from run to run would make every repeat-run test a tolerance test)."""
+    slabs = torch.empty((sk, M, N), dtype=torch.float32, device=a.device)
+    # (the library rounds the K range per split up to whole K tiles and may run fewer splits than asked: slabs it does not write must not
+    #  be read -- ask it how many it will use)
+    kps = -(-K // sk)
+    kps = -(-kps // 64) * 64
+    used = -(-K // kps)
+    gemm_raw(dtype=DU_BF16, out_dtype=DU_F32, a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=M, N=N, K=K, A=a.data_ptr(), lda=lda,
+             B=w.data_ptr(), ldb=ldb, Cmat=slabs.data_ptr(), ldc=N, split_k=sk, store_mode=STORE_SLABS, geom=g)
+    _lib.check(_lib.lib().du_splitk_reduce_bf16(_p(slabs), _p(out), used, M * N, _st()), "du_splitk_reduce_bf16")
+
+
 def conv_fwd(x, wp, bias, KH, KW, stride, pad, x2=None, out=None, act=ACT_NONE):
     _req(x, wp)
     if KH == 3 and KW == 3 and stride == 1 and pad == 1 and out is None and act == ACT_NONE:
@@ -941,10 +956,7 @@ def conv_fwd(x, wp, bias, KH, KW, stride, pad, x2=None, out=None, act=ACT_NONE):
     _, _, _, _, ldc = _nhwc(out)
     sk = _im2col_split(B * Ho * Wo, Cout, Kc) if (x.dtype == torch.bfloat16 and bias is None and act == ACT_NONE and out.is_contiguous()) else 0
     if sk:
-        acc = ZEROS.zeros((B * Ho * Wo, Cout), x.device)
-        gemm_raw(dtype=DU_BF16, out_dtype=DU_F32, a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * Ho * Wo, N=Cout, K=Kc, A=x.data_ptr(), lda=ld,
-                 B=wp.data_ptr(), ldb=ldb, Cmat=acc.data_ptr(), ldc=Cout, split_k=sk, geom=g)
-        _lib.check(_lib.lib().du_cast(DU_F32, DU_BF16, _p(acc), _p(out), acc.numel(), _st()), "du_cast")
+        _conv_splitk(sk, B * Ho * Wo, Cout, Kc, x, ld, wp, ldb, g, out)
         return out
     gemm_raw(dtype=_code(x.dtype), out_dtype=_code(out.dtype), a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * Ho * Wo, N=Cout,
              K=Kc, A=x.data_ptr(), lda=ld, B=wp.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=ldc, bias=_dp(bias), act=act,
@@ -963,10 +975,7 @@ def conv_dgrad(dy, wd, KH, KW, stride, pad, Hin, Win, out=None):
     _, _, _, _, ldc = _nhwc(out)
     sk = _im2col_split(B * Hin * Win, Cin, Kc) if (dy.dtype == torch.bfloat16 and out.is_contiguous()) else 0
     if sk:
-        acc = ZEROS.zeros((B * Hin * Win, Cin), dy.device)
-        gemm_raw(dtype=DU_BF16, out_dtype=DU_F32, a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * Hin * Win, N=Cin, K=Kc, A=dy.data_ptr(), lda=ld,
-                 B=wd.data_ptr(), ldb=ldb, Cmat=acc.data_ptr(), ldc=Cin, split_k=sk, geom=g)
-        _lib.check(_lib.lib().du_cast(DU_F32, DU_BF16, _p(acc), _p(out), acc.numel(), _st()), "du_cast")
+        _conv_splitk(sk, B * Hin * Win, Cin, Kc, dy, ld, wd, ldb, g, out)
         return out
     gemm_raw(dtype=_code(dy.dtype), out_dtype=_code(out.dtype), a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * Hin * Win, N=Cin,
              K=Kc, A=dy.data_ptr(), lda=ld, B=wd.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=ldc, geom=g)

@@ -68,6 +68,9 @@ extern "C" {
 
 /* du_gemm store modes */
 #define DU_STORE_PLAIN 0
+#define DU_STORE_SLABS 4 /* split_k > 1, fp32 result, generic bf16 engine only: split s writes its partial product with plain stores to
+                            C + s * M * ldc (split_k slabs of M x ldc floats, no zero fill needed) instead of adding into C atomically --
+                            the caller reduces the slabs in a fixed order (du_splitk_reduce_bf16): bit-reproducible results */
 #define DU_STORE_TAPS 3 /* grouped convolution weight gradients only (du_gemm_tn_group: du_tn_job.taps): column n = (tap, c) of the product is
                            element (m, c, tap) of a torch-layout weight gradient */
 #define DU_STORE_QKV_ROPE 2 /* the ViT's qkv projection stored head-major with RoPE: row m = (b, token t) of M = B * ps_H tokens, column
@@ -388,6 +391,8 @@ int du_swiglu_pairs(int dtype, const void* u, void* out, int64_t rows, int64_t h
    (batch-subset stochastic depth of the ViT-7B blocks in train mode, layers/block.py:126-187) */
 int du_sample_copy(const float* src, float* dst, const int64_t* idx, int k, int64_t n_per_sample, int scatter, void* stream);
 int du_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
+/* out[i] = bf16( sum_{s < splits, in order} slabs[s * n + i] ): the second half of a DU_STORE_SLABS split-K product (n % 4 == 0) */
+int du_splitk_reduce_bf16(const float* slabs, void* out, int splits, int64_t n, void* stream);
 /* NCHW fp32 image -> NHWC `dtype` with channels zero-padded to Cpad */
 int du_nchw_to_nhwc_pad(int dst_dtype, const float* src, void* dst, int B, int C, int H, int W, int Cpad, void* stream);
 /* NHWC `dtype` (pixel stride ld) -> NCHW fp32 */

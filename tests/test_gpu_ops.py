@@ -84,7 +84,9 @@ def test_gemm_plain_epilogues(dt, M, N, K):
                                               # tiles per workgroup with ragged last tile rows AND columns, K at its lower limit (drain over 4
                                               # K-steps) and above 768 with GELU (drain over 8), no bias, one tile per workgroup
                                               (70000, 264, 512, False, "bias"), (33000, 1000, 896, False, "gelu"), (33000, 1000, 640, False, "gelu"),
-                                              (43008, 1024, 512, False, "none"), (5000, 136, 2048, False, "bias")])
+                                              (43008, 1024, 512, False, "none"), (5000, 136, 2048, False, "bias"),
+                                              # ... K = 256 (the four-K-step form: the drain runs under the whole next tile) and K = 384
+                                              (43008, 1024, 256, False, "bias"), (70000, 264, 256, False, "gelu"), (33000, 520, 384, False, "bias")])
 def test_gemm_multiphase_nt(mode, M, N, K, f32out, epi):
     """256 x 256 (mode 1), 256 x 128 (mode 2) and persistent 256 x 128 (mode 4, round 5; where its epilogue rules do not hold the library
     runs the mode-2 kernel) multi-phase NT kernels (gemm_p8.hip) forced through du_set_option, on the ViT-L products and ragged shapes:

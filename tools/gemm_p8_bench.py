@@ -37,7 +37,9 @@ def check():
              (2048, 384, 1536, bf, 0), (8192, 3072, 1024, bf, 2), (8192, 3072, 1024, torch.float32, 0), (4096, 4096, 512, bf, 0),
              (8232, 1280, 256, bf, 3), (8232, 1000, 512, torch.float32, 1),
              # persistent kernel: several tiles per workgroup with ragged last tile rows / columns, K at its lower limit, bias and GELU
-             (70000, 264, 512, bf, 1), (33000, 1000, 640, bf, 3), (43008, 1024, 512, bf, 1), (5000, 136, 2048, bf, 0)]
+             (70000, 264, 512, bf, 1), (33000, 1000, 640, bf, 3), (43008, 1024, 512, bf, 1), (5000, 136, 2048, bf, 0),
+             # ... its K = 256 form (four K-steps per tile, three bias slots) and K = 384
+             (43008, 1024, 256, bf, 1), (70000, 264, 256, bf, 3), (9000, 1000, 256, bf, 0), (33000, 520, 384, bf, 1)]
     for M, N, K, od, epi in cases:
         x, w = rnd(M, K).to(bf), (rnd(N, K) * 0.05).to(bf)
         bias = rnd(N) if epi else None
