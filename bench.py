@@ -158,7 +158,9 @@ def main():
         for what, e0, e1 in small:
             small_cnt[what] = small_cnt.get(what, 0) + 1
             small_ms += e0.elapsed_time(e1)
-        comm = {"gradient_buckets_elems": nb, "gradient_bytes_per_step": 4 * sum(nb), "gradient_allreduces_per_step": len(nb),
+        comm = {"capture": ts.capture_mode,     # whole_step (RCCL kernels inside the hipGraph) | segments(n) (DINOUNET_COMM_OUTSIDE_GRAPH=1 or
+                                                # the fallback when the whole-step capture fails: collectives issued between n graphs) | eager
+                "gradient_buckets_elems": nb, "gradient_bytes_per_step": 4 * sum(nb), "gradient_allreduces_per_step": len(nb),
                 # measured on the 2 eager steps: how many latency-bound all-reduces (SyncBatchNorm statistics, batch-Dice sums) a step issues
                 # and how long the compute stream spends in them (they sit on the critical path; absent at world size 1)
                 "small_collectives_per_step": {k: v // 2 for k, v in small_cnt.items()},

@@ -114,6 +114,7 @@ class KernelProfile:
 PROFILE = None
 
 
+CAPTURE_CUT = None           # training.TrainStep while it captures a step in segments: callable(eager_fn, what) ending the current graph
 SMALL_COLLECTIVES = None     # bench.py (N > 1 / forced reducer): list -> every small all-reduce of an eager step is bracketed by HIP events
 
 
@@ -121,7 +122,13 @@ def _small_all_reduce(t, group, what):
     """the step's latency-bound collectives (SyncBatchNorm statistics forward / backward, the batch-Dice sums): <= 2 KB each, on the
     critical path.  With SMALL_COLLECTIVES set (eager steps only) each one is bracketed by events on the compute stream so the bench
     line can say what they cost at N ranks (VERDICT r4 next #6)."""
-    rec = SMALL_COLLECTIVES is not None and t.is_cuda and not torch.cuda.is_current_stream_capturing()
+    capturing = t.is_cuda and torch.cuda.is_current_stream_capturing()
+    if capturing and CAPTURE_CUT is not None:
+        # a step captured in segments (training.TrainStep, DINOUNET_COMM_OUTSIDE_GRAPH=1): the graph ends here, the collective is issued
+        # from the host on every replay, the next graph begins
+        CAPTURE_CUT(lambda: torch.distributed.all_reduce(t, group=group), what)
+        return
+    rec = SMALL_COLLECTIVES is not None and t.is_cuda and not capturing
     if rec:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -2092,7 +2099,7 @@ class _DiceCE(torch.autograd.Function):
         sums = torch.empty(1 + 3 * (K - 1), dtype=torch.float32, device=logits.device)
         _lib.check(L.du_dice_ce_sums(_p(logits), _p(tgt), _p(sums), B, K, HW, _p(ws), n, _st()), "du_dice_ce_sums")
         mult = 1.0
-        if group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+        if group is not None and torch.distributed.is_initialized():   # (dc_and_ce_loss passes a group only for a DDP loss)
             _small_all_reduce(sums[1:], group, "dice_sums")
             mult = float(torch.distributed.get_world_size(group))
         loss = torch.empty(1, dtype=torch.float32, device=logits.device)

@@ -80,6 +80,7 @@ class GradAllReducer:
             self.buckets.append(cur)
         self.flat, self.views, self.pending, self.works, self.gather = [], [], [], [], []
         self.timeline = None         # list -> eager steps record, per bucket, (ready on the compute stream, all-reduce start, all-reduce done)
+        self.defer = False           # True while TrainStep captures a step in segments: hooks gather, reduce_deferred() all-reduces (see there)
         self._hooks = []
         self._keep = []
         dev = named[0][1].device
@@ -156,6 +157,8 @@ class GradAllReducer:
         return hook
 
     def _launch(self, bi):
+        if self.defer:
+            return
         flat = self.flat[bi]
         if self.is_cuda:
             rec = self.timeline is not None and not torch.cuda.is_current_stream_capturing()
@@ -179,25 +182,54 @@ class GradAllReducer:
         else:
             self.works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def finish(self):
-        """Wait for every bucket, install the averaged gradients (views of the flat buffers) as p.grad, re-arm."""
+    def reduce_deferred(self):
+        """Every bucket's all-reduce issued from the host, all at once, after the backward pass: the collective leg of a step captured
+        in segments (training.TrainStep, DINOUNET_COMM_OUTSIDE_GRAPH=1: graph | this | graph).  No collective is recorded into a
+        hipGraph in that mode, at the price of the overlap with backward: the buckets queue on RCCL's stream back to back and the
+        compute stream waits for the last one.  Stateless (no hook bookkeeping): it runs once per REPLAY, where no Python hook fires."""
+        if self.is_cuda:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                works = [dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for f in self.flat]
+            for w in works:
+                w.wait()                 # stream-level: the compute stream trails each collective, the host does not block
+        else:
+            for w in [dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for f in self.flat]:
+                w.wait()
+
+    def fill_missing(self):
+        """Buckets some gradient of which never arrived (e.g. a frozen branch): reduce what there is."""
         if self.is_cuda:
             from . import ops
             ops.WGRAD.flush()
         for bi, b in enumerate(self.buckets):
-            if self.pending[bi] != 0:      # a gradient never arrived (e.g. frozen branch): reduce what we have
+            if self.pending[bi] != 0:
                 for j, (_, p) in enumerate(b):
                     if p.grad is None:
                         self.views[bi][j].zero_()
                     elif self.is_cuda:
                         self.views[bi][j].copy_(p.grad)
+                self.pending[bi] = 0
                 self._launch(bi)
-            self.works[bi].wait()
-            if self.is_cuda:
-                torch.cuda.current_stream().wait_stream(self.side)
+
+    def finish(self):
+        """Wait for every bucket, install the averaged gradients (views of the flat buffers) as p.grad, re-arm."""
+        self.fill_missing()
+        for bi, b in enumerate(self.buckets):
+            if self.works[bi] is not None:      # (None: deferred mode, reduce_deferred() has run / will run between the two graphs)
+                self.works[bi].wait()
+                if self.is_cuda:
+                    torch.cuda.current_stream().wait_stream(self.side)
             self.flat[bi].div_(self.world)
             for j, (_, p) in enumerate(b):
                 p.grad = self.views[bi][j]
+            self.pending[bi] = len(b)
+            self.works[bi] = None
+        self._keep.clear()
+
+    def rearm(self):
+        """Forget a step that did not reach finish() (a capture that raised part-way through backward)."""
+        for bi, b in enumerate(self.buckets):
             self.pending[bi] = len(b)
             self.works[bi] = None
         self._keep.clear()

@@ -2,6 +2,9 @@
 (dinounet/training/nnUNetTrainer/nnUNetTrainer.py:899-929): forward -> DC+CE loss -> backward -> clip_grad_norm_(12)
 -> SGD(nesterov, momentum 0.99, wd 3e-5).  On the GPU the loss is the fused Dice+CE kernel pair (csrc/loss.hip) and clip + SGD the
 fused three-launch optimiser (csrc/optim.hip); the torch formula below serves the CPU / many-class path of the gloo tests."""
+import os
+import threading
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -57,6 +60,60 @@ def dc_and_ce_loss(logits, target, smooth=1e-5, ddp=None, group=None):
     return ce - dc.mean()
 
 
+class _CaptureSegments:
+    """A train step recorded as SEVERAL hipGraphs with host-issued work between them (DINOUNET_COMM_OUTSIDE_GRAPH=1, or the fallback
+    when the capture of a whole multi-rank step fails): graph | batch-Dice all-reduce | graph | gradient all-reduces | graph.  No RCCL
+    call is recorded into a graph; everything else keeps the replay's launch path.  The graphs share one memory pool and are replayed
+    in capture order, so a tensor made in one segment is alive in the next.  A cut ends the running capture, which HIP only allows from
+    the thread that began it: cuts happen at main-thread points of the step (the loss forward, after backward), never inside autograd's
+    device thread."""
+
+    def __init__(self, mode):
+        self.mode = mode
+        self.graphs, self.between, self.what = [], [], []
+        self.pool = torch.cuda.graph_pool_handle()
+        self.cur = None
+        self.thread = threading.get_ident()
+
+    def begin(self):
+        self.cur = torch.cuda.CUDAGraph()
+        self.cur.capture_begin(pool=self.pool, capture_error_mode=self.mode)
+
+    def cut(self, eager_fn, what="cut"):
+        if threading.get_ident() != self.thread:
+            raise RuntimeError(f"segmented capture: '{what}' asks for a cut from a thread that did not begin the capture")
+        self.cur.capture_end()
+        self.graphs.append(self.cur)
+        self.between.append(eager_fn)
+        self.what.append(what)
+        self.begin()
+
+    def end(self):
+        self.cur.capture_end()
+        self.graphs.append(self.cur)
+        self.between.append(None)
+        self.cur = None
+
+    def abort(self):
+        if self.cur is not None:
+            try:
+                self.cur.capture_end()
+            except Exception:  # noqa: BLE001
+                pass
+            self.cur = None
+
+    def replay(self):
+        for g, fn in zip(self.graphs, self.between):
+            g.replay()
+            if fn is not None:
+                fn()
+
+    def reset(self):
+        for g in self.graphs:
+            g.reset()
+        self.graphs, self.between, self.what = [], [], []
+
+
 class TrainStep:
     """One optimiser step of the reference trainer (nnUNetTrainer.py:899-929) on static input buffers:
     zero_grad -> forward -> DC+CE -> backward [-> bucketed RCCL all-reduce] -> clip_grad_norm_(12) -> SGD step.
@@ -66,8 +123,15 @@ class TrainStep:
     (MI355X guide: "capture launch-bound inner loops in hipGraphs").  Device-side RNG (drop-path masks, RoPE rescale) stays
     live under replay because torch registers the generator's Philox offset with the graph."""
 
-    def __init__(self, net, optimizer, params, x_shape, tgt_shape, device, reducer=None, max_norm=12.0, graph=True, warmup=3):
+    def __init__(self, net, optimizer, params, x_shape, tgt_shape, device, reducer=None, max_norm=12.0, graph=True, warmup=3,
+                 ddp_loss=None, comm_outside_graph=None):
         self.net, self.opt, self.params, self.reducer, self.max_norm = net, optimizer, params, reducer, max_norm
+        self.ddp_loss = ddp_loss         # None: batch-Dice sums all-reduced iff world size > 1 (dice.py:58-119 with ddp=True)
+        if comm_outside_graph is None:
+            comm_outside_graph = os.environ.get("DINOUNET_COMM_OUTSIDE_GRAPH", "0") == "1"
+        self.comm_outside_graph = bool(comm_outside_graph) and reducer is not None
+        self.capture_mode = "eager"      # -> "whole_step" | "segments(n)" once a capture exists (bench.py reports it)
+        self._segments = None
         self.x = torch.zeros(x_shape, device=device)
         self.tgt = torch.zeros(tgt_shape, dtype=torch.long, device=device)
         self.loss = None
@@ -81,12 +145,15 @@ class TrainStep:
     def _step(self):
         self.opt.zero_grad(set_to_none=True)
         logits = self.net(self.x)
-        loss = dc_and_ce_loss(logits, self.tgt)
+        loss = dc_and_ce_loss(logits, self.tgt, ddp=self.ddp_loss)
         loss.backward()
         if logits.is_cuda:
             from . import ops
             ops.WGRAD.flush()          # deferred weight gradients (already flushed by the engine callback; idempotent)
         if self.reducer is not None:
+            if self._segments is not None:                  # segmented capture: every bucket's all-reduce from the host, between two graphs
+                self.reducer.fill_missing()
+                self._segments.cut(self.reducer.reduce_deferred, "gradient_buckets")
             if self.comm_events is not None:               # bench.py: how long the step waits for the gradient all-reduce after backward
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -102,6 +169,29 @@ class TrainStep:
             torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
             self.opt.step()
         return loss.detach()
+
+    def _capture_in_segments(self, mode):
+        import gc
+        from . import ops
+        seg = _CaptureSegments(mode)
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        self._segments, ops.CAPTURE_CUT, self.reducer.defer = seg, seg.cut, True
+        try:
+            with torch.cuda.stream(s):
+                seg.begin()
+                self.loss = self._step()
+                seg.end()
+        except BaseException:
+            seg.abort()
+            raise
+        finally:
+            self._segments, ops.CAPTURE_CUT, self.reducer.defer = None, None, False
+        torch.cuda.current_stream().wait_stream(s)
+        return seg
 
     def __call__(self, x=None, tgt=None):
         if x is not None:
@@ -129,24 +219,41 @@ class TrainStep:
                 # watchdog has nothing to query during the capture (collectives issued INSIDE a capture are not handed to it).
                 import time
                 time.sleep(0.35)
-            try:
-                graph = torch.cuda.CUDAGraph()
-                # With a process group alive, ProcessGroupNCCL's watchdog thread polls its work events (hipEventQuery) while this
-                # thread captures; under the default "global" capture mode that call is illegal and the watchdog aborts the process
-                # ("operation not permitted when stream is capturing").  thread_local confines the capture restrictions to this thread.
-                mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
-                with torch.cuda.graph(graph, capture_error_mode=mode):
-                    self.loss = self._step()
-                self.graph = graph
-                self._opt_generation = getattr(self.opt, "generation", 0)
-            except Exception as e:  # noqa: BLE001   capture is an optimisation: a step that cannot be captured still has to train
+            # With a process group alive, ProcessGroupNCCL's watchdog thread polls its work events (hipEventQuery) while this
+            # thread captures; under the default "global" capture mode that call is illegal and the watchdog aborts the process
+            # ("operation not permitted when stream is capturing").  thread_local confines the capture restrictions to this thread.
+            mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+            err = None
+            if not self.comm_outside_graph:
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, capture_error_mode=mode):
+                        self.loss = self._step()
+                    self.graph = graph
+                    self.capture_mode = "whole_step"
+                except Exception as e:  # noqa: BLE001
+                    err = e
+                    torch.cuda.synchronize()
+                    if self.reducer is not None:
+                        self.reducer.rearm()
+            if self.graph is None and self.reducer is not None:
+                # the collectives outside the graphs: asked for, or the capture of the whole step (RCCL kernels recorded into it) failed
+                try:
+                    self.graph = self._capture_in_segments(mode)
+                    self.capture_mode = f"segments({len(self.graph.graphs)})"
+                    err = None
+                except Exception as e:  # noqa: BLE001
+                    err = e
+                    torch.cuda.synchronize()
+                    self.reducer.rearm()
+            if self.graph is None:     # capture is an optimisation: a step that cannot be captured still has to train
                 import warnings
-                warnings.warn(f"hipGraph capture of the train step failed ({e!r}); continuing with eager steps")
+                warnings.warn(f"hipGraph capture of the train step failed ({err!r}); continuing with eager steps")
                 self.use_graph = False
-                self.graph = None
                 torch.cuda.synchronize()
                 self.loss = self._step()
                 return self.loss
+            self._opt_generation = getattr(self.opt, "generation", 0)
         if isinstance(self.opt, FusedClipSGD):
             if getattr(self.opt, "generation", 0) != self._opt_generation:
                 # optimizer.load_state_dict / reallocated parameters since the capture: the recorded step points at retired tables and

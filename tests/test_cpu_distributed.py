@@ -45,6 +45,21 @@ def _worker(rank, world, port, q):
         ((net(xs) - ts) ** 2).mean().backward()
         red.finish()
     grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    # the collective leg of a step captured in segments (training._CaptureSegments): hooks only gather, every bucket is all-reduced
+    # after backward by reduce_deferred(), finish() divides and installs -- same averaged gradients, and the hooks re-arm
+    for _ in range(2):
+        for p in net.parameters():
+            p.grad = None
+        red.defer = True
+        ((net(xs) - ts) ** 2).mean().backward()
+        assert all(w is None for w in red.works)
+        red.fill_missing()
+        red.reduce_deferred()
+        red.finish()
+        red.defer = False
+        for n, p in net.named_parameters():
+            if p.grad is not None:
+                assert torch.allclose(p.grad, grads[n], atol=1e-7), n
     # DDP batch-dice: loss/grad must equal the single-process loss on the concatenated batch
     lg = torch.randn(4, 3, 8, 8, generator=torch.Generator().manual_seed(2)).requires_grad_(True)
     tg = torch.randint(0, 3, (4, 1, 8, 8), generator=torch.Generator().manual_seed(3))

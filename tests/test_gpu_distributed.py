@@ -174,6 +174,78 @@ def test_single_rank_rccl_reducer_inside_the_captured_step_bench():
     ratio = forced["value"] / plain["value"]
     print(f"single-rank RCCL reducer in the captured step: {forced['value']:.1f} vs {plain['value']:.1f} slices/s (ratio {ratio:.3f}); comm {forced['comm']}")
     assert ratio > 0.95, (forced["value"], plain["value"])
+    assert c["capture"] == "whole_step", c["capture"]
+    # the same run with the collectives OUTSIDE the graphs (graph | every bucket's all-reduce from the host | graph): the measured price
+    # of the fallback a multi-rank capture problem degrades to -- no overlap with backward, two graph launches instead of one
+    outside = run(dict(fenv, DINOUNET_COMM_OUTSIDE_GRAPH="1", MASTER_PORT=str(_free_port())))
+    assert outside["hipgraph"] and outside["comm"]["capture"] == "segments(2)", outside.get("comm")
+    r2 = outside["value"] / plain["value"]
+    print(f"collectives outside the graphs: {outside['value']:.1f} slices/s (ratio {r2:.3f} to the plain step)")
+    assert r2 > 0.93, (outside["value"], plain["value"])
+
+
+def test_step_captured_in_segments_with_every_collective_outside_the_graphs():
+    """`DINOUNET_COMM_OUTSIDE_GRAPH=1` (TrainStep(comm_outside_graph=True)) records the step as three hipGraphs with the
+    batch-Dice all-reduce and the gradient-bucket all-reduces issued from the host between them (no RCCL kernel inside a graph) -- the
+    measured alternative a multi-rank run degrades to if the whole-step capture fails, instead of fully eager steps.  On a live single-rank
+    RCCL group (Dice collective forced): the segmented step must train exactly like the whole-step capture (same kernels in the same
+    order: losses and parameters over 2 eager + 4 replayed steps agree to the round-off of the step's fp32 atomics)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import json, os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from dinounet_amd.plans import PLANS_2D
+from dinounet_amd.network_architecture import DinoUNet
+from dinounet_amd.dinov3.adapter import DropPath
+from dinounet_amd.parallel import GradAllReducer
+from dinounet_amd.training import TrainStep
+from dinounet_amd.optim import FusedClipSGD
+dev = torch.device("cuda", 0)
+g = torch.Generator().manual_seed(3)
+x = torch.randn(2, 3, 128, 128, generator=g).to(dev); t = torch.randint(0, 2, (2, 1, 128, 128), generator=g).to(dev)
+out = {}
+for mode in ("whole", "segments"):
+    torch.manual_seed(7)
+    net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name="dinounet_s", precision="bf16").to(dev).train()
+    for m in net.modules():
+        if isinstance(m, DropPath):
+            m.drop_prob = 0.0
+    net.encoder.dinov3_adapter.backbone.rope_embed.rescale_coords = None
+    params = [p for p in net.parameters() if p.requires_grad]
+    red = GradAllReducer(net, 1, bucket_elems=1 << 20)
+    opt = FusedClipSGD(params, lr=1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5, max_norm=12.0)
+    ts = TrainStep(net, opt, params, x.shape, t.shape, dev, reducer=red, graph=True, warmup=2, ddp_loss=True, comm_outside_graph=(mode == "segments"))
+    losses = [float(ts(x, t)) for _ in range(6)]
+    torch.cuda.synchronize()
+    out[mode] = {"capture": ts.capture_mode, "losses": losses, "buckets": len(red.buckets),
+                 "what": list(getattr(ts.graph, "what", [])),
+                 "params": [float(p.detach().double().sum()) for p in params], "absmax": [float(p.detach().abs().max()) for p in params]}
+    ts.graph.reset(); ts.graph = None
+    red.remove(); del ts, red, opt, net
+print(json.dumps(out))
+dist.destroy_process_group()
+""" % root
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, DINOUNET_ALLOW_RANDOM_BACKBONE="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.pop("DINOUNET_COMM_OUTSIDE_GRAPH", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    w, sg = out["whole"], out["segments"]
+    assert w["capture"] == "whole_step" and sg["capture"] == "segments(3)", (w["capture"], sg["capture"])
+    assert sg["what"] == ["dice_sums", "gradient_buckets"] and sg["buckets"] >= 2, sg["what"]
+    assert all(l == l for l in sg["losses"]) and sg["losses"][-1] != sg["losses"][0]          # finite, and the replays do train
+    # same kernels in the same order; the few fp32-atomic reductions of the step (MSDA backward) make two runs differ in the last bits
+    assert max(abs(a - b) for a, b in zip(sg["losses"], w["losses"])) < 2e-3, (sg["losses"], w["losses"])
+    assert max(abs(a - b) / (1.0 + abs(b)) for a, b in zip(sg["params"], w["params"])) < 1e-3
+    assert max(abs(a - b) / (1e-3 + abs(b)) for a, b in zip(sg["absmax"], w["absmax"])) < 2e-2
+    print(f"segmented capture {sg['capture']} cuts {sg['what']}: losses {sg['losses']} (whole-step capture {w['losses']}; identical {sg['losses'] == w['losses']})")
 
 
 def test_deferred_weight_gradients_flushed_per_bucket_match_the_undeferred_step():
