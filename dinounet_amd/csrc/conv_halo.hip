@@ -525,6 +525,266 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_halo_kernel(WgradParams P) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the same product with every fragment read ONCE per tile and two tiles in flight.
+//
+// What bounded the kernel above (profiles/r04: 1.3-2.9 TB/s, the matrix pipe 17 % busy): (1) a wave's accumulator tiles were dealt
+// round-robin over (tap, mt, nb), so every MFMA fetched both of its fragments -- 4 transpose reads per MFMA, 2x what the LDS pipe
+// delivers per matrix-pipe slot; (2) one tile (20-39 KB per CU) of loads in flight, consumed one iteration later: 5 MB on the chip
+// against the ~16 MB that 8 TB/s x 2 us of loaded latency ask for; (3) two barriers per tile.
+// Here a wave owns ALL 9 TAPS of one (mt, nb) block pair (9 accumulators = 144 registers) over RW of the tile's 8 rows:
+//   * the dY fragment of a k-step (one tile row) is read once and feeds 9 MFMAs;
+//   * the X fragment of halo row r and column shift dx serves tap (dy, dx) at k-step r - dy: a rolling window of 3 rows x 3 shifts
+//     stays in registers, 3 new fragments per k-step -- 8 transpose reads per 9 MFMAs instead of 36;
+//   * two LDS stages and two register sets: the loads of tile i + 3 are issued while tile i is multiplied (two tiles = 40-78 KB per
+//     CU in flight), a tile's registers -> LDS copy goes to the stage that is not being read, ONE barrier per tile;
+//   * (mt, nb) pairs fewer than 4 (32 output channels, or one 32-channel input block): the waves split the tile's rows RG ways and
+//     their accumulators are added through LDS once, after the tile loop (tap by tap, two alternating 16 KB buffers).
+// Slab layout, bias-gradient sums and the finalize pass are those of the kernel above.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CK, int MT>
+constexpr size_t wgrad_rows_lds() { return (size_t)2 * (HW_ * tr_pitch(CK) + 128 * tr_pitch(MT * 32)) * 2; }
+
+// one workgroup per CU with two register sets of prefetch, except the smallest form (32 -> 32 channels: 39 KB, 246 registers): two per CU
+template <int CK, int MT>
+constexpr bool wgrad_rows_two() { return !(MT == 1 && wgrad_rows_lds<CK, MT>() <= 80 * 1024); }
+
+template <int CK, int MT>
+__global__ __launch_bounds__(256, (wgrad_rows_two<CK, MT>() ? 1 : 2)) void conv3x3_wgrad_rows_kernel(WgradParams P) {
+  constexpr int COUT = MT * 32;
+  constexpr int NB = CK / 32;
+  static_assert(MT * NB == 1 || MT * NB == 2 || MT * NB == 4, "4 waves = (mt, nb) pairs x row groups");
+  constexpr int RG = 4 / (MT * NB), RW = TH / RG;       // row groups, tile rows per wave
+  constexpr int PX = tr_pitch(CK), PD = tr_pitch(COUT);
+  constexpr int CV = CK / 8, DV = COUT / 8;
+  constexpr int HV = (HW_ * CV + 255) / 256, YV = (128 * DV + 255) / 256;
+  constexpr int STAGE = HW_ * PX + 128 * PD;            // bf16 elements: [180][PX] halo + [128][PD] dY tile
+  constexpr bool TWO = wgrad_rows_two<CK, MT>();        // one workgroup per CU: two register sets of prefetch
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* S = (bf16_t*)smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, p16 = lane & 15;
+  const int txk = 8 * (g >> 1) + (p16 >> 2);            // pixel column this lane addresses in a transpose read (second read: + 4)
+  const int oc = 16 * (g & 1) + 4 * (p16 & 3);          // outer-index offset inside a 32-wide block
+  const int nb = wave % NB, mt = (wave / NB) % MT, rg = wave / (NB * MT);
+  const int r0 = rg * RW;
+  const int xoffb = txk * PX + nb * 32 + oc, yoffb = txk * PD + mt * 32 + oc;
+  const int nch = P.Cin / CK;
+  const int G = gridDim.x;
+
+  // per-thread constants of the staging copies (the same for every tile: without them the compiler rebuilt -- and kept live -- the
+  // divisions of every one of the 5 load and 3 store sites): LDS offsets, packed halo coordinates, pixel offsets relative to the tile
+  int hlds[HV], ylds[YV], hpix[HV], ypix[YV];
+  unsigned hpk[HV];
+#pragma unroll
+  for (int i = 0; i < HV; i++) {
+    const int v = tid + i * 256, pix = v / CV, cv = v % CV, py = pix / HXW, px = pix % HXW;
+    hlds[i] = pix * PX + cv * 8;
+    hpix[i] = (py - 1) * P.W + (px - 1);                 // x ld + cv * 8 + chunk offset: per chunk below
+    hpk[i] = v < HW_ * CV ? (unsigned)py | ((unsigned)px << 8) : 0xffffu;
+  }
+#pragma unroll
+  for (int i = 0; i < YV; i++) {
+    const int v = tid + i * 256, pix = v / DV, dv = v % DV;
+    ylds[i] = pix * PD + dv * 8;
+    ypix[i] = ((pix >> 4) * P.W + (pix & 15)) * (int)P.lddy + dv * 8;
+  }
+  static_assert((128 * DV) % 256 == 0, "whole dY vectors per thread");
+  // buffer descriptors: a halo pixel outside the image is requested at an offset beyond num_records and comes back as zeros (no branch)
+  const unsigned pixels = (unsigned)P.B * (unsigned)P.H * (unsigned)P.W;
+  const auto yrs = __builtin_amdgcn_make_buffer_rsrc((void*)P.dy, 0, (int)(pixels * (unsigned)P.lddy * 2u), 0x00020000);
+  float dbs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // bias gradient: see the kernel above
+  auto stores = [&](const uint4 (&hreg)[HV], const uint4 (&yreg)[YV], int stage, bool sum_dy) {
+    bf16_t* Xs = S + stage * STAGE;
+    bf16_t* Ys = Xs + HW_ * PX;
+#pragma unroll
+    for (int i = 0; i < HV; i++)
+      if ((i + 1) * 256 <= HW_ * CV || tid + i * 256 < HW_ * CV) *(uint4*)(Xs + hlds[i]) = hreg[i];
+#pragma unroll
+    for (int i = 0; i < YV; i++) {
+      *(uint4*)(Ys + ylds[i]) = yreg[i];
+      if (sum_dy) {
+        const bf16x8 t = __builtin_bit_cast(bf16x8, yreg[i]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) dbs[e] += (float)t[e];
+      }
+    }
+  };
+  auto trfrag = [&](const bf16_t* q, int pitch) -> bf16x8 {      // q: this lane's address of the first 4-pixel read
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)q);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(q + 4 * pitch));
+    s16x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, r);
+  };
+
+  if ((int)blockIdx.x >= P.ntiles) return;
+  for (int ch = 0; ch < nch; ch++) {
+    f32x16 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+    auto compute = [&](int stage) {
+      const bf16_t* Xs = S + stage * STAGE;
+      const bf16_t* Ys = Xs + HW_ * PX;
+      const bf16_t* xq = Xs + r0 * HXW * PX + xoffb;
+      const bf16_t* yq = Ys + r0 * 16 * PD + yoffb;
+      bf16x8 xw[3][3];
+#pragma unroll
+      for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) xw[d][dx] = trfrag(xq + (d * HXW + dx) * PX, PX);
+      bf16x8 fa = trfrag(yq, PD);
+#pragma unroll
+      for (int t = 0; t < RW; t++) {
+        // this step's reads: halo row t + 2 (first used by the 7th MFMA below) and the NEXT step's dY fragment; the step boundary is
+        // pinned -- left alone the scheduler hoists the reads of all 8 steps to the top (128 more live registers: it spilled)
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) xw[(t + 2) % 3][dx] = trfrag(xq + ((t + 2) * HXW + dx) * PX, PX);
+        bf16x8 fan = fa;
+        if (t + 1 < RW) fan = trfrag(yq + (t + 1) * 16 * PD, PD);
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+#pragma unroll
+          for (int dx = 0; dx < 3; dx++)
+            acc[d * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xw[(t + d) % 3][dx], acc[d * 3 + dx], 0, 0, 0);
+        fa = fan;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    const bool sdy = P.with_db && ch == 0;
+    const int c0 = ch * CK;
+    const bool second = c0 >= P.C1;
+    const int ldc = (int)(second ? P.ldx2 : P.ldx), cofs = second ? c0 - P.C1 : c0;
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? P.x2 : P.x), 0, (int)(pixels * (unsigned)ldc * 2u), 0x00020000);
+    int hrel[HV];
+#pragma unroll
+    for (int i = 0; i < HV; i++) hrel[i] = hpix[i] * ldc + (tid + i * 256) % CV * 8 + cofs;
+    auto loads = [&](uint4 (&hreg)[HV], uint4 (&yreg)[YV], int tile) {
+      // a tile beyond the last one: every lane asks beyond num_records (zeros, no traffic; the set is never copied to LDS).  No branch
+      // around the loads: with a path that issues none the compiler's counted waits in front of the OTHER set's copy collapse to
+      // vmcnt(0), i.e. one tile in flight again
+      const bool live = tile < P.ntiles;
+      const int tx0 = (tile % P.tilesX) * TW, t2 = tile / P.tilesX;
+      const int ty0 = (t2 % P.tilesY) * TH, b = t2 / P.tilesY;
+      const int org = (b * P.H + ty0) * P.W + tx0;        // pixel index of the tile's first output pixel
+#pragma unroll
+      for (int i = 0; i < HV; i++) {
+        const unsigned gy = (unsigned)(ty0 - 1) + (hpk[i] & 0xffu), gx = (unsigned)(tx0 - 1) + (hpk[i] >> 8);
+        const unsigned off = live && gy < (unsigned)P.H && gx < (unsigned)P.W ? (unsigned)(org * ldc + hrel[i]) * 2u : 0x80000000u;
+        hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < YV; i++)
+        yreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(yrs, live ? (org * (int)P.lddy + ypix[i]) * 2 : (int)0x80000000u, 0, 0));
+    };
+    uint4 hA[HV], yA[YV];
+    // workgroup i runs on XCD i % 8: give each XCD G / 8 CONSECUTIVE tiles of every round (two tile rows of a 256-wide image), so the
+    // one-pixel halo ring a tile shares with its neighbours is found in that XCD's L2 instead of being fetched once per XCD
+    int tile = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3), st = 0;
+    if constexpr (TWO) {
+      uint4 hB[HV], yB[YV];
+      loads(hA, yA, tile);
+      loads(hB, yB, tile + G);
+      stores(hA, yA, 0, sdy);
+      loads(hA, yA, tile + 2 * G);
+      __syncthreads();
+      for (;;) {
+        // stage st holds `tile`; set B holds tile + G, set A tile + 2 G (both in flight)
+        if (tile + G < P.ntiles) stores(hB, yB, st ^ 1, sdy);
+        loads(hB, yB, tile + 3 * G);
+        compute(st);
+        __syncthreads();
+        tile += G; st ^= 1;
+        if (tile >= P.ntiles) break;
+        // set A holds tile + G, set B tile + 2 G
+        if (tile + G < P.ntiles) stores(hA, yA, st ^ 1, sdy);
+        loads(hA, yA, tile + 3 * G);
+        compute(st);
+        __syncthreads();
+        tile += G; st ^= 1;
+        if (tile >= P.ntiles) break;
+      }
+    } else {                           // two workgroups per CU: one register set each (256 registers per wave), the CU still has two tiles in flight
+      loads(hA, yA, tile);
+      stores(hA, yA, 0, sdy);
+      loads(hA, yA, tile + G);
+      __syncthreads();
+      for (;;) {
+        if (tile + G < P.ntiles) stores(hA, yA, st ^ 1, sdy);
+        loads(hA, yA, tile + 2 * G);
+        compute(st);
+        __syncthreads();
+        tile += G; st ^= 1;
+        if (tile >= P.ntiles) break;
+      }
+    }
+    // (every LDS read of the tile loop is behind its last barrier: the stages are free as scratch)
+    const long slab = (long)COUT * 9 * P.Cin + (P.with_db ? COUT : 0);
+    if (sdy) {
+      float* red = (float*)smem_raw;   // [256][8]
+#pragma unroll
+      for (int e = 0; e < 8; e++) red[tid * 8 + e] = dbs[e];
+      __syncthreads();
+      if (tid < COUT) {                // channel tid = group (tid >> 3) element (tid & 7); contributors: threads with t % DV == tid >> 3
+        float sacc = 0.f;
+        for (int t = tid >> 3; t < 256; t += DV) sacc += red[t * 8 + (tid & 7)];
+        P.part[(long)blockIdx.x * slab + (long)COUT * 9 * P.Cin + tid] = sacc;
+      }
+      __syncthreads();
+    }
+    if constexpr (RG > 1) {            // add the row groups of each (mt, nb) pair into its rg = 0 wave
+      float4* red = (float4*)smem_raw; // [2][4 waves][4][64 lanes] float4 = 2 x 16 KB
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        float4* buf = red + (tap & 1) * 1024;
+        if (rg > 0) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            buf[(wave * 4 + j) * 64 + lane] = make_float4(acc[tap][4 * j], acc[tap][4 * j + 1], acc[tap][4 * j + 2], acc[tap][4 * j + 3]);
+        }
+        __syncthreads();               // (the buffer of tap - 1 is read before this barrier, that of tap + 1 written after it)
+        if (rg == 0) {
+#pragma unroll
+          for (int o = 1; o < RG; o++) {
+            const int w2 = wave + o * NB * MT;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const float4 v = buf[(w2 * 4 + j) * 64 + lane];
+              acc[tap][4 * j] += v.x; acc[tap][4 * j + 1] += v.y; acc[tap][4 * j + 2] += v.z; acc[tap][4 * j + 3] += v.w;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // flush this chunk's tiles: part[block][co][tap * Cin + ch * CK + ci]
+    if (rg == 0) {
+      float* dst = P.part + (long)blockIdx.x * slab;
+      // this lane's part of the 144 store addresses, made opaque here: left visible, the compiler builds all of them at kernel entry
+      // (they do not depend on the tile loop) and parks them in scratch -- 140 spills in, 137 reloads out
+      int voff = ((mt * 32 + 4 * (lane >> 5)) * 9) * P.Cin + ch * CK + nb * 32 + (lane & 31);
+      asm volatile("" : "+v"(voff));
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) dst[voff + (((r & 3) + 8 * (r >> 2)) * 9 + tap) * P.Cin] = acc[tap][r];
+      }
+    }
+  }
+}
+
+template <int CK, int MT>
+int launch_wgrad_rows(WgradParams& P, int max_blocks, hipStream_t st) {
+  constexpr size_t lds = wgrad_rows_lds<CK, MT>();
+  auto kfn = conv3x3_wgrad_rows_kernel<CK, MT>;
+  if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DU_ERR_LAUNCH;
+  int grid = max_blocks < P.ntiles ? max_blocks : P.ntiles;
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, P);
+  return du_check_launch();
+}
+
 template <int CK, int MT>
 int launch_wgrad(WgradParams& P, int max_blocks, hipStream_t st) {
   constexpr int COUT = MT * 32;
@@ -538,6 +798,8 @@ int launch_wgrad(WgradParams& P, int max_blocks, hipStream_t st) {
 
 }  // namespace
 
+int g_wgrad_rows = 1;     // du_set_option key 13: 1 = the round-5 weight-gradient kernel (conv3x3_wgrad_rows_kernel), 0 = the round-3 one (A-B aid)
+
 // number of workgroups (= partial dW slabs) the weight-gradient kernel uses for this shape; 0 = shape not served
 extern "C" int du_conv3x3_wgrad_halo_blocks(int C1, int Cin, int Cout, int B, int H, int W) {
   if (H % TH || W % TW || B <= 0) return 0;
@@ -550,7 +812,9 @@ extern "C" int du_conv3x3_wgrad_halo_blocks(int C1, int Cin, int Cout, int B, in
   // measured (bench A-B, round 3): 512^2 64->32 257 -> 168 us, 32->32 138 -> 93 us with 512 workgroups; the 64-output layers at 256^2
   // (147-295 KB slabs) lose 10 % to the doubled finalize traffic: two per CU only while a slab stays under 80 KB
   static const int cap_env = DU_GETENV("DU_HALO_WGRAD_BLOCKS") ? atoi(DU_GETENV("DU_HALO_WGRAD_BLOCKS")) : 0;
-  const int cap = cap_env > 0 ? cap_env : ((long)Cout * 9 * Cin * 4 <= 80L * 1024 ? 512 : 256);
+  int cap = cap_env > 0 ? cap_env : ((long)Cout * 9 * Cin * 4 <= 80L * 1024 ? 512 : 256);
+  // round-5 kernel: two LDS stages; all forms but 32 -> 32 channels run one workgroup per CU (72-118 KB), so a second slab per CU buys nothing
+  if (g_wgrad_rows && cap_env <= 0 && (Cout == 64 || (Cin % 64 == 0 && C1 % 64 == 0))) cap = 256;
   return ntiles < cap ? ntiles : cap;
 }
 
@@ -571,7 +835,13 @@ extern "C" int du_conv3x3_wgrad_halo(const void* x, int64_t ldx, const void* x2,
   P.with_db = with_db ? 1 : 0;
   const bool c64 = Cin % 64 == 0 && C1 % 64 == 0;
   int rc = DU_ERR_UNSUPPORTED;
-  if (Cout == 32) rc = c64 ? launch_wgrad<64, 1>(P, blocks, st) : launch_wgrad<32, 1>(P, blocks, st);
+  // the round-5 kernel addresses the three tensors through 32-bit buffer offsets
+  const long pix = (long)B * H * W;
+  const bool small = pix * ldx * 2 < 0x7fffffffL && pix * lddy * 2 < 0x7fffffffL && (!x2 || pix * ldx2 * 2 < 0x7fffffffL);
+  if (g_wgrad_rows && small) {
+    if (Cout == 32) rc = c64 ? launch_wgrad_rows<64, 1>(P, blocks, st) : launch_wgrad_rows<32, 1>(P, blocks, st);
+    else if (Cout == 64) rc = c64 ? launch_wgrad_rows<64, 2>(P, blocks, st) : launch_wgrad_rows<32, 2>(P, blocks, st);
+  } else if (Cout == 32) rc = c64 ? launch_wgrad<64, 1>(P, blocks, st) : launch_wgrad<32, 1>(P, blocks, st);
   else if (Cout == 64) rc = launch_wgrad<32, 2>(P, blocks, st);        // 32-channel chunks: 5 accumulator tiles per wave, no spills
   if (rc != DU_OK) return rc;
   // finalize works on (C, 2) pairs: C = elements / 2; with_db the Cout bias-gradient sums ride behind the weight gradient

@@ -1907,6 +1907,7 @@ int launch_p8_tn(const du_gemm_args& a, int splits, hipStream_t st) {
 extern int g_attn_w;      // attention.hip
 extern int g_attn_impl, g_attn_thresh_log2, g_attn_var;
 extern int g_rk_mode;     // gemm_rk.hip
+extern int g_wgrad_rows;  // conv_halo.hip
 
 extern "C" int du_set_option(int key, int value) {
   switch (key) {
@@ -1923,6 +1924,7 @@ extern "C" int du_set_option(int key, int value) {
     case 10: g_p8_persist = value; return DU_OK;
     case 11: g_p8_pp_full = value; return DU_OK;
     case 12: g_rk_mode = value; return DU_OK;
+    case 13: g_wgrad_rows = value; return DU_OK;
     default: return DU_ERR_BAD_ARG;
   }
 }

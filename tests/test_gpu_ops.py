@@ -1201,6 +1201,46 @@ def test_conv3x3_halo_kernel_fwd_bwd_stats(B, H, W, C1, C2, Cout):
     assert rel(sums, sums_ref) < 1e-4
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout", [(1, 8, 16, 32, 0, 32), (1, 8, 32, 64, 0, 64), (3, 40, 80, 96, 0, 32), (2, 24, 16, 32, 32, 64),
+                                              (5, 64, 64, 64, 64, 64), (2, 16, 48, 64, 0, 32), (7, 8, 16, 32, 0, 64), (2, 128, 256, 64, 0, 64),
+                                              (4, 264, 272, 32, 0, 32)])
+@pytest.mark.parametrize("with_db", [False, True])
+def test_conv3x3_weight_gradient_rows_kernel(B, H, W, C1, C2, Cout, with_db):
+    """The round-5 3 x 3 weight-gradient kernel (conv3x3_wgrad_rows_kernel: a wave owns all 9 taps of a 32 x 32 channel block pair, the
+    waves split the tile's rows when there are fewer than 4 pairs and are added through LDS, two register sets of prefetch) against the
+    fp32 weight gradient of the same bf16 operands and against the round-3 kernel (du_set_option(13, 0)): one tile, fewer tiles than
+    workgroups, tile counts that are no multiple of the grid, 1-3 channel chunks, the fused concat, the bias-gradient sums."""
+    from dinounet_amd import _lib, ops
+    d = dev()
+    dt = torch.bfloat16
+    Cin = C1 + C2
+    x = q(gen(B, H, W, C1, seed=41), dt)
+    x2 = q(gen(B, H, W, C2, seed=42), dt) if C2 else None
+    go = q(gen(B, H, W, Cout, seed=43), dt)
+    xin = (torch.cat([x, x2], -1) if C2 else x).float().permute(0, 3, 1, 2)
+    wr = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    (F.conv2d(xin, wr, None, 1, 1) * go.float().permute(0, 3, 1, 2)).sum().backward()
+    ref = wr.grad.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
+    ref_db = go.float().sum((0, 1, 2))
+    L = _lib.lib()
+    outs = {}
+    try:
+        for mode in (1, 0):
+            L.du_set_option(13, mode)
+            r = ops.conv3x3_wgrad_halo(x.to(d, dt), go.to(d, dt), x2.to(d, dt) if C2 else None, with_db=with_db)
+            assert r is not None
+            outs[mode] = r if with_db else (r, None)
+            r2 = ops.conv3x3_wgrad_halo(x.to(d, dt), go.to(d, dt), x2.to(d, dt) if C2 else None, with_db=with_db)
+            assert torch.equal(r2[0] if with_db else r2, outs[mode][0]), "two runs differ"
+    finally:
+        L.du_set_option(13, 1)
+    scale = float(ref.abs().max())
+    for mode in (1, 0):
+        assert float((outs[mode][0].cpu() - ref).abs().max()) / scale < 2e-5, mode       # fp32 accumulation of exact bf16 products
+        if with_db:
+            assert float((outs[mode][1].cpu() - ref_db).abs().max()) / float(ref_db.abs().max()) < 1e-5, mode
+
+
 # ------------------------------------------------------------------------------------------------ squeeze-excitation
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("B,H,W,C,with_sc", [(2, 16, 16, 32, True), (3, 8, 8, 256, False), (8, 32, 32, 128, True)])
