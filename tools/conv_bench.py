@@ -29,6 +29,11 @@ SHAPES = [            # (H, W, C1, C2, Cout)   C2 > 0: fused concat of two sourc
     (128, 128, 64, 0, 128),
 ]
 B = 8
+if "--option" in sys.argv:                   # e.g. --option 14 0: the 128 -> 128 layers on the chunked form (du_set_option, include/dinounet_hip.h)
+    i = sys.argv.index("--option")
+    _lib.lib().du_set_option(int(sys.argv[i + 1]), int(sys.argv[i + 2]))
+if "--c128" in sys.argv:
+    SHAPES = [s for s in SHAPES if s[2] == 128 and s[4] == 128]
 
 
 def main():
