@@ -102,7 +102,8 @@ def time_variants(rounds):
     if "--narrow" in sys.argv:
         shapes = shapes[-3:]
     if "--residual" in sys.argv:     # the adapter's products into the fp32 query stream (LayerScale + residual epilogue: 350 MB of epilogue traffic)
-        shapes = [(43008, 1024, 256, torch.float32, "ffn_fc2_res"), (43008, 1024, 512, torch.float32, "oproj_res"), (8232, 1024, 1024, torch.float32, "proj")]
+        shapes = [(43008, 1024, 256, torch.float32, "ffn_fc2_res"), (43008, 1024, 512, torch.float32, "oproj_res"), (8232, 1024, 1024, torch.float32, "proj"),
+                  (8232, 1024, 4096, torch.float32, "fc2"), (8192, 1024, 1024, torch.float32, "proj8192")]
         variants = [v for v in variants if v[0] in ("256x256", "256 noepi", "256x128", "128 noepi", "4wave", "4w noepi", "auto")]
     print(f"{'shape':>34} " + " ".join(f"{n:>11}" for n, _ in variants) + "   (us median | TF/s of `auto` = what ships, fraction of 2.5 PF | best complete variant)")
     import time
