@@ -185,7 +185,7 @@ class DinoVisionTransformer(nn.Module):
         # per-launch costs at the source, and the two do not add (two half-chip persistent launches side by side lose).  The kernel route
         # ships; the chains stay available: DINOUNET_VIT_CHAINS=2, or `backbone.chains = 2`.  0 / 1 = one chain on the caller's stream.
         self.chains = int(os.environ.get("DINOUNET_VIT_CHAINS", "1"))
-        self.overlap_prior = os.environ.get("DINOUNET_VIT_OVERLAP_PRIOR", "1") != "0"     # the adapter's prior module beside the chains
+        self.overlap_prior = ops._ab_env("DINOUNET_VIT_OVERLAP_PRIOR", "1") != "0"     # the adapter's prior module beside the chains
         self._chain_streams = {}
         self._chain_ws = {}
         self.init_weights()
