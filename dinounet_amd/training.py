@@ -66,7 +66,8 @@ class _CaptureSegments:
     call is recorded into a graph; everything else keeps the replay's launch path.  The graphs share one memory pool and are replayed
     in capture order, so a tensor made in one segment is alive in the next.  A cut ends the running capture, which HIP only allows from
     the thread that began it: cuts happen at main-thread points of the step (the loss forward, after backward), never inside autograd's
-    device thread."""
+    device thread.  Consequence: a collective issued by a BACKWARD node (SyncBatchNorm's statistics all-reduce, i.e. the full model at
+    N > 1) asks for a cut from that thread, `cut` raises, and TrainStep falls back to eager steps for that configuration."""
 
     def __init__(self, mode):
         self.mode = mode
