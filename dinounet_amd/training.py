@@ -171,6 +171,15 @@ class TrainStep:
             self.opt.step()
         return loss.detach()
 
+    def _forget_failed_pass(self):
+        """a capture that raised part-way through backward: re-arm the reducer's bucket counters and drop the weight-gradient products
+        the dead pass queued (nobody will read them; the queue would otherwise launch them at the next backward, ops.WgradQueue._arm)"""
+        if self.reducer is not None:
+            self.reducer.rearm()
+        if self.x.is_cuda:
+            from . import ops
+            ops.WGRAD._drop()
+
     def _capture_in_segments(self, mode):
         import gc
         from . import ops
@@ -235,8 +244,7 @@ class TrainStep:
                 except Exception as e:  # noqa: BLE001
                     err = e
                     torch.cuda.synchronize()
-                    if self.reducer is not None:
-                        self.reducer.rearm()
+                    self._forget_failed_pass()
             if self.graph is None and self.reducer is not None:
                 # the collectives outside the graphs: asked for, or the capture of the whole step (RCCL kernels recorded into it) failed
                 try:
@@ -246,7 +254,7 @@ class TrainStep:
                 except Exception as e:  # noqa: BLE001
                     err = e
                     torch.cuda.synchronize()
-                    self.reducer.rearm()
+                    self._forget_failed_pass()
             if self.graph is None:     # capture is an optimisation: a step that cannot be captured still has to train
                 import warnings
                 warnings.warn(f"hipGraph capture of the train step failed ({err!r}); continuing with eager steps")

@@ -9,6 +9,29 @@ import torch.multiprocessing as mp
 from torch import nn
 
 
+def _np(x):
+    """queue payloads travel as numpy arrays, pickled BY VALUE: a torch tensor is handed over as a shared-memory handle that dies with its
+    producer, and a worker that exits before the parent has opened the handle makes q.get() raise FileNotFoundError (seen once in round 5)"""
+    if isinstance(x, torch.Tensor):
+        return x.detach().numpy().copy()
+    if isinstance(x, dict):
+        return {k: _np(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_np(v) for v in x)
+    return x
+
+
+def _t(x):
+    import numpy as np
+    if isinstance(x, np.ndarray):
+        return torch.from_numpy(x)
+    if isinstance(x, dict):
+        return {k: _t(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_t(v) for v in x)
+    return x
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -67,7 +90,7 @@ def _worker(rank, world, port, q):
     l = dc_and_ce_loss(lo, tg[rank * 2:(rank + 1) * 2], ddp=True)
     (gl,) = torch.autograd.grad(l, lg)
     dist.all_reduce(gl)
-    q.put((rank, grads, float(l), gl / world))
+    q.put(_np((rank, grads, float(l.detach()), gl / world)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,7 +101,7 @@ def test_bucketed_allreduce_and_ddp_dice_world2():
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([_t(q.get(timeout=120)) for _ in range(world)], key=lambda t: t[0])
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     # single-process reference on the full batch
@@ -124,8 +147,8 @@ def _syncbn_worker(rank, world, port, q):
     with shim.patched_ops():
         ys = ops.sync_bn_multi(xs, bns, ACT_RELU, None)
     torch.autograd.backward(ys, [d[rank * 2:(rank + 1) * 2] for d in DY])
-    q.put((rank, [y.detach() for y in ys], [x.grad for x in xs], [bn.weight.grad for bn in bns], [bn.bias.grad for bn in bns],
-           [bn.running_mean.clone() for bn in bns], [bn.running_var.clone() for bn in bns]))
+    q.put(_np((rank, [y.detach() for y in ys], [x.grad for x in xs], [bn.weight.grad for bn in bns], [bn.bias.grad for bn in bns],
+               [bn.running_mean.clone() for bn in bns], [bn.running_var.clone() for bn in bns])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -136,7 +159,7 @@ def test_syncbn_stand_in_matches_full_batch_batchnorm_world2():
     q = ctx.Queue()
     procs = [ctx.Process(target=_syncbn_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([_t(q.get(timeout=120)) for _ in range(world)], key=lambda t: t[0])
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     g = torch.Generator().manual_seed(5)
