@@ -1470,10 +1470,26 @@ __device__ __forceinline__ void pp_lds_read1(f32x4& a, unsigned addr) { asm vola
 __device__ __forceinline__ void pp_wait_lds(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
 __device__ __forceinline__ void pp_wait_lds1(f32x4& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory"); }
 
-template <int ACT, bool NK4>
+// RES (round 6): the bf16 RESIDUAL of the product (y = x + f(...), the adapter's output projection and ConvFFN fc2 into the query stream,
+// dinov3_adapter.py:142-148) enters as TWO MORE K-STEPS of the same tile: A' = [A | R(rows, the tile's 128 columns)], W' = [W | I_128], so
+// sum_k' R[m][k'] * I[n][k'] = R[m][n] lands in the accumulators through the staging ring like any other K-tile -- no residual registers
+// (the kernel has none to spare), no read in the drain, the 88 MB of a 43008 x 1024 residual stream travel under the MFMAs of the
+// tile before.  bf16 x 1.0 accumulated in fp32 is exact.  RES == 2: DropPath's per-sample scale (row_scale, rs_rows % 256 == 0: a
+// tile lies inside one sample) multiplies the accumulators between the last K-step of A and the first of R (acc[0] in the phase that
+// works on acc[1] and vice versa) and the bias in the drain: y = s * (A W^T + b) + R.  One-shot kernels: 95.6 / 111.8 us at
+// 43008 x 1024 x {256, 512} (the epilogue re-reads the residual with the matrix pipe idle, profiles/r05_gemm_residual_epilogue_v1.txt).
+struct PpIdent {
+  unsigned short v[128 * 128];
+  constexpr PpIdent() : v() { for (int i = 0; i < 128; i++) v[i * 128 + i] = 0x3F80; }      // bf16 1.0 on the diagonal
+};
+__device__ const PpIdent g_pp_ident{};
+
+template <int ACT, bool NK4, int RES = 0>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<bf16_t>(P, smem); return; }
+  static_assert(RES == 0 || ACT == DU_ACT_NONE, "the residual form has no activation");
+  constexpr bool FOUR = NK4 && RES == 0;          // the four-K-step tile form (K = 256 without a residual); with one the tile is six K-steps
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -1484,7 +1500,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
     lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int ntiles = P.tiles_m * P.tiles_n;
-  const int nk = P.K / PBK;
+  const int nk = P.K / PBK + (RES ? 2 : 0);       // K-steps of a tile (RES: the residual's two behind A's)
   auto coords = [&](int tile, int& m0, int& n0) {
     int tm, tn;
     if (P.group_m > 1) {
@@ -1504,6 +1520,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)P.b.p, 0, (int)((((long)P.N - 1) * P.b.ld + P.K) * 2), 0x00020000);
   const auto rc = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, (int)((((long)P.M - 1) * P.ldc + P.N) * 2), 0x00020000);
   const auto rbias = __builtin_amdgcn_make_buffer_rsrc(P.bias ? (void*)P.bias : P.C, 0, P.bias ? P.N * 4 : 0, 0x00020000);
+  const int nrec_r = RES ? (int)((((long)P.M - 1) * P.ldr + P.N) * 2) : 0;
+  const unsigned ldr2 = (unsigned)(P.ldr * 2);
 
   // staging: piece (round r, wave w) of a half = tile rows (r*8 + w)*8 .. +8, lane l -> row + l/8, physical 16-byte chunk l%8 holds
   // logical chunk (l%8) ^ ((row >> 1) & 7) (as gemm_nt_p8n_kernel)
@@ -1519,7 +1537,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   }
   const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
   unsigned va_s[2][2], vb_s[2];   // ... of the tile being STAGED, out of range for rows past M / N and past the last tile
-  unsigned sa_base = 0, sb_base = 0;
+  unsigned sa_base = 0, sb_base = 0, sr_base = 0;
   // the tile whose K-tiles are requested from now on; its bias slice -> LDS slot `slot` (waves 0 / 1, one 4-byte LDS-DMA each)
   auto set_stage_tile = [&](int tile, int slot) {
     if (tile < ntiles) {
@@ -1533,6 +1551,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
       }
       sa_base = (unsigned)m0 * (unsigned)(P.a.ld * 2);
       sb_base = (unsigned)n0 * (unsigned)(P.b.ld * 2);
+      if constexpr (RES != 0) sr_base = (unsigned)m0 * ldr2 + (unsigned)n0 * 2u;
       if (wave < 2) {
         // inline asm: behind an LDS-DMA builtin the compiler waits vmcnt(0) in front of every read of the bias image (it cannot tell the
         // slots apart) -- once per phase of the drain.  Unseen, the image is ordered by distance: it is read a whole tile later, behind
@@ -1548,14 +1567,32 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
       for (int r = 0; r < 2; r++) { va_s[0][r] = PP_OOR; va_s[1][r] = PP_OOR; vb_s[r] = PP_OOR; }
     }
   };
-  // which: 0 = A-half0, 1 = A-half1, 2 = B of the staged tile's K-tile at byte offset kofs, into the buffer at byte offset bo
-  auto stage = [&](auto which_c, int bo, unsigned kofs) {
+  // which: 0 = A-half0, 1 = A-half1, 2 = B of the staged tile's K-tile at byte offset kofs, into the buffer at byte offset bo.
+  // EXT (RES, compile time: the K-steps that request the residual are fixed points of the tile program): K-tile e = kofs / 128 of the
+  // residual -- A' rows = the tile's rows of R at columns n0 + 64 e .. + 63, W' rows = rows of the 128 x 128 identity at the same columns
+  const auto rr = __builtin_amdgcn_make_buffer_rsrc(RES ? (void*)P.residual : (void*)P.a.p, 0, nrec_r, 0x00020000);
+  const auto ri = __builtin_amdgcn_make_buffer_rsrc((void*)g_pp_ident.v, 0, 32768, 0x00020000);
+  auto stage = [&](auto which_c, int bo, unsigned kofs, auto ext_c) {
     constexpr int which = decltype(which_c)::value;
+    constexpr bool EXT = RES != 0 && decltype(ext_c)::value != 0;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       unsigned char* dst = smem + bo + which * HALF_B + (r * 8 + wave) * 1024;
-      if constexpr (which < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, va_s[which][r], sa_base + kofs, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)dst, 16, vb_s[r], sb_base + kofs, 0, 0);
+      if constexpr (EXT) {
+        // (the lane offsets are recomputed at every request -- two VALU operations -- from a value the optimiser cannot see through:
+        //  hoisted out of the tile loop they are six more live registers in a kernel that has none, and it spills)
+        unsigned sr = (unsigned)srow[r];
+        asm volatile("" : "+v"(sr));
+        if constexpr (which < 2) {
+          const unsigned vext = va_s[which][r] == PP_OOR ? PP_OOR : (which * 128u + sr) * ldr2 + (unsigned)lc * 16u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_void*)dst, 16, vext, sr_base + kofs, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (lds_void*)dst, 16, sr * 256u + (unsigned)lc * 16u, kofs, 0, 0);
+        }
+      } else {
+        if constexpr (which < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, va_s[which][r], sa_base + kofs, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)dst, 16, vb_s[r], sb_base + kofs, 0, 0);
+      }
     }
   };
   int L[4];
@@ -1626,6 +1663,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   unsigned pbias = lds_base + PP_BIAS_OFF + (unsigned)((wn * 64 + 4 * hi) * 4);     // this lane's corner of the finished tile's bias image
   unsigned crow[2] = {PP_OOR, PP_OOR};   // byte offset of this lane's row of A half i, at its first column (wave's 64 + 8 hi), in C
   int pcol = 0;                   // that first column
+  float rs_cur = 1.0f, rs_prev = 1.0f;   // RES == 2: DropPath scale of the tile being computed / drained (uniform: a tile lies inside one sample)
   auto set_prev_tile = [&](int tile) {
     int m0, n0;
     coords(tile, m0, n0);
@@ -1655,7 +1693,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
       // (no "is there a finished tile" branch: before the first one `prev` holds zeros and crow is out of range -- the store is dropped;
       //  a branch would end the phase's scheduling region in front of the drain and push it behind the MFMAs)
       const f32x16& a = prev[i][c];
-      f32x2 o0 = {a[4 * g] + bq[0], a[4 * g + 1] + bq[1]}, o1 = {a[4 * g + 2] + bq[2], a[4 * g + 3] + bq[3]};
+      f32x2 o0, o1;
+      if constexpr (RES == 2) {
+        o0 = {__builtin_fmaf(bq[0], rs_prev, a[4 * g]), __builtin_fmaf(bq[1], rs_prev, a[4 * g + 1])};
+        o1 = {__builtin_fmaf(bq[2], rs_prev, a[4 * g + 2]), __builtin_fmaf(bq[3], rs_prev, a[4 * g + 3])};
+      } else {
+        o0 = {a[4 * g] + bq[0], a[4 * g + 1] + bq[1]}; o1 = {a[4 * g + 2] + bq[2], a[4 * g + 3] + bq[3]};
+      }
       // (packed fp32: a one-element-at-a-time form on plain v_fma_f32 -- the micro-architecture guide prices a packed operation beside MFMAs
       //  at +22 cycles -- measured SLOWER here, 87.0 vs 84.5 us on the fc1 product, profiles/r05_gemm_p8_table_v3.txt: 11 instead of 7
       //  instructions per element at two waves per SIMD)
@@ -1685,13 +1729,24 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   // tile's); HA0 / HB0 (HA1 / HB1): the halves drained in phase 0 (1), -1 = none; the bias of the NEXT phase's halves is fetched at the end
   // of a phase (phase 1 fetches NA / NB = the following K-step's phase-0 halves) from the image at fbase; CP1: prev[1] <- acc[1] in phase
   // 0 (first K-step of a tile, before its phase 1 restarts acc[1]); CP0: prev[0] <- acc[0] in phase 1 (last K-step: acc[0] is final)
+  // SC (RES == 2): 1 = this is A's last K-step: acc[0] (final after phase 0) is scaled in phase 1; 2 = the residual's first K-step: acc[1]
+  // is scaled in phase 0, before phase 1 adds the residual to it
+  auto scale_acc = [&](auto i_c) {
+    constexpr int i = decltype(i_c)::value;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][c][r] *= rs_cur;
+  };
   auto kstep = [&](auto par_c, auto first_c, auto ha0, auto hb0, auto ha1, auto hb1, auto na, auto nb, auto cp1_c, auto cp0_c, int bc, int bn,
-                   int bnn, unsigned kofs, unsigned fbase, unsigned fbase2) {
+                   int bnn, unsigned kofs, unsigned fbase, unsigned fbase2, auto sc_c, auto ext_c) {
     constexpr int p = decltype(par_c)::value;
+    constexpr int SC = RES == 2 ? decltype(sc_c)::value : 0;
     // phase 0
     readA(IC<1>{}, bc);
-    stage(IC<0>{}, bnn, kofs); stage(IC<2>{}, bnn, kofs);
+    stage(IC<0>{}, bnn, kofs, ext_c); stage(IC<2>{}, bnn, kofs, ext_c);
     if constexpr (decltype(cp1_c)::value) { prev[1][0] = acc[1][0]; prev[1][1] = acc[1][1]; }
+    if constexpr (SC == 2) scale_acc(IC<1>{});
     mma(IC<0>{}, IC<p>{}, first_c);
     half(ha0, bqa); half(hb0, bqb);
     pin(IC<4>{}, IC<4>{});
@@ -1700,8 +1755,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
     finish6();
     // phase 1
     readA(IC<0>{}, bn); readB(IC<1 - p>{}, bn);
-    stage(IC<1>{}, bnn, kofs);
+    stage(IC<1>{}, bnn, kofs, ext_c);
     if constexpr (decltype(cp0_c)::value) { prev[0][0] = acc[0][0]; prev[0][1] = acc[0][1]; }
+    if constexpr (SC == 1) scale_acc(IC<0>{});
     mma(IC<1>{}, IC<p>{}, first_c);
     half(ha1, bqa); half(hb1, bqb);
     pin(IC<12>{}, IC<2>{});
@@ -1714,17 +1770,20 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   // its last phase fetches the bias of the first unit of THIS tile, from the image at nbase)
   auto dstep = [&](auto j_c, auto par_c, int bc_, int bn_, int bnn_, unsigned kofs, unsigned nbase) {
     constexpr int j = decltype(j_c)::value;
-    constexpr bool wrap = NK4 && j == 3;
+    constexpr bool wrap = FOUR && j == 3;
+    // (RES with K = 256: the tile is six K-steps; K-steps 2 and 3 request the residual's K-tiles 0 and 1, K-step 3 is A's last)
+    constexpr bool ext = NK4 && RES != 0 && j >= 2;
     kstep(par_c, IC<(j == 0)>{}, IC<4 * j>{}, IC<4 * j + 1>{}, IC<4 * j + 2>{}, IC<4 * j + 3>{}, IC<(j < 3 ? 4 * j + 4 : (wrap ? 0 : -1))>{},
-          IC<(j < 3 ? 4 * j + 5 : (wrap ? 1 : -1))>{}, IC<(j == 0)>{}, IC<wrap>{}, bc_, bn_, bnn_, kofs, pbias, wrap ? nbase : pbias);
+          IC<(j < 3 ? 4 * j + 5 : (wrap ? 1 : -1))>{}, IC<(j == 0)>{}, IC<wrap>{}, bc_, bn_, bnn_, ext ? (unsigned)(j - 2) * 128u : kofs, pbias,
+          wrap ? nbase : pbias, IC<((ext && j == 3) ? 1 : 0)>{}, IC<(ext ? 1 : 0)>{});
   };
 
   // ---- this workgroup's first tile: the only prologue (K-tiles 0 and 1) ----
   int tile = lin;
   if (tile >= ntiles) return;
   set_stage_tile(tile, 0);
-  stage(IC<0>{}, 0, 0u); stage(IC<2>{}, 0, 0u); stage(IC<1>{}, 0, 0u);
-  stage(IC<0>{}, NBUF_B, 128u); stage(IC<2>{}, NBUF_B, 128u); stage(IC<1>{}, NBUF_B, 128u);
+  stage(IC<0>{}, 0, 0u, F_{}); stage(IC<2>{}, 0, 0u, F_{}); stage(IC<1>{}, 0, 0u, F_{});
+  stage(IC<0>{}, NBUF_B, 128u, F_{}); stage(IC<2>{}, NBUF_B, 128u, F_{}); stage(IC<1>{}, NBUF_B, 128u, F_{});
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // K-tile 0 landed
   __builtin_amdgcn_s_barrier();
   readA(IC<0>{}, 0);
@@ -1738,7 +1797,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   auto bias_at = [&](int sl) { return lds_base + PP_BIAS_OFF + (unsigned)(sl * 512 + (wn * 64 + 4 * hi) * 4); };
   for (;;) {
     const int next = tile + G;
-    if constexpr (NK4) {
+    if constexpr (RES == 2) {
+      int m0c, n0c;
+      coords(tile, m0c, n0c);
+      rs_cur = P.row_scale[__builtin_amdgcn_readfirstlane(m0c / P.rs_rows)];
+    }
+    if constexpr (FOUR) {
       // four K-steps = the tile; the previous tile drains under all of them.  K-steps 0, 1 request this tile's K-tiles 2, 3; then the
       // staging moves on: K-steps 2, 3 request K-tiles 0, 1 of the NEXT tile (out of range behind the last one)
       const int nslot = slot == 2 ? 0 : slot + 1;
@@ -1761,19 +1825,27 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
       dstep(IC<3>{}, IC<1>{}, bn, bnn, bc, 5u * 128u, 0u);
       rot2();
       int t = 4;
-      for (; t + 2 < nk; t += 2) {
-        kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, (unsigned)(t + 2) * 128u, 0u, 0u);
-        kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bn, bnn, bc, (unsigned)(t + 3) * 128u, 0u, 0u);
+      // (RES: the requests (t + 2) * 128 >= kext of the last pair before the final one are the residual's two K-tiles; that pair is peeled
+      //  because its second K-step is A's last -- the DropPath scale hook)
+      for (; t + (RES != 0 && !NK4 ? 4 : 2) < nk; t += 2) {
+        kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, (unsigned)(t + 2) * 128u, 0u, 0u, IC<0>{}, IC<0>{});
+        kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bn, bnn, bc, (unsigned)(t + 3) * 128u, 0u, 0u, IC<0>{}, IC<0>{});
+        rot2();
+      }
+      if constexpr (RES != 0 && !NK4) {      // A's last two K-steps request the residual's K-tiles 0 and 1
+        kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, 0u, 0u, 0u, IC<0>{}, IC<1>{});
+        kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bn, bnn, bc, 128u, 0u, 0u, IC<1>{}, IC<1>{});
         rot2();
       }
       // the last two K-steps request K-tiles 0 and 1 of the NEXT tile (out of range behind the last one); the very last phase fetches the
       // bias of the first unit of THIS tile (its image: slot `slot`)
       set_stage_tile(next, slot ^ 1);
       pbias = bias_at(slot);
-      kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, 0u, 0u, 0u);
-      kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, IC<0>{}, IC<1>{}, F_{}, T_{}, bn, bnn, bc, 128u, 0u, pbias);
+      kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, 0u, 0u, 0u, IC<2>{}, IC<0>{});
+      kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, IC<0>{}, IC<1>{}, F_{}, T_{}, bn, bnn, bc, 128u, 0u, pbias, IC<0>{}, IC<0>{});
       rot2();
       set_prev_tile(tile);
+      rs_prev = rs_cur;
       slot ^= 1;
     }
     tile = next;
@@ -1801,6 +1873,7 @@ int g_p8_corun = 1;      // du_set_option key 9: independent products the caller
                          // alone is a full round beside its twin
 int g_p8_persist = 1;    // du_set_option key 10: 0 = never, 1 = the persistent 256 x 128 kernel where its epilogue / shape rules hold and a CU gets
                          // >= 2 tiles (default), 2 = wherever legal
+int g_p8_res = 1;        // du_set_option key 14 (A-B aid): 0 = products with a bf16 residual stay on the one-shot kernels (round 5)
 int g_p8_pp_full = 0;    // du_set_option key 11 (A-B aid): 1 = the persistent kernel always launches min(tiles, 256) workgroups, co-running or not
 int g_p8_group = 4;
 int g_p8_debug = 0;      // bit 0: skip the bf16 global stores, bit 1: skip the whole epilogue (timing ablations only)
@@ -1844,13 +1917,15 @@ int launch_pp(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
     P.tail_rows = tail_rows;
     grid.x += (a.N + SK_BN - 1) / SK_BN;
   }
-  // drain schedule: the 16 half-units of a finished tile over 8 K-steps where the tile has them to spare (K >= 768), else over 4
   const bool nk4 = a.K == 256;
+  const int res = a.residual ? (a.row_scale ? 2 : 1) : 0;       // the residual as two more K-steps (+ DropPath's per-sample scale)
   void (*kfn)(GemmParams);
-  if (nk4) kfn = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, true> : gemm_nt_pp_kernel<DU_ACT_NONE, true>;
+  if (res == 2) kfn = nk4 ? gemm_nt_pp_kernel<DU_ACT_NONE, true, 2> : gemm_nt_pp_kernel<DU_ACT_NONE, false, 2>;
+  else if (res == 1) kfn = nk4 ? gemm_nt_pp_kernel<DU_ACT_NONE, true, 1> : gemm_nt_pp_kernel<DU_ACT_NONE, false, 1>;
+  else if (nk4) kfn = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, true> : gemm_nt_pp_kernel<DU_ACT_NONE, true>;
   else kfn = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, false> : gemm_nt_pp_kernel<DU_ACT_NONE, false>;
-  static bool attr_set[4] = {false, false, false, false};
-  const int ai = (a.act == DU_ACT_GELU ? 1 : 0) + (nk4 ? 2 : 0);
+  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
+  const int ai = res ? 2 + 2 * res + (nk4 ? 1 : 0) : (a.act == DU_ACT_GELU ? 1 : 0) + (nk4 ? 2 : 0);
   if (!attr_set[ai]) {
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess) return DU_ERR_LAUNCH;
     attr_set[ai] = true;
@@ -1925,6 +2000,7 @@ extern "C" int du_set_option(int key, int value) {
     case 11: g_p8_pp_full = value; return DU_OK;
     case 12: g_rk_mode = value; return DU_OK;
     case 13: g_wgrad_rows = value; return DU_OK;
+    case 14: g_p8_res = value; return DU_OK;
     default: return DU_ERR_BAD_ARG;
   }
 }
@@ -1970,9 +2046,16 @@ static bool p8_legal(const du_gemm_args& a) {
 // the persistent 256 x 128 kernel: bf16 result with a bias (+ GELU) epilogue, plain store, K >= 512, every extent below 2^31 bytes
 static bool pp_legal(const du_gemm_args& a) {
   if (!p8_legal(a) || a.out_dtype != DU_BF16 || a.store_mode != DU_STORE_PLAIN || a.batch > 1) return false;
-  if (a.residual || a.gamma || a.row_scale || a.alpha != 1.0f || (a.act != DU_ACT_NONE && a.act != DU_ACT_GELU)) return false;
+  if (a.gamma || a.alpha != 1.0f || (a.act != DU_ACT_NONE && a.act != DU_ACT_GELU)) return false;
   if ((a.K != 256 && a.K < 384) || a.N % 8 || a.ldc % 8 || (((uintptr_t)a.C) & 15)) return false;      // (K = 256: the four-K-step form)
   const long lim = 0x7fffffffL;
+  if (a.residual) {
+    // the residual as two more K-steps of the tile (bf16, the result's dtype): whole 128-column tiles, 16-byte rows; DropPath's scale only
+    // where a 256-row tile lies inside one sample
+    if (a.act != DU_ACT_NONE || a.N % 128 || a.ldr % 8 || (((uintptr_t)a.residual) & 15)) return false;
+    if (a.row_scale && (a.rs_rows < 256 || a.rs_rows % 256)) return false;
+    if (((long)a.M * a.ldr + a.N) * 2 >= lim) return false;
+  } else if (a.row_scale) return false;
   return ((long)a.M * a.lda + a.K) * 2 < lim && ((long)a.N * a.ldb + a.K) * 2 < lim && ((long)a.M * a.ldc + a.N) * 2 < lim;
 }
 
@@ -2004,10 +2087,16 @@ int du_gemm_p8_choice(const du_gemm_args& a) {
   // x 512 six against three (56.3 vs 66.8); FAPM's 131072 x 512 x 1024 (8 tiles against 4 full rounds: 161 vs 141 us) and the big
   // square / 7B products stay on the wide tile (profiles/r05_gemm_p8_table_v2.txt)
   if (g_p8_persist && pp_legal(a)) {
+    // (round 6) a bf16 residual: the one-shot kernels re-read it in an exposed epilogue (95.6 / 111.8 us at 43008 x 1024 x {256, 512} against
+    // 36.5 / 56.3 without one); the persistent kernel takes it in as two more K-steps
+    if (a.residual) {
+      if (g_p8_res && (g_p8_persist > 1 || t128 >= 2 * cus)) return 4;
+    } else {
     const double r = a.K <= 256 ? 0.40 : (a.K <= 512 ? 0.45 : (a.act == DU_ACT_GELU ? 0.49 : 0.53));
     const double cpp = (double)((t128 + cus - 1) / cus) * r;
     const double best = (t256 * g_p8_corun >= 128 && c256 <= c128) ? c256 : c128;
     if (g_p8_persist > 1 || (t128 >= 2 * cus && cpp < best)) return 4;
+    }
   }
   if (t256 * g_p8_corun >= 128 && c256 <= c128) return 1;
   return 2;

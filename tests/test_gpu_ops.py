@@ -86,7 +86,13 @@ def test_gemm_plain_epilogues(dt, M, N, K):
                                               (70000, 264, 512, False, "bias"), (33000, 1000, 896, False, "gelu"), (33000, 1000, 640, False, "gelu"),
                                               (43008, 1024, 512, False, "none"), (5000, 136, 2048, False, "bias"),
                                               # ... K = 256 (the four-K-step form: the drain runs under the whole next tile) and K = 384
-                                              (43008, 1024, 256, False, "bias"), (70000, 264, 256, False, "gelu"), (33000, 520, 384, False, "bias")])
+                                              (43008, 1024, 256, False, "bias"), (70000, 264, 256, False, "gelu"), (33000, 520, 384, False, "bias"),
+                                              # round 6: a bf16 residual as two more K-steps of the persistent kernel's tile (+ DropPath's per-sample
+                                              # scale): the adapter's output projection / ConvFFN fc2 shapes, K = 256 (six-K-step tile), 384, 512, 1024,
+                                              # ragged last tile row + rows behind the last full tile, one tile per workgroup
+                                              (43008, 1024, 256, False, "res_rs"), (43008, 1024, 512, False, "res"), (33000, 1024, 384, False, "res"),
+                                              (10752, 256, 256, False, "res_rs"), (21504, 640, 1024, False, "res_rs"), (5000, 128, 512, False, "res"),
+                                              (16424, 512, 512, False, "res")])
 def test_gemm_multiphase_nt(mode, M, N, K, f32out, epi):
     """256 x 256 (mode 1), 256 x 128 (mode 2) and persistent 256 x 128 (mode 4, round 5; where its epilogue rules do not hold the library
     runs the mode-2 kernel) multi-phase NT kernels (gemm_p8.hip) forced through du_set_option, on the ViT-L products and ragged shapes:
@@ -114,18 +120,33 @@ def test_gemm_multiphase_nt(mode, M, N, K, f32out, epi):
     if epi == "rs":
         kw.update(row_scale=rs, rs_rows=rows)
         ref = ref * rs.repeat_interleave(rows)[:M, None]
+    if epi in ("res", "res_rs"):                         # y = s * (x w^T + b) + r, r in the result's dtype (dinov3_adapter.py:142-148)
+        kw["bias"] = b
+        ref = ref + b
+        if epi == "res_rs":
+            rows = 5376
+            rs = (torch.arange((M + rows - 1) // rows, device=d) % 3 != 0).float() / 0.7
+            kw.update(row_scale=rs, rs_rows=rows)
+            ref = ref * rs.repeat_interleave(rows)[:M, None]
+        resb = res.to(bf)
+        kw["residual"] = resb
+        ref = ref + resb.float()
     od = torch.float32 if f32out else bf
     L = _lib.lib()
     try:
         L.du_set_option(0, mode)
+        ops.TRACK_ROUTE = True
         outs = []
         for _ in range(6):
             out = torch.empty((M, N), dtype=od, device=d)
             if epi == "ls_res":
                 kw["residual"] = res.clone() if od == torch.float32 else res.to(od)
             outs.append(ops.mm(x, w, out=out, **kw).float())
+        if mode == 4 and epi in ("res", "res_rs"):
+            assert ops.LAST_GEMM_ROUTE == 6, ops.LAST_GEMM_ROUTE      # the persistent kernel itself, not a fallback
     finally:
         L.du_set_option(0, -1)
+        ops.TRACK_ROUTE = False
     assert rel(outs[0], ref) < (2e-4 if f32out and epi != "ls_res" else TOL[bf])
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), "run-to-run difference: pipeline race"

@@ -105,6 +105,11 @@ def time_variants(rounds):
         shapes = [(43008, 1024, 256, torch.float32, "ffn_fc2_res"), (43008, 1024, 512, torch.float32, "oproj_res"), (8232, 1024, 1024, torch.float32, "proj"),
                   (8232, 1024, 4096, torch.float32, "fc2"), (8192, 1024, 1024, torch.float32, "proj8192")]
         variants = [v for v in variants if v[0] in ("256x256", "256 noepi", "256x128", "128 noepi", "4wave", "4w noepi", "auto")]
+    bf16res = "--bf16res" in sys.argv
+    if bf16res:      # round 6: the adapter's products into the bf16 query stream as the model issues them (bias + bf16 residual, fc2: + DropPath scale)
+        shapes = [(43008, 1024, 256, bf, "ffn_fc2_res"), (43008, 1024, 512, bf, "oproj_res"), (43008, 1024, 1024, bf, "k1024_res"),
+                  (21504, 1024, 256, bf, "fc2_res_b4"), (43008, 768, 384, bf, "b_oproj_res")]
+        variants = [v for v in variants if v[0] in ("256x256", "256x128", "persist", "auto")] + [("auto r5", dict(mode=-1))]
     print(f"{'shape':>34} " + " ".join(f"{n:>11}" for n, _ in variants) + "   (us median | TF/s of `auto` = what ships, fraction of 2.5 PF | best complete variant)")
     import time
     for M, N, K, od, name in shapes:
@@ -116,10 +121,15 @@ def time_variants(rounds):
             kwargs["act"] = 1
         if od != bf:
             kwargs.update(gamma=torch.randn(N, device=dev), residual=out)
+        if bf16res:
+            kwargs.update(residual=torch.randn(M, N, device=dev).to(bf))
+            if name.startswith("f"):      # ConvFFN fc2: DropPath's per-sample scale (5376 rows per sample)
+                kwargs.update(row_scale=(torch.arange(M // 5376, device=dev) % 3 != 0).float() / 0.7, rs_rows=5376)
         ts = {n: [] for n, _ in variants}
         graphs = {}
         for n, kw in variants:                     # warm-up, then capture 10 back-to-back launches per variant (no host time in the number)
             opt(**kw)
+            L.du_set_option(14, 0 if n == "auto r5" else 1)
             ops.mm(x, w, out=out, **kwargs)
             torch.cuda.synchronize()
             g_ = torch.cuda.CUDAGraph()
@@ -148,6 +158,7 @@ def time_variants(rounds):
         print(f"{name:>10} M{M:>6} N{N:>5} K{K:>5} " + " ".join(f"{med[n]:11.1f}" for n, _ in variants)
               + f"   | auto {fl / med['auto'] / 1e6:7.1f} TF/s ({fl / med['auto'] / 1e6 / 2500:.3f}) | best {bn} {fl / complete[bn] / 1e6:7.1f}", flush=True)
     opt()
+    L.du_set_option(14, 1)
 
 
 if __name__ == "__main__":
