@@ -388,7 +388,7 @@ class DINOv3_Adapter(nn.Module):
         if self.add_vit_feature:                                                            # ADP:469-476
             cs = [ops.bilinear_add(layers[j][0].view(B, H_t, W_t, D), cs[j]) for j in range(4)]
         norms = [self.norm1, self.norm2, self.norm3, self.norm4]
-        if (self.training and group is not None and torch.distributed.get_world_size(group) > 1
+        if (self.training and group is not None and ops.sync_active(group)
                 and all(bn.track_running_stats for bn in norms)):
             for bn in norms:                                                                # ADP:479-482, one packed collective each way
                 if bn.num_batches_tracked is not None:

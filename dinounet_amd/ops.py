@@ -118,6 +118,21 @@ CAPTURE_CUT = None           # training.TrainStep while it captures a step in se
 SMALL_COLLECTIVES = None     # bench.py (N > 1 / forced reducer): list -> every small all-reduce of an eager step is bracketed by HIP events
 
 
+# DINOUNET_FORCE_SMALL_COLLECTIVES=1 (test configuration, like DINOUNET_FORCE_REDUCER): the SyncBatchNorm statistics and batch-Dice
+# all-reduces are issued on a ONE-rank process group too, where they are identities -- so a single MI355X executes the N > 1 step with every
+# collective in it (the whole-step capture records them from autograd's device thread), bit-identical to the ungated step.
+_FORCE_SMALL = os.environ.get("DINOUNET_FORCE_SMALL_COLLECTIVES") == "1"
+
+
+def sync_active(group=None):
+    """True when the step's statistics collectives are issued over `group`: more than one rank (nnUNetTrainer.py:216-218,
+    convert_sync_batchnorm + DDP; dice.py:58-119 with ddp=True), or forced on a single rank."""
+    d = torch.distributed
+    if not (d.is_available() and d.is_initialized()):
+        return False
+    return d.get_world_size(group) > 1 or _FORCE_SMALL
+
+
 def _small_all_reduce(t, group, what):
     """the step's latency-bound collectives (SyncBatchNorm statistics forward / backward, the batch-Dice sums): <= 2 KB each, on the
     critical path.  With SMALL_COLLECTIVES set (eager steps only) each one is bracketed by events on the compute stream so the bench
@@ -1541,7 +1556,7 @@ class _NormAct(torch.autograd.Function):
             rstd = torch.empty((G, Cc), dtype=torch.float32, device=x.device)
             upd = kind == "bn" and running_mean is not None
             rm, rv = (_p(running_mean), _p(running_var)) if upd else (None, None)
-            synced = kind == "bn" and group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1
+            synced = kind == "bn" and group is not None and sync_active(group)
             L = _lib.lib()
             if not synced:
                 # totals, mean / rstd and the running statistics in ONE launch behind the partials (du_*_norm)
@@ -1588,7 +1603,7 @@ class _NormAct(torch.autograd.Function):
         _lib.check(L.du_norm_act_bwd_stats_grads(_code(x.dtype), _p(x), ld, _p(dy), Cc, _p(mean), _p(rstd), _p(wf), _p(bf), _p(bs), _p(dw),
                                                  _p(db), G, P, Cc, act, _p(ws), n, _st()), "du_norm_act_bwd_stats_grads")
         bsr = bs
-        if kind == "bn" and use_batch and group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+        if kind == "bn" and use_batch and group is not None and sync_active(group):
             bsr = bs.clone()
             _small_all_reduce(bsr, group, "syncbn_bwd")
         dx = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device)

@@ -11,6 +11,13 @@ import torch.nn.functional as F
 
 from .optim import FusedClipSGD
 
+# test configuration (ops.sync_active): the SyncBatchNorm / batch-Dice collectives issued on a one-rank group as well
+_FORCE_SMALL = os.environ.get("DINOUNET_FORCE_SMALL_COLLECTIVES") == "1"
+
+
+def _ddp_default(group):
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE_SMALL)
+
 
 class _AllReduceSumGrad(torch.autograd.Function):
     """dinounet/utilities/ddp_allgather.py:25-48 followed by .sum(0): all-gather forward / all-reduce backward."""
@@ -38,7 +45,7 @@ def dc_and_ce_loss(logits, target, smooth=1e-5, ddp=None, group=None):
     if logits.is_cuda and 2 <= K <= 8:
         from . import ops
         if ddp is None:
-            ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+            ddp = _ddp_default(group)
         return ops.dice_ce_loss(logits, target, smooth, (group if group is not None else dist.group.WORLD) if ddp else None)
     lab = target[:, 0].long()
     ce = F.cross_entropy(logits, lab)
@@ -50,7 +57,7 @@ def dc_and_ce_loss(logits, target, smooth=1e-5, ddp=None, group=None):
     inter = (p * onehot).sum((2, 3))
     sum_pred = p.sum((2, 3))
     if ddp is None:
-        ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        ddp = _ddp_default(group)
     inter, sum_pred, sum_gt = inter.sum(0), sum_pred.sum(0), sum_gt.sum(0).to(p.dtype)
     if ddp:
         inter = _AllReduceSumGrad.apply(inter, group)
@@ -81,7 +88,9 @@ class _CaptureSegments:
         self.cur.capture_begin(pool=self.pool, capture_error_mode=self.mode)
 
     def cut(self, eager_fn, what="cut"):
-        if threading.get_ident() != self.thread:
+        if threading.get_ident() != self.thread and self.mode != "relaxed":
+            # (hipStreamEndCapture from another thread than the one that began the capture is an error in the global / thread-local
+            #  modes; "relaxed" lifts that, which is what a collective issued by a backward node -- autograd's device thread -- needs)
             raise RuntimeError(f"segmented capture: '{what}' asks for a cut from a thread that did not begin the capture")
         self.cur.capture_end()
         self.graphs.append(self.cur)
@@ -179,6 +188,15 @@ class TrainStep:
         if self.x.is_cuda:
             from . import ops
             ops.WGRAD._drop()
+            ops.ZEROS.rec = []           # the dead pass's truncated request record must not become the next step's plan
+
+    def _all_ranks(self, ok):
+        """the capture mode is a collective decision: MIN over the ranks of 'my capture worked' (outside any capture)"""
+        if self.reducer is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.x.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
 
     def _capture_in_segments(self, mode):
         import gc
@@ -245,16 +263,37 @@ class TrainStep:
                     err = e
                     torch.cuda.synchronize()
                     self._forget_failed_pass()
-            if self.graph is None and self.reducer is not None:
-                # the collectives outside the graphs: asked for, or the capture of the whole step (RCCL kernels recorded into it) failed
-                try:
-                    self.graph = self._capture_in_segments(mode)
-                    self.capture_mode = f"segments({len(self.graph.graphs)})"
-                    err = None
-                except Exception as e:  # noqa: BLE001
-                    err = e
-                    torch.cuda.synchronize()
+                if not self._all_ranks(self.graph is not None) and self.graph is not None:
+                    # another rank's capture failed: every rank leaves this mode together -- a rank replaying a whole-step graph issues
+                    # its bucket all-reduces in hook-ready order, a segmented one in bucket-index order (mixed modes hang
+                    # or sum the wrong buckets)
+                    self.graph.reset()
+                    self.graph = None
+                    self.capture_mode = "eager"
+                    err = RuntimeError("whole-step capture failed on another rank")
                     self._forget_failed_pass()
+            if self.graph is None and self.reducer is not None:
+                # the collectives outside the graphs: asked for, or the capture of the whole step (RCCL kernels recorded into it) failed.
+                # First with the mode of the whole-step attempt (cuts from the capturing thread only); a step whose BACKWARD issues
+                # collectives (SyncBatchNorm at N > 1: autograd's device thread) asks for a cut from that thread, which only a "relaxed"
+                # capture may serve -- second attempt
+                for seg_mode in (mode, "relaxed"):
+                    try:
+                        self.graph = self._capture_in_segments(seg_mode)
+                        self.capture_mode = f"segments({len(self.graph.graphs)})" + ("" if seg_mode == mode else "/relaxed")
+                        err = None
+                    except Exception as e:  # noqa: BLE001
+                        err = e
+                        torch.cuda.synchronize()
+                        self._forget_failed_pass()
+                    if not self._all_ranks(self.graph is not None) and self.graph is not None:
+                        self.graph.reset()
+                        self.graph = None
+                        self.capture_mode = "eager"
+                        err = RuntimeError("segmented capture failed on another rank")
+                        self._forget_failed_pass()
+                    if self.graph is not None:
+                        break
             if self.graph is None:     # capture is an optimisation: a step that cannot be captured still has to train
                 import warnings
                 warnings.warn(f"hipGraph capture of the train step failed ({err!r}); continuing with eager steps")

@@ -303,3 +303,94 @@ red.remove(); dist.destroy_process_group()
             worst = (k, e)
     print(f"deferred (flush per bucket: {m1['launches']} flushes, {m1['queued']} products) vs undeferred gradients: worst rel-L2 {worst[1]:.2e} at {worst[0]}")
     assert worst[1] < 2e-3, worst
+
+
+def test_n_gt_1_step_with_every_collective_executes_on_one_rank():
+    """the captured multi-rank step WITH its SyncBatchNorm (forward + backward: the backward ones are issued from
+    autograd's device thread) and batch-Dice all-reduces had never executed anywhere -- at world size 1 those collectives are gated off.
+    `DINOUNET_FORCE_SMALL_COLLECTIVES=1` (test configuration) lifts the gates (ops.sync_active), so a one-rank RCCL group issues every one
+    of them (identities on one rank).  Three forms of the same 6 steps of dinounet_s: (a) the ungated whole-step capture, (b) the forced
+    whole-step capture -- RCCL kernels recorded from two threads into one hipGraph --, (c) the forced step captured in segments with the
+    collectives issued from the host between the graphs (cuts inside autograd's thread need a "relaxed" capture).  (b) must capture as
+    `whole_step` and train like (a); (c) must capture (not fall back to eager) and train like (a); the count of small collectives per
+    eager step must be the 6 SPM BatchNorms + 1 packed output-norm collective each way + the Dice sums."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import json, os, sys, time, torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from dinounet_amd import ops
+from dinounet_amd.plans import PLANS_2D
+from dinounet_amd.network_architecture import DinoUNet
+from dinounet_amd.dinov3.adapter import DropPath
+from dinounet_amd.parallel import GradAllReducer
+from dinounet_amd.training import TrainStep
+from dinounet_amd.optim import FusedClipSGD
+dev = torch.device("cuda", 0)
+g = torch.Generator().manual_seed(3)
+x = torch.randn(2, 3, 128, 128, generator=g).to(dev); t = torch.randint(0, 2, (2, 1, 128, 128), generator=g).to(dev)
+torch.manual_seed(7)
+net = DinoUNet.from_config(PLANS_2D, 3, 2, dinov3_pretrained_path=None, dinov3_model_name="dinounet_s", precision="bf16").to(dev).train()
+for m in net.modules():
+    if isinstance(m, DropPath):
+        m.drop_prob = 0.0
+net.encoder.dinov3_adapter.backbone.rope_embed.rescale_coords = None
+params = [p for p in net.parameters() if p.requires_grad]
+red = GradAllReducer(net, 1, bucket_elems=1 << 20)
+opt = FusedClipSGD(params, lr=1e-3, momentum=0.99, nesterov=True, weight_decay=3e-5, max_norm=12.0)
+ts = TrainStep(net, opt, params, x.shape, t.shape, dev, reducer=red, graph=True, warmup=2,
+               comm_outside_graph=os.environ.get("T_SEGMENTS") == "1")
+ops.SMALL_COLLECTIVES = []
+losses = [float(ts(x, t)) for _ in range(2)]            # the eager warm-up steps: their small collectives are counted
+small = [w for w, _, _ in ops.SMALL_COLLECTIVES]
+ops.SMALL_COLLECTIVES = None
+losses += [float(ts(x, t)) for _ in range(4)]
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    ts(x, t)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) * 100.0
+out = {"capture": ts.capture_mode, "losses": losses, "small": {w: small.count(w) // 2 for w in set(small)}, "ms": ms,
+       "what": list(getattr(ts.graph, "what", [])) if ts.graph is not None else None,
+       "params": [float(p.detach().double().sum()) for p in params], "absmax": [float(p.detach().abs().max()) for p in params]}
+if ts.graph is not None:
+    ts.graph.reset(); ts.graph = None
+red.remove()
+print(json.dumps(out))
+dist.destroy_process_group()
+""" % root
+
+    def run(extra):
+        env = dict(os.environ, DINOUNET_ALLOW_RANDOM_BACKBONE="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(_free_port()), **extra)
+        for k in ("DINOUNET_COMM_OUTSIDE_GRAPH", "DINOUNET_FORCE_SMALL_COLLECTIVES", "T_SEGMENTS"):
+            if k not in extra:
+                env.pop(k, None)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (extra, r.stdout[-2000:], r.stderr[-6000:])
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    plain = run({})
+    whole = run({"DINOUNET_FORCE_SMALL_COLLECTIVES": "1"})
+    segs = run({"DINOUNET_FORCE_SMALL_COLLECTIVES": "1", "T_SEGMENTS": "1"})
+    print(f"ungated {plain['capture']} {plain['ms']:.2f} ms/step | forced collectives: {whole['capture']} {whole['ms']:.2f} ms/step, "
+          f"{segs['capture']} {segs['ms']:.2f} ms/step, cuts {segs['what']}; small collectives per eager step {whole['small']}")
+    assert plain["capture"] == "whole_step" and plain["small"] == {}, plain
+    # 6 sequential SPM BatchNorms + the 4 output norms packed into one collective, forward and backward; the Dice sums once
+    assert whole["small"] == {"syncbn_fwd": 7, "syncbn_bwd": 7, "dice_sums": 1}, whole["small"]
+    assert whole["capture"] == "whole_step", whole["capture"]
+    assert segs["capture"].startswith("segments("), segs["capture"]          # captured, not the eager fallback
+    assert segs["what"].count("syncbn_fwd") == 7 and segs["what"].count("syncbn_bwd") == 7 and "dice_sums" in segs["what"], segs["what"]
+    for o in (whole, segs):
+        assert all(l == l for l in o["losses"]) and o["losses"][-1] != o["losses"][0]
+        # one-rank all-reduces are identities: the same kernels in the same order as the ungated step (the step's few fp32-atomic
+        # reductions make any two runs differ in the last bits)
+        assert max(abs(a - b) for a, b in zip(o["losses"], plain["losses"])) < 2e-3, (o["losses"], plain["losses"])
+        assert max(abs(a - b) / (1.0 + abs(b)) for a, b in zip(o["params"], plain["params"])) < 1e-3
+        assert max(abs(a - b) / (1e-3 + abs(b)) for a, b in zip(o["absmax"], plain["absmax"])) < 2e-2
