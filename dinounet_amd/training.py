@@ -277,7 +277,10 @@ class TrainStep:
                 # First with the mode of the whole-step attempt (cuts from the capturing thread only); a step whose BACKWARD issues
                 # collectives (SyncBatchNorm at N > 1: autograd's device thread) asks for a cut from that thread, which only a "relaxed"
                 # capture may serve -- second attempt
-                for seg_mode in (mode, "relaxed"):
+                # (a capture that dies inside autograd's thread cannot be ended cleanly -- the graph's destructor throws and takes the
+                #  process down, seen on hardware -- so the doomed thread-local attempt is not made when backward collectives are known to come)
+                from . import ops as _ops
+                for seg_mode in (("relaxed",) if _ops.sync_active() else (mode, "relaxed")):
                     try:
                         self.graph = self._capture_in_segments(seg_mode)
                         self.capture_mode = f"segments({len(self.graph.graphs)})" + ("" if seg_mode == mode else "/relaxed")

@@ -351,14 +351,14 @@ small = [w for w, _, _ in ops.SMALL_COLLECTIVES]
 ops.SMALL_COLLECTIVES = None
 losses += [float(ts(x, t)) for _ in range(4)]
 torch.cuda.synchronize()
+psum, pmax = [float(p.detach().double().sum()) for p in params], [float(p.detach().abs().max()) for p in params]
 t0 = time.perf_counter()
 for _ in range(10):
     ts(x, t)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) * 100.0
 out = {"capture": ts.capture_mode, "losses": losses, "small": {w: small.count(w) // 2 for w in set(small)}, "ms": ms,
-       "what": list(getattr(ts.graph, "what", [])) if ts.graph is not None else None,
-       "params": [float(p.detach().double().sum()) for p in params], "absmax": [float(p.detach().abs().max()) for p in params]}
+       "what": list(getattr(ts.graph, "what", [])) if ts.graph is not None else None, "params": psum, "absmax": pmax}
 if ts.graph is not None:
     ts.graph.reset(); ts.graph = None
 red.remove()
@@ -373,6 +373,11 @@ dist.destroy_process_group()
             if k not in extra:
                 env.pop(k, None)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            out = os.path.join(root, "gpurun_out")
+            if os.path.isdir(out):
+                with open(os.path.join(out, "forced_small_failure.log"), "a") as f:
+                    f.write(f"==== rc {r.returncode} extra {sorted(extra)}\n{r.stdout[-4000:]}\n---- stderr\n{r.stderr[-30000:]}\n")
         assert r.returncode == 0, (extra, r.stdout[-2000:], r.stderr[-6000:])
         return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
