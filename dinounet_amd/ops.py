@@ -569,6 +569,8 @@ class WgradQueue:
     flush before they read), or whose forward ran inside a torch DistributedDataParallel wrapper (its reducer copies gradients out of
     the accumulators as they arrive).  DINOUNET_WGRAD_DEFER=0 disables the queue."""
 
+    trace = None       # tools/wgrad_jobs.py: list -> every flush appends its job table
+
     def __init__(self):
         self.enabled = os.environ.get("DINOUNET_WGRAD_DEFER", "1") != "0"
         self.jobs = []          # du_tn_job records
@@ -732,6 +734,8 @@ class WgradQueue:
             return
         n = len(self.jobs)
         arr = (_lib.TnJob * n)(*self.jobs)
+        if self.trace is not None:           # tools/wgrad_jobs.py: the job table of a step (M, N, K, gather kind, per-sample scale?)
+            self.trace.append([(int(j.gather), int(j.M), int(j.N), int(j.K), bool(j.alpha), int(j.accumulate)) for j in self.jobs])
         e0 = PROFILE.start() if PROFILE is not None else None
         rc = _lib.lib().du_gemm_tn_group(arr, n, _st())
         fl, nb = self.flops, self.nbytes
