@@ -1484,7 +1484,10 @@ struct PpIdent {
 };
 __device__ const PpIdent g_pp_ident{};
 
-template <int ACT, bool NK4, int RES = 0>
+// PS: the pixel-shuffle store of ConvTranspose2d k2 s2 (column n = (tap, co) of input pixel m = (b, y, x) -> output pixel (b, 2y + tap / 2,
+// 2x + tap % 2), channel co; ps_C % 128 == 0: a tile's 128 columns lie in one tap; ps_H, ps_W powers of two), with the residual read through
+// the same mapping -- the adapter's `up` + c1 (dinov3_adapter.py:360,467), 32768 x 4096 x 1024: 428 us on the one-shot 256 x 256 kernel.
+template <int ACT, bool NK4, int RES = 0, bool PS = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<bf16_t>(P, smem); return; }
@@ -1518,9 +1521,17 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   // whole-matrix descriptors (the host checked every extent against 2^31 bytes); the tile's first row travels in the scalar offset
   const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)P.a.p, 0, (int)((((long)P.M - 1) * P.a.ld + P.K) * 2), 0x00020000);
   const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)P.b.p, 0, (int)((((long)P.N - 1) * P.b.ld + P.K) * 2), 0x00020000);
-  const auto rc = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, (int)((((long)P.M - 1) * P.ldc + P.N) * 2), 0x00020000);
+  const long out_rows = PS ? 4L * P.M : (long)P.M;           // rows (pixels) of C and of the residual
+  const int out_cols = PS ? P.ps_C : P.N;
+  const auto rc = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, (int)(((out_rows - 1) * P.ldc + out_cols) * 2), 0x00020000);
+  const int ps_lw = PS ? __builtin_ctz(P.ps_W) : 0, ps_lh = PS ? __builtin_ctz(P.ps_H) : 0;
+  // PS: output pixel (before the tap's shift) of input pixel m, as a row index of C / the residual
+  auto ps_pixel = [&](unsigned m) -> unsigned {
+    const unsigned x = m & (unsigned)(P.ps_W - 1), y = (m >> ps_lw) & (unsigned)(P.ps_H - 1), b = m >> (ps_lw + ps_lh);
+    return ((b * 2u * (unsigned)P.ps_H + 2u * y) * 2u * (unsigned)P.ps_W) + 2u * x;
+  };
   const auto rbias = __builtin_amdgcn_make_buffer_rsrc(P.bias ? (void*)P.bias : P.C, 0, P.bias ? P.N * 4 : 0, 0x00020000);
-  const int nrec_r = RES ? (int)((((long)P.M - 1) * P.ldr + P.N) * 2) : 0;
+  const int nrec_r = RES ? (int)(((out_rows - 1) * P.ldr + out_cols) * 2) : 0;
   const unsigned ldr2 = (unsigned)(P.ldr * 2);
 
   // staging: piece (round r, wave w) of a half = tile rows (r*8 + w)*8 .. +8, lane l -> row + l/8, physical 16-byte chunk l%8 holds
@@ -1538,6 +1549,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
   unsigned va_s[2][2], vb_s[2];   // ... of the tile being STAGED, out of range for rows past M / N and past the last tile
   unsigned sa_base = 0, sb_base = 0, sr_base = 0;
+  unsigned sm0 = 0;               // PS: first row of the staged tile (the residual's lane offsets are absolute output pixels)
   // the tile whose K-tiles are requested from now on; its bias slice -> LDS slot `slot` (waves 0 / 1, one 4-byte LDS-DMA each)
   auto set_stage_tile = [&](int tile, int slot) {
     if (tile < ntiles) {
@@ -1551,7 +1563,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
       }
       sa_base = (unsigned)m0 * (unsigned)(P.a.ld * 2);
       sb_base = (unsigned)n0 * (unsigned)(P.b.ld * 2);
-      if constexpr (RES != 0) sr_base = (unsigned)m0 * ldr2 + (unsigned)n0 * 2u;
+      if constexpr (RES != 0 && !PS) sr_base = (unsigned)m0 * ldr2 + (unsigned)n0 * 2u;
+      if constexpr (RES != 0 && PS) {
+        const int q = n0 / P.ps_C, co0 = n0 - q * P.ps_C;           // the tile's tap: pixel shift (q / 2) rows + (q % 2) columns
+        sr_base = (unsigned)((q >> 1) * 2 * P.ps_W + (q & 1)) * ldr2 + (unsigned)co0 * 2u;
+        sm0 = (unsigned)m0;
+      }
       if (wave < 2) {
         // inline asm: behind an LDS-DMA builtin the compiler waits vmcnt(0) in front of every read of the bias image (it cannot tell the
         // slots apart) -- once per phase of the drain.  Unseen, the image is ordered by distance: it is read a whole tile later, behind
@@ -1584,7 +1601,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
         unsigned sr = (unsigned)srow[r];
         asm volatile("" : "+v"(sr));
         if constexpr (which < 2) {
-          const unsigned vext = va_s[which][r] == PP_OOR ? PP_OOR : (which * 128u + sr) * ldr2 + (unsigned)lc * 16u;
+          const unsigned rowi = PS ? ps_pixel(sm0 + which * 128u + sr) : which * 128u + sr;
+          const unsigned vext = va_s[which][r] == PP_OOR ? PP_OOR : rowi * ldr2 + (unsigned)lc * 16u;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_void*)dst, 16, vext, sr_base + kofs, 0, 0);
         } else {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (lds_void*)dst, 16, sr * 256u + (unsigned)lc * 16u, kofs, 0, 0);
@@ -1671,7 +1689,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int m = m0 + i * 128 + wm * 32 + (lane & 31);
-      crow[i] = m < P.M ? (unsigned)(((long)m * P.ldc + pcol) * 2) : PP_OOR;
+      if constexpr (PS) {
+        const int q = n0 / P.ps_C, co0 = n0 - q * P.ps_C;
+        const unsigned pix = ps_pixel((unsigned)m) + (unsigned)((q >> 1) * 2 * P.ps_W + (q & 1));
+        crow[i] = m < P.M ? (unsigned)(((long)pix * P.ldc + co0 + wn * 64 + hi * 8) * 2) : PP_OOR;
+      } else {
+        crow[i] = m < P.M ? (unsigned)(((long)m * P.ldc + pcol) * 2) : PP_OOR;
+      }
     }
   };
   // The bias quad of a half is fetched ONE PHASE AHEAD by an inline-asm ds_read the compiler does not see: behind the LDS-DMA builtins it
@@ -1919,13 +1943,15 @@ int launch_pp(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
   }
   const bool nk4 = a.K == 256;
   const int res = a.residual ? (a.row_scale ? 2 : 1) : 0;       // the residual as two more K-steps (+ DropPath's per-sample scale)
+  const bool ps = a.store_mode == DU_STORE_PIXEL_SHUFFLE2;     // (pp_legal: with a residual, K >= 384)
   void (*kfn)(GemmParams);
-  if (res == 2) kfn = nk4 ? gemm_nt_pp_kernel<DU_ACT_NONE, true, 2> : gemm_nt_pp_kernel<DU_ACT_NONE, false, 2>;
+  if (ps) kfn = gemm_nt_pp_kernel<DU_ACT_NONE, false, 1, true>;
+  else if (res == 2) kfn = nk4 ? gemm_nt_pp_kernel<DU_ACT_NONE, true, 2> : gemm_nt_pp_kernel<DU_ACT_NONE, false, 2>;
   else if (res == 1) kfn = nk4 ? gemm_nt_pp_kernel<DU_ACT_NONE, true, 1> : gemm_nt_pp_kernel<DU_ACT_NONE, false, 1>;
   else if (nk4) kfn = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, true> : gemm_nt_pp_kernel<DU_ACT_NONE, true>;
   else kfn = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, false> : gemm_nt_pp_kernel<DU_ACT_NONE, false>;
-  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
-  const int ai = res ? 2 + 2 * res + (nk4 ? 1 : 0) : (a.act == DU_ACT_GELU ? 1 : 0) + (nk4 ? 2 : 0);
+  static bool attr_set[9] = {false, false, false, false, false, false, false, false, false};
+  const int ai = ps ? 8 : (res ? 2 + 2 * res + (nk4 ? 1 : 0) : (a.act == DU_ACT_GELU ? 1 : 0) + (nk4 ? 2 : 0));
   if (!attr_set[ai]) {
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess) return DU_ERR_LAUNCH;
     attr_set[ai] = true;
@@ -2045,7 +2071,13 @@ static bool p8_legal(const du_gemm_args& a) {
 
 // the persistent 256 x 128 kernel: bf16 result with a bias (+ GELU) epilogue, plain store, K >= 512, every extent below 2^31 bytes
 static bool pp_legal(const du_gemm_args& a) {
-  if (!p8_legal(a) || a.out_dtype != DU_BF16 || a.store_mode != DU_STORE_PLAIN || a.batch > 1) return false;
+  if (!p8_legal(a) || a.out_dtype != DU_BF16 || a.batch > 1) return false;
+  const bool ps = a.store_mode == DU_STORE_PIXEL_SHUFFLE2;
+  if (ps) {     // ConvTranspose2d k2 s2 forward + residual: a 128-column tile inside one tap, power-of-two pixel grid
+    if (!a.residual || a.row_scale || a.K < 384 || a.ps_C % 128 || a.N != 4 * a.ps_C || a.ps_H <= 0 || a.ps_W <= 0) return false;
+    if ((a.ps_H & (a.ps_H - 1)) || (a.ps_W & (a.ps_W - 1)) || a.M % (a.ps_H * a.ps_W)) return false;
+    if ((4L * a.M * a.ldc + a.N) * 2 >= 0x7fffffffL || (4L * a.M * a.ldr + a.N) * 2 >= 0x7fffffffL) return false;
+  } else if (a.store_mode != DU_STORE_PLAIN) return false;
   if (a.gamma || a.alpha != 1.0f || (a.act != DU_ACT_NONE && a.act != DU_ACT_GELU)) return false;
   if ((a.K != 256 && a.K < 384) || a.N % 8 || a.ldc % 8 || (((uintptr_t)a.C) & 15)) return false;      // (K = 256: the four-K-step form)
   const long lim = 0x7fffffffL;

@@ -538,6 +538,39 @@ def test_conv_transpose2x2_bwd_on_gather_kernels(B, H, W, Cin, Cout):
     assert rel(res[1][1], res[0][1]) < 1e-4
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 64, 64, 1024, 1024), (1, 32, 64, 384, 256), (3, 16, 32, 512, 128)])
+def test_conv_transpose2x2_residual_on_the_persistent_kernel(B, H, W, Cin, Cout):
+    """Round 6: ConvTranspose2d k2 s2 + skip add (dinov3_adapter.py:360,467: `up(c2) + c1`) on the persistent multi-phase kernel -- pixel-shuffle
+    store from the drain, the residual read through the same pixel mapping as two more K-steps of the tile (gemm_nt_pp_kernel<.., PS>).
+    Forced where the cost model would not choose it (du_set_option key 0 = 4), against conv_transpose2d + add in fp32 of the same bf16
+    operands, against the one-shot kernel (key 14 = 0), and repeat-run identical."""
+    from dinounet_amd import _lib, ops
+    d = dev()
+    dt = torch.bfloat16
+    x, w, b = q(gen(B, Cin, H, W, seed=1), dt), q(gen(Cin, Cout, 2, 2, seed=2, scale=Cin ** -0.5), dt), gen(Cout, seed=3)
+    res = q(gen(B, Cout, 2 * H, 2 * W, seed=5), dt)
+    ref = F.conv_transpose2d(x.float(), w.float(), b, stride=2) + res.float()
+    xg, rg = nhwc(x).to(d, dt), nhwc(res).to(d, dt)
+    L = _lib.lib()
+    outs = {}
+    try:
+        for name, mode, k14 in (("pp", 4, 1), ("pp2", 4, 1), ("oneshot", 1, 0)):
+            L.du_set_option(0, mode)
+            L.du_set_option(14, k14)
+            ops.TRACK_ROUTE, ops.ROUTES[:] = True, []
+            with torch.no_grad():
+                outs[name] = ops.conv_transpose2x2(xg, w.to(d), b.to(d), residual=rg).float().cpu()
+            ops.TRACK_ROUTE = False
+            assert ops.LAST_GEMM_ROUTE == (6 if mode == 4 else 3), (name, ops.LAST_GEMM_ROUTE)
+    finally:
+        ops.TRACK_ROUTE = False
+        L.du_set_option(0, -1)
+        L.du_set_option(14, 1)
+    assert rel(outs["pp"].permute(0, 3, 1, 2), ref) < TOL[dt]
+    assert torch.equal(outs["pp"], outs["pp2"]), "run-to-run difference: pipeline race"
+    assert rel(outs["pp"], outs["oneshot"]) < 1e-2           # same bf16 products, another summation order, one bf16 rounding
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,bias", [(2, 16, 16, 256, 128, True), (2, 16, 32, 32, 32, True), (4, 16, 16, 384, 384, False),
                                                  (2, 32, 32, 64, 32, True), (1, 32, 64, 24, 40, True)])
 def test_conv_transpose2x2_weight_gradient_on_the_grouped_launch(B, H, W, Cin, Cout, bias):

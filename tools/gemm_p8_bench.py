@@ -108,7 +108,7 @@ def time_variants(rounds):
     bf16res = "--bf16res" in sys.argv
     if bf16res:      # round 6: the adapter's products into the bf16 query stream as the model issues them (bias + bf16 residual, fc2: + DropPath scale)
         shapes = [(43008, 1024, 256, bf, "ffn_fc2_res"), (43008, 1024, 512, bf, "oproj_res"), (43008, 1024, 1024, bf, "k1024_res"),
-                  (21504, 1024, 256, bf, "fc2_res_b4"), (43008, 768, 384, bf, "b_oproj_res")]
+                  (21504, 1024, 256, bf, "fc2_res_b4"), (43008, 768, 384, bf, "b_oproj_res"), (32768, 4096, 1024, bf, "convt_up")]
         variants = [v for v in variants if v[0] in ("256x256", "256x128", "persist", "auto")] + [("auto r5", dict(mode=-1))]
     print(f"{'shape':>34} " + " ".join(f"{n:>11}" for n, _ in variants) + "   (us median | TF/s of `auto` = what ships, fraction of 2.5 PF | best complete variant)")
     import time
@@ -125,17 +125,24 @@ def time_variants(rounds):
             kwargs.update(residual=torch.randn(M, N, device=dev).to(bf))
             if name.startswith("f"):      # ConvFFN fc2: DropPath's per-sample scale (5376 rows per sample)
                 kwargs.update(row_scale=(torch.arange(M // 5376, device=dev) % 3 != 0).float() / 0.7, rs_rows=5376)
+        call = lambda: ops.mm(x, w, out=out, **kwargs)
+        if bf16res and name == "convt_up":        # the adapter's `up` + c1: pixel-shuffle store, residual in the output layout
+            out = torch.empty((4 * M, N // 4), dtype=od, device=dev)
+            cres, cbias = torch.randn(4 * M, N // 4, device=dev).to(bf), torch.randn(N, device=dev)
+            call = lambda: ops.gemm_raw(dtype=_lib.DU_BF16, out_dtype=_lib.DU_BF16, a_mode=ops.PLAIN_ROW, b_mode=ops.PLAIN_ROW, M=M, N=N, K=K,
+                                        A=x.data_ptr(), lda=K, B=w.data_ptr(), ldb=K, Cmat=out.data_ptr(), ldc=N // 4, bias=cbias.data_ptr(),
+                                        residual=cres.data_ptr(), ldr=N // 4, store_mode=ops.STORE_PIXEL_SHUFFLE2, ps=(64, 64, N // 4))
         ts = {n: [] for n, _ in variants}
         graphs = {}
         for n, kw in variants:                     # warm-up, then capture 10 back-to-back launches per variant (no host time in the number)
             opt(**kw)
             L.du_set_option(14, 0 if n == "auto r5" else 1)
-            ops.mm(x, w, out=out, **kwargs)
+            call()
             torch.cuda.synchronize()
             g_ = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_):
                 for _ in range(10):
-                    ops.mm(x, w, out=out, **kwargs)
+                    call()
             graphs[n] = g_
         torch.cuda.synchronize()
         t0 = time.time()                            # warm the clocks: a cold chip runs the first variants ~10 % slower than the last
