@@ -195,6 +195,13 @@ def main():
            "final_loss": round(float(loss.item()), 5), "hipgraph": bool(graph_used)}
     if comm is not None:
         out["comm"] = comm
+    # the only trustworthy round-over-round delta is an interleaved same-box A/B of the two trees (box-to-box spread of one tree: ~15 %);
+    # its factor is committed beside the raw runs and quoted here so it need not be dug out
+    try:
+        ab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "ab_vs_prev_round.json")))
+        out["ab_vs_prev_round"], out["ab_source"] = ab["factor"], ab["source"]
+    except Exception:  # noqa: BLE001
+        pass
     if rank == 0:
         if prof is not None:
             try:
@@ -245,9 +252,13 @@ def north_star_targets(prof, steps=1):
         a[1] += fl
         a[2] += nb
     out = {}
-    if "attn_fwd_kernel" in agg and agg["attn_fwd_kernel"][0] > 0:
-        t, fl, _ = agg["attn_fwd_kernel"]
-        out["attention_mfma_frac"] = {"measured": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "target": 0.40, "kernel": "attn_fwd_kernel"}
+    # every target line names where its number comes from: "north_star" = BASELINE.json, "builder" = a goal this repo set itself
+    for ak in ("attn_fwd_w64_kernel", "attn_fwd_kernel"):
+        if ak in agg and agg[ak][0] > 0:
+            t, fl, _ = agg[ak]
+            out["attention_mfma_frac"] = {"measured": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "target": 0.40, "kernel": ak,
+                                          "source": "north_star"}
+            break
     # decoder 3x3 convolutions, named by the kernel that ran: strip = streaming kernel (32 / 64 channels, W % 128 == 0), halo = LDS-tiled
     # kernel (64 + 64 concat and whatever the strip kernel declines), c128 = LDS-tiled kernel with 128 output channels (above the ridge:
     # reported against the MFMA roof).  `decoder_conv_hbm_frac` keeps its round-4 meaning (all layers with <= 64 output channels, both
@@ -256,27 +267,28 @@ def north_star_targets(prof, steps=1):
     le64 = [fam[k] for k in ("conv3x3_strip_kernel", "conv3x3_halo_kernel") if k in fam]
     if le64:
         t, nb = sum(v[0] for v in le64), sum(v[2] for v in le64)
-        out["decoder_conv_hbm_frac"] = {"measured": round(nb / t / 1e9 / HBM_PEAK_GBS, 4), "target": 0.60,
+        out["decoder_conv_hbm_frac"] = {"measured": round(nb / t / 1e9 / HBM_PEAK_GBS, 4), "target": 0.60, "source": "north_star",
                                         "kernel": "conv3x3_strip_kernel + conv3x3_halo_kernel, Cout <= 64", "ms_per_step": round(t * 1e3 / steps, 3)}
         for k, label in (("conv3x3_strip_kernel", "decoder_conv_strip_hbm_frac"), ("conv3x3_halo_kernel", "decoder_conv_halo_hbm_frac")):
             if k in fam:
                 t1, _, nb1 = fam[k]
-                out[label] = {"measured": round(nb1 / t1 / 1e9 / HBM_PEAK_GBS, 4), "target": 0.60, "kernel": k + ", Cout <= 64",
-                              "ms_per_step": round(t1 * 1e3 / steps, 3)}
+                out[label] = {"measured": round(nb1 / t1 / 1e9 / HBM_PEAK_GBS, 4), "target": 0.60, "source": "north_star (per kernel)",
+                              "kernel": k + ", Cout <= 64", "ms_per_step": round(t1 * 1e3 / steps, 3)}
     if fam:
         t, nb = sum(v[0] for v in fam.values()), sum(v[2] for v in fam.values())
-        out["decoder_conv_all_hbm_frac"] = {"measured": round(nb / t / 1e9 / HBM_PEAK_GBS, 4), "target": 0.60,
+        out["decoder_conv_all_hbm_frac"] = {"measured": round(nb / t / 1e9 / HBM_PEAK_GBS, 4), "target": 0.60, "source": "north_star",
                                             "kernel": "every 3x3 stride-1 convolution of the step (rounds 1-3 definition: 128-channel layers included)",
                                             "ms_per_step": round(t * 1e3 / steps, 3)}
     if "conv3x3_halo_c128_kernel" in fam:   # 128 output channels: above the ridge -> MFMA roof
         t, fl, _ = fam["conv3x3_halo_c128_kernel"]
-        out["decoder_conv_mfma_frac"] = {"measured": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "target": 0.35,
+        out["decoder_conv_mfma_frac"] = {"measured": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "target": 0.35, "source": "builder",
                                          "kernel": "conv3x3_halo_kernel, Cout = 128", "ms_per_step": round(t * 1e3 / steps, 3)}
     for key, name, tgt in (("msda_fwd", "msda_fwd_hbm_frac", 0.35), ("msda_bwd", "msda_bwd_hbm_frac", 0.25)):
         if key in agg and agg[key][0] > 0:                                        # the gather path of MSDeformAttn (algorithmic bytes)
             t, _, nb = agg[key]
-            out[name] = {"measured": round(nb / t / 1e9 / HBM_PEAK_GBS, 4), "target": tgt, "gbs": round(nb / t / 1e9, 1), "ms_per_step": round(t * 1e3 / steps, 3)}
-    out["scaling_8gpu"] = {"measured": None, "target": 6.5, "note": "the driver's SCALE run measures it"}
+            out[name] = {"measured": round(nb / t / 1e9 / HBM_PEAK_GBS, 4), "target": tgt, "source": "builder", "gbs": round(nb / t / 1e9, 1),
+                         "ms_per_step": round(t * 1e3 / steps, 3)}
+    out["scaling_8gpu"] = {"measured": None, "target": 6.5, "source": "north_star", "note": "the driver's SCALE run measures it"}
     return out
 
 

@@ -779,7 +779,11 @@ template <int CK, int MT>
 int launch_wgrad_rows(WgradParams& P, int max_blocks, hipStream_t st) {
   constexpr size_t lds = wgrad_rows_lds<CK, MT>();
   auto kfn = conv3x3_wgrad_rows_kernel<CK, MT>;
-  if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DU_ERR_LAUNCH;
+  static bool attr_set = false;          // once per instantiation (as launch_pp / rk_launch)
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DU_ERR_LAUNCH;
+    attr_set = true;
+  }
   int grid = max_blocks < P.ntiles ? max_blocks : P.ntiles;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, P);
   return du_check_launch();
@@ -814,7 +818,11 @@ extern "C" int du_conv3x3_wgrad_halo_blocks(int C1, int Cin, int Cout, int B, in
   static const int cap_env = DU_GETENV("DU_HALO_WGRAD_BLOCKS") ? atoi(DU_GETENV("DU_HALO_WGRAD_BLOCKS")) : 0;
   int cap = cap_env > 0 ? cap_env : ((long)Cout * 9 * Cin * 4 <= 80L * 1024 ? 512 : 256);
   // round-5 kernel: two LDS stages; all forms but 32 -> 32 channels run one workgroup per CU (72-118 KB), so a second slab per CU buys nothing
-  if (g_wgrad_rows && cap_env <= 0 && (Cout == 64 || (Cin % 64 == 0 && C1 % 64 == 0))) cap = 256;
+  // (keyed on the kernel that will run: past the 32-bit offset limit -- judged here on the dense tensors, ld = channels -- the round-3
+  //  kernel takes the shape and keeps the workgroup count it was tuned for)
+  const long pix = (long)B * H * W;
+  const bool small = pix * (Cin > C1 ? Cin : C1) * 2 < 0x7fffffffL && pix * Cout * 2 < 0x7fffffffL;
+  if (g_wgrad_rows && small && cap_env <= 0 && (Cout == 64 || (Cin % 64 == 0 && C1 % 64 == 0))) cap = 256;
   return ntiles < cap ? ntiles : cap;
 }
 

@@ -439,6 +439,15 @@ int launch_modes(const du_gemm_args& a, hipStream_t st) {
 
 }  // namespace
 
+// slabs a DU_STORE_SLABS product writes: make_params' rounding of the K range per split to whole K tiles of THIS engine (BK), empty ranges dropped
+extern "C" int du_gemm_slab_count(int K, int split_k) {
+  if (K <= 0) return 0;
+  if (split_k < 1) split_k = 1;
+  int kps = (K + split_k - 1) / split_k;
+  kps = ((kps + BK - 1) / BK) * BK;
+  return (K + kps - 1) / kps;
+}
+
 int du_gemm_nt_glds(const du_gemm_args& a, hipStream_t st);   // gemm_glds.hip
 int du_gemm_skinny(const du_gemm_args& a, hipStream_t st);    // gemm_skinny.hip
 int64_t du_gemm_skinny_ws_elems(int N, int K);

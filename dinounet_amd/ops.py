@@ -638,6 +638,15 @@ class WgradQueue:
         self.state.clear()
         self._armed_task = None
 
+    def reset(self):
+        """Forget everything queued WITHOUT launching it.  Call after a backward pass that raised (out of memory, an interrupted step): its
+        final callback never ran, and the queue cannot tell that dead pass from a suspended outer pass of a nested backward -- so the next
+        pass would LAUNCH the dead jobs.  That is harmless when the parameters' gradients were dropped since (zero_grad(set_to_none=True),
+        the default), but with zero_grad(set_to_none=False) or gradient accumulation autograd may still hold a dead job's result buffer
+        as p.grad, and the stale product would be added into the new gradient.  TrainStep does this itself after a failed
+        capture (training._forget_failed_pass)."""
+        self._drop()
+
     def _hand_over(self, ids):
         """the parameters `ids` are about to receive a COMPLETE contribution: whatever is queued for them must be complete first"""
         for i in ids:
@@ -956,7 +965,7 @@ def _im2col_split(M, N, K):
     engine's split-K form adds fp32 partial tiles into a zeroed buffer (no bias / activation: those layers have none); the caller converts
     to bf16.  0 = leave the product alone."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if not _CONV_SPLITK or tiles > 128 or K < 1024:
+    if not _CONV_SPLITK or tiles > 128 or K < 1024 or N % 4:
         return 0
     return max(2, min(8, 256 // tiles, K // 256))
 
@@ -966,14 +975,16 @@ def _conv_splitk(sk, M, N, K, a, lda, w, ldb, g, out):
     zero fill, no atomics) and du_splitk_reduce_bf16 adds the slabs in order -- the result does not depend on the order in which the
     workgroups finish (a forward pass whose bits changed from run to run would make every repeat-run test a tolerance test)."""
     slabs = torch.empty((sk, M, N), dtype=torch.float32, device=a.device)
+    kw = dict(dtype=DU_BF16, out_dtype=DU_F32, a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=M, N=N, K=K, A=a.data_ptr(), lda=lda,
+              B=w.data_ptr(), ldb=ldb, Cmat=slabs.data_ptr(), ldc=N, split_k=sk, store_mode=STORE_SLABS, geom=g)
+    if gemm_route(**kw) != 1:          # only the bf16 tile engine writes slabs (du_gemm would return DU_ERR_UNSUPPORTED): the caller runs
+        return False                   # the product unsplit (ADVICE r5)
     # (the library rounds the K range per split up to whole K tiles and may run fewer splits than asked: slabs it does not write must not
-    #  be read -- ask it how many it will use)
-    kps = -(-K // sk)
-    kps = -(-kps // 64) * 64
-    used = -(-K // kps)
-    gemm_raw(dtype=DU_BF16, out_dtype=DU_F32, a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=M, N=N, K=K, A=a.data_ptr(), lda=lda,
-             B=w.data_ptr(), ldb=ldb, Cmat=slabs.data_ptr(), ldc=N, split_k=sk, store_mode=STORE_SLABS, geom=g)
+    #  be read -- it says how many it writes)
+    used = int(_lib.lib().du_gemm_slab_count(K, sk))
+    gemm_raw(**kw)
     _lib.check(_lib.lib().du_splitk_reduce_bf16(_p(slabs), _p(out), used, M * N, _st()), "du_splitk_reduce_bf16")
+    return True
 
 
 def conv_fwd(x, wp, bias, KH, KW, stride, pad, x2=None, out=None, act=ACT_NONE):
@@ -992,8 +1003,7 @@ def conv_fwd(x, wp, bias, KH, KW, stride, pad, x2=None, out=None, act=ACT_NONE):
         out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
     _, _, _, _, ldc = _nhwc(out)
     sk = _im2col_split(B * Ho * Wo, Cout, Kc) if (x.dtype == torch.bfloat16 and bias is None and act == ACT_NONE and out.is_contiguous()) else 0
-    if sk:
-        _conv_splitk(sk, B * Ho * Wo, Cout, Kc, x, ld, wp, ldb, g, out)
+    if sk and _conv_splitk(sk, B * Ho * Wo, Cout, Kc, x, ld, wp, ldb, g, out):
         return out
     gemm_raw(dtype=_code(x.dtype), out_dtype=_code(out.dtype), a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * Ho * Wo, N=Cout,
              K=Kc, A=x.data_ptr(), lda=ld, B=wp.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=ldc, bias=_dp(bias), act=act,
@@ -1011,8 +1021,7 @@ def conv_dgrad(dy, wd, KH, KW, stride, pad, Hin, Win, out=None):
         out = torch.empty((B, Hin, Win, Cin), dtype=dy.dtype, device=dy.device)
     _, _, _, _, ldc = _nhwc(out)
     sk = _im2col_split(B * Hin * Win, Cin, Kc) if (dy.dtype == torch.bfloat16 and out.is_contiguous()) else 0
-    if sk:
-        _conv_splitk(sk, B * Hin * Win, Cin, Kc, dy, ld, wd, ldb, g, out)
+    if sk and _conv_splitk(sk, B * Hin * Win, Cin, Kc, dy, ld, wd, ldb, g, out):
         return out
     gemm_raw(dtype=_code(dy.dtype), out_dtype=_code(out.dtype), a_mode=IM2COL_ROW, b_mode=PLAIN_ROW, M=B * Hin * Win, N=Cin,
              K=Kc, A=dy.data_ptr(), lda=ld, B=wd.data_ptr(), ldb=ldb, Cmat=out.data_ptr(), ldc=ldc, geom=g)
@@ -1044,7 +1053,9 @@ def conv3x3_wgrad_halo(x, dy, x2=None, with_db=False):
         return None
     _lib.check(rc, "du_conv3x3_wgrad_halo")
     if PROFILE is not None:
-        PROFILE.stop("conv3x3_wgrad_halo_kernel<bf16>" + (f" {H}x{W} {Cin}->{Cout}" if PROFILE.detail else ""), e0,
+        # (named by the kernel the library runs for this shape: the round-5 rows kernel serves 32 / 64 output channels, conv_halo.hip)
+        wk = "conv3x3_wgrad_rows_kernel<bf16>" if Cout in (32, 64) else "conv3x3_wgrad_halo_kernel<bf16>"
+        PROFILE.stop(wk + (f" {H}x{W} {Cin}->{Cout}" if PROFILE.detail else ""), e0,
                      2.0 * B * H * W * Cin * Cout * 9, 2.0 * B * H * W * (Cin + Cout))
     return (dw, out[Cout * 9 * Cin:]) if with_db else dw
 
@@ -2304,7 +2315,7 @@ def qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, workspace):
             e0 = PROFILE.start() if PROFILE is not None else None
             _lib.check(L.du_attention_fwd(_p(q), _p(k), _p(v), _p(out), B, H, N, Npad, Dh, _st()), "du_attention_fwd")
             if PROFILE is not None:
-                PROFILE.stop("attn_fwd_kernel<bf16>", e0, 4.0 * B * H * N * N * Dh, 4.0 * B * H * N * Dh * 2)
+                PROFILE.stop(("attn_fwd_w64_kernel<bf16>" if Dh == 64 else "attn_fwd_kernel<bf16>"), e0, 4.0 * B * H * N * N * Dh, 4.0 * B * H * N * Dh * 2)
             return out
     return attention(mm(h, w, bias=bias), sin, cos, B, N, H, Dh, prefix, workspace)
 
@@ -2328,7 +2339,7 @@ def attention(qkv, sin, cos, B, N, H, Dh, prefix, workspace):
         e0 = PROFILE.start() if PROFILE is not None else None
         _lib.check(L.du_attention_fwd(_p(q), _p(k), _p(v), _p(out), B, H, N, Npad, Dh, _st()), "du_attention_fwd")
         if PROFILE is not None:
-            PROFILE.stop("attn_fwd_kernel<bf16>", e0, 4.0 * B * H * N * N * Dh, 4.0 * B * H * N * Dh * 2)
+            PROFILE.stop(("attn_fwd_w64_kernel<bf16>" if Dh == 64 else "attn_fwd_kernel<bf16>"), e0, 4.0 * B * H * N * N * Dh, 4.0 * B * H * N * Dh * 2)
         return out
     skey = ("scores", B, H, Npad)
     if skey not in workspace:

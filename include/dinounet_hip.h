@@ -391,6 +391,9 @@ int du_swiglu_pairs(int dtype, const void* u, void* out, int64_t rows, int64_t h
    (batch-subset stochastic depth of the ViT-7B blocks in train mode, layers/block.py:126-187) */
 int du_sample_copy(const float* src, float* dst, const int64_t* idx, int k, int64_t n_per_sample, int scatter, void* stream);
 int du_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
+/* number of slabs a DU_STORE_SLABS product with contraction K asked to run `split_k` ranges actually writes (each range is rounded up
+   to whole K tiles of the engine; empty ranges are dropped): what the caller passes to du_splitk_reduce_bf16 as `splits` */
+int du_gemm_slab_count(int K, int split_k);
 /* out[i] = bf16( sum_{s < splits, in order} slabs[s * n + i] ): the second half of a DU_STORE_SLABS split-K product (n % 4 == 0) */
 int du_splitk_reduce_bf16(const float* slabs, void* out, int splits, int64_t n, void* stream);
 /* NCHW fp32 image -> NHWC `dtype` with channels zero-padded to Cpad */

@@ -159,6 +159,34 @@ def test_a_backward_pass_that_raised_does_not_disarm_the_queue(queue):
     assert torch.equal(w2.grad, torch.full((4, 3), 4.5)) and w.grad is None
 
 
+def test_reset_after_a_failed_backward_drops_the_dead_jobs_instead_of_launching_them(queue):
+    """ADVICE r5: with zero_grad(set_to_none=False) / gradient accumulation autograd may still hold a dead pass's result buffer as p.grad;
+    launching the leftovers at the next backward would add a stale product into the new gradient.  WGRAD.reset() after the failure is the
+    documented way out: nothing of the dead pass is launched, the next pass arms itself and completes its own gradients."""
+    q, fake = queue
+
+    class _Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    w = torch.nn.Parameter(torch.ones(2, 3))
+    x = torch.ones(5, requires_grad=True)
+    with pytest.raises(RuntimeError):
+        _Lin.apply(_Boom.apply(x), w).sum().backward()
+    assert q.jobs and q._armed_task is not None
+    q.reset()
+    assert not q.jobs and not q.keep and not q.groups and not q.state and q._armed_task is None
+    w2 = torch.nn.Parameter(torch.ones(4, 3))
+    _Lin.apply(x, w2).sum().backward()
+    assert fake.launched == [(4, 3, 0)]                       # the dead (2, 3) job was never launched
+    assert torch.equal(w2.grad, torch.full((4, 3), 4.5))
+
+
 def test_a_nested_backward_pass_does_not_lose_the_outer_passes_jobs(queue):
     """a backward pass started INSIDE a node of another pass (reentrant checkpointing, autograd.grad in a hook or a custom
     Function) has its own graph-task id.  The outer pass is alive and has already handed its zero-filled buffers to autograd: its queued
