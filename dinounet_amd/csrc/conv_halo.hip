@@ -802,14 +802,22 @@ int launch_wgrad(WgradParams& P, int max_blocks, hipStream_t st) {
 
 }  // namespace
 
-int g_wgrad_rows = 1;     // du_set_option key 13: 1 = the round-5 weight-gradient kernel (conv3x3_wgrad_rows_kernel), 0 = the round-3 one (A-B aid)
+int g_wgrad_rows = 1;     // du_set_option key 13: 1 = conv3x3_wgrad_rows_kernel for 32 / 64 output channels, 128 on the grouped launch's in-place gather
+                          // (default); 2 = 128 output channels on the rows kernel too (round 6: 106 / 200 us for the two layers against 400 us of
+                          // grouped launch, but x1.0001 in the step -- profiles/r06_ab_wgrad128_side_v1.txt -- so it stays opt-in); 0 = the round-3 kernel
 
 // number of workgroups (= partial dW slabs) the weight-gradient kernel uses for this shape; 0 = shape not served
 extern "C" int du_conv3x3_wgrad_halo_blocks(int C1, int Cin, int Cout, int B, int H, int W) {
   if (H % TH || W % TW || B <= 0) return 0;
-  if (!(Cout == 32 || Cout == 64) || Cin % 32 || C1 % 32) return 0;   // 128 output channels: 9 accumulator tiles per wave spill
-  if ((long)Cout * 9 * Cin > 80L * 1024) return 0;                 // larger filters: MFMA-bound anyway, partial slabs too big
   const int ntiles = B * (H / TH) * (W / TW);
+  if (Cout == 128 && g_wgrad_rows >= 2 && Cin % 32 == 0 && C1 % 32 == 0 && Cin <= 256 &&
+      (long)B * H * W * (Cin > 128 ? Cin : 128) * 2 < 0x7fffffffL) {
+    // round 6: the 128-output layers of the first decoder stage (dinounet_training.py:581-592) on the rows kernel, one 32-output block per
+    // wave over 32-channel input chunks; the partial slabs are 0.6-1.2 MB each: 128 workgroups (75-150 MB for the finalize pass to read)
+    return ntiles < 128 ? ntiles : 128;
+  }
+  if (!(Cout == 32 || Cout == 64) || Cin % 32 || C1 % 32) return 0;   // (round-3 kernel: 9 accumulator tiles per wave spill at 128 outputs)
+  if ((long)Cout * 9 * Cin > 80L * 1024) return 0;                 // larger filters: MFMA-bound anyway, partial slabs too big
   // persistent workgroups = partial dW slabs.  36-50 KB of LDS and 4 waves each: one per CU leaves every SIMD with a single wave and
   // nothing to switch to while it waits for its LDS writes / barrier / transpose reads (1.4 TB/s measured); two per CU double the
   // slab traffic of the finalize (<= 2 x 75 MB) and hide that latency.  DU_HALO_WGRAD_BLOCKS overrides (A-B aid).
@@ -846,7 +854,10 @@ extern "C" int du_conv3x3_wgrad_halo(const void* x, int64_t ldx, const void* x2,
   // the round-5 kernel addresses the three tensors through 32-bit buffer offsets
   const long pix = (long)B * H * W;
   const bool small = pix * ldx * 2 < 0x7fffffffL && pix * lddy * 2 < 0x7fffffffL && (!x2 || pix * ldx2 * 2 < 0x7fffffffL);
-  if (g_wgrad_rows && small) {
+  if (Cout == 128) {
+    if (!(g_wgrad_rows >= 2 && small)) return DU_ERR_UNSUPPORTED;
+    rc = launch_wgrad_rows<32, 4>(P, blocks, st);
+  } else if (g_wgrad_rows && small) {
     if (Cout == 32) rc = c64 ? launch_wgrad_rows<64, 1>(P, blocks, st) : launch_wgrad_rows<32, 1>(P, blocks, st);
     else if (Cout == 64) rc = c64 ? launch_wgrad_rows<64, 2>(P, blocks, st) : launch_wgrad_rows<32, 2>(P, blocks, st);
   } else if (Cout == 32) rc = c64 ? launch_wgrad<64, 1>(P, blocks, st) : launch_wgrad<32, 1>(P, blocks, st);

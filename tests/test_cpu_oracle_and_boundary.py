@@ -558,7 +558,8 @@ def test_conv3x3_kernel_choice_host_logic_without_gpu():
     assert int(L.du_conv3x3_strip(*big)) == -2
     assert int(L.du_conv3x3_halo(*big)) == -2
     # weight gradient: workgroups = partial slabs.  The round-5 kernel (two LDS stages) runs one workgroup per CU for everything but the
-    # 32 -> 32 form (39 KB of LDS: two per CU); the round-3 kernel (du_set_option(13, 0)) went by slab size alone.  128 outputs: not served.
+    # 32 -> 32 form (39 KB of LDS: two per CU); the round-3 kernel (du_set_option(13, 0)) went by slab size alone.  128 outputs: not served
+    # (the grouped launch) unless option 13 = 2 (round 6, opt-in): the rows kernel with 128 workgroups (0.6-1.2 MB slabs).
     blocks = lambda C1, Cin, Cout, B, H, W: int(L.du_conv3x3_wgrad_halo_blocks(C1, Cin, Cout, B, H, W))
     try:
         assert blocks(32, 32, 32, 8, 512, 512) == 512 and blocks(32, 64, 32, 8, 512, 512) == 512      # (32 + 32 concat: 32-channel chunks)
@@ -566,7 +567,11 @@ def test_conv3x3_kernel_choice_host_logic_without_gpu():
         assert blocks(32, 32, 64, 8, 256, 256) == 256
         assert blocks(32, 32, 32, 1, 16, 32) == 4                                                         # fewer tiles than workgroups
         assert blocks(128, 128, 128, 8, 128, 128) == 0 and blocks(32, 32, 32, 1, 12, 128) == 0
+        L.du_set_option(13, 2)
+        assert blocks(128, 128, 128, 8, 128, 128) == 128 and blocks(128, 256, 128, 8, 128, 128) == 128 and blocks(128, 128, 128, 1, 8, 16) == 1
+        assert blocks(128, 384, 128, 8, 128, 128) == 0 and blocks(64, 64, 64, 8, 256, 256) == 256
         L.du_set_option(13, 0)
+        assert blocks(128, 128, 128, 8, 128, 128) == 0
         assert blocks(64, 64, 32, 8, 512, 512) == 512 and blocks(32, 32, 64, 8, 256, 256) == 512 and blocks(64, 64, 64, 8, 256, 256) == 256
     finally:
         L.du_set_option(13, 1)

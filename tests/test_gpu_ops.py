@@ -623,6 +623,7 @@ def test_conv3x3_weight_gradient_on_the_grouped_launch(B, H, W, C1, C2, Cout, bi
     wg = torch.nn.Parameter(w.to(d))
     bg = torch.nn.Parameter(bv.to(d)) if bias else None
     n0 = ops.WGRAD.queued
+    from dinounet_amd import _lib
     y = ops.conv2d(xg, wg, bg, 1, 1, x2g)
     gg = torch.autograd.grad(y, (wg, bg) if bias else (wg,), go.to(d, dt))
     assert ops.WGRAD.queued == n0 + 1 and not ops.WGRAD.jobs
@@ -630,6 +631,20 @@ def test_conv3x3_weight_gradient_on_the_grouped_launch(B, H, W, C1, C2, Cout, bi
     assert rel(gg[0].flatten(1), gr[0].float().flatten(1)) < 2e-5
     if bias:
         assert rel(gg[1], gr[1].float()) < 2e-5
+    # round 6: the same layer through autograd on the rows kernel (du_set_option(13, 2), opt-in): same gradients
+    wg2 = torch.nn.Parameter(w.to(d))
+    bg2 = torch.nn.Parameter(bv.to(d)) if bias else None
+    xg2, x2g2 = x.to(d, dt).requires_grad_(True), (x2.to(d, dt).requires_grad_(True) if C2 else None)
+    try:
+        _lib.lib().du_set_option(13, 2)
+        g2 = torch.autograd.grad(ops.conv2d(xg2, wg2, bg2, 1, 1, x2g2), (wg2, bg2) if bias else (wg2,), go.to(d, dt))
+    finally:
+        _lib.lib().du_set_option(13, 1)
+    if C1 % 32 == 0 and C2 % 32 == 0 and H % 8 == 0 and W % 16 == 0:
+        assert ops.WGRAD.queued == n0 + 1                       # not queued: computed at once by du_conv3x3_wgrad_halo
+    assert rel(g2[0].flatten(1), gr[0].float().flatten(1)) < 2e-5
+    if bias:
+        assert rel(g2[1], gr[1].float()) < 2e-5
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -1257,7 +1272,10 @@ def test_conv3x3_halo_kernel_fwd_bwd_stats(B, H, W, C1, C2, Cout):
 
 @pytest.mark.parametrize("B,H,W,C1,C2,Cout", [(1, 8, 16, 32, 0, 32), (1, 8, 32, 64, 0, 64), (3, 40, 80, 96, 0, 32), (2, 24, 16, 32, 32, 64),
                                               (5, 64, 64, 64, 64, 64), (2, 16, 48, 64, 0, 32), (7, 8, 16, 32, 0, 64), (2, 128, 256, 64, 0, 64),
-                                              (4, 264, 272, 32, 0, 32)])
+                                              (4, 264, 272, 32, 0, 32),
+                                              # round 6: 128 output channels (the first decoder stage): one 32-output block per wave, 4 and 8 input chunks,
+                                              # the fused concat, more tiles than the 128 workgroups
+                                              (1, 8, 16, 128, 0, 128), (2, 64, 64, 128, 128, 128), (3, 128, 128, 128, 0, 128), (1, 16, 32, 96, 32, 128)])
 @pytest.mark.parametrize("with_db", [False, True])
 def test_conv3x3_weight_gradient_rows_kernel(B, H, W, C1, C2, Cout, with_db):
     """The round-5 3 x 3 weight-gradient kernel (conv3x3_wgrad_rows_kernel: a wave owns all 9 taps of a 32 x 32 channel block pair, the
@@ -1278,8 +1296,9 @@ def test_conv3x3_weight_gradient_rows_kernel(B, H, W, C1, C2, Cout, with_db):
     ref_db = go.float().sum((0, 1, 2))
     L = _lib.lib()
     outs = {}
+    modes = (2,) if Cout == 128 else (2, 0)        # (the round-3 kernel does not serve 128 outputs)
     try:
-        for mode in (1, 0):
+        for mode in modes:
             L.du_set_option(13, mode)
             r = ops.conv3x3_wgrad_halo(x.to(d, dt), go.to(d, dt), x2.to(d, dt) if C2 else None, with_db=with_db)
             assert r is not None
@@ -1289,7 +1308,7 @@ def test_conv3x3_weight_gradient_rows_kernel(B, H, W, C1, C2, Cout, with_db):
     finally:
         L.du_set_option(13, 1)
     scale = float(ref.abs().max())
-    for mode in (1, 0):
+    for mode in modes:
         assert float((outs[mode][0].cpu() - ref).abs().max()) / scale < 2e-5, mode       # fp32 accumulation of exact bf16 products
         if with_db:
             assert float((outs[mode][1].cpu() - ref_db).abs().max()) / float(ref_db.abs().max()) < 1e-5, mode
