@@ -68,9 +68,9 @@ class MSDeformAttn(nn.Module):
         M, P = self.n_heads, self.n_points
         value = ops.linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         value = value.view(N, S, M, value.shape[-1] // M)
-        raw = ops.linear_cat(query, self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias,
-                             self.attention_weights.bias, out_dtype=torch.float32).view(N * Lq, M * P * 3)   # MSA:188-189, fp32 (MSA:30)
-        loc, attn = ops.msda_prep(raw, reference_points, Lq, M, P, Hs, Ws)                   # MSA:190-197
+        # MSA:188-197: offsets | weights product (fp32, MSA:30) + reference-point / softmax step as one autograd node (ops._OffsetsPrep)
+        loc, attn = ops.offsets_prep(query, self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias,
+                                     self.attention_weights.bias, reference_points, Lq, M, P, Hs, Ws)
         shapes, lsi = _level_tensors(Hs, Ws, query.device)   # cached: no host->device copy (sync) per call
         out = ops.msda(value, shapes, lsi, loc.view(N, Lq, M, 1, P, 2), attn.view(N, Lq, M, 1, P))   # MSA:207-214
         return ops.linear(out, self.output_proj.weight, self.output_proj.bias, residual=residual)

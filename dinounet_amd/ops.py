@@ -1277,45 +1277,59 @@ class _LinearCat(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, w2, b1, b2, out_dtype):
-        n1 = w1.shape[0]
-        wq = PACK.get((w1.reshape(n1, -1), w2.reshape(w2.shape[0], -1)), PK_CAST, x.dtype)
-        if wq is None:
-            wq = torch.cat([w1.reshape(n1, -1), w2.reshape(w2.shape[0], -1)], 0).to(x.dtype)
-        bq = None
-        if b1 is not None:
-            bq = PACK.get((b1, b2), PK_CAST, torch.float32)
-            if bq is None:
-                bq = torch.cat([b1, b2], 0).float()
-        y = mm(x, wq, bias=bq, out_dtype=out_dtype)
-        # [w1; w2]^T from the weight pack: the data gradient becomes a contraction-contiguous product (see _Linear)
-        ctx.wT = None
-        if _DGRAD_NT and w1.dtype != x.dtype and (n1 + w2.shape[0]) % 64 == 0:
-            ctx.wT = PACK.get((w1.reshape(n1, -1), w2.reshape(w2.shape[0], -1)), PK_TRANSPOSE, x.dtype)
-        ctx.save_for_backward(x, wq)
-        ctx.conf = (n1, tuple(w1.shape), tuple(w2.shape), b1 is not None)
-        ctx.wrefs = WGRAD.note_use(*([w1, w2] if b1 is None else [w1, w2, b1, b2]))
+        y = _linear_cat_fwd(ctx, x, w1, w2, b1, b2, out_dtype)
+        ctx.save_for_backward(*ctx.lc_saved)
+        ctx.lc_saved = None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wq = ctx.saved_tensors
-        n1, s1, s2, has_bias = ctx.conf
+        x = ctx.saved_tensors[0]
         dyc = dy if dy.stride(1) == 1 else dy.contiguous()
         if dyc.dtype != x.dtype:
             dyc = cast(dyc, x.dtype)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = mm(dyc, ctx.wT) if ctx.wT is not None else mm_dgrad(dyc, wq)
-        db1 = db2 = None
-        grp = WGRAD.begin(ctx.wrefs)
-        if has_bias:
-            dw, db = mm_wgrad(dyc, x, with_colsum=True, defer=grp)
-            db1, db2 = db[:n1], db[n1:]
-        else:
-            dw = mm_wgrad(dyc, x, defer=grp)
-        if grp is not None and not grp["ret"]:
-            return dx, None, None, None, None, None
-        return dx, dw[:n1].view(s1), dw[n1:].view(s2), db1, db2, None
+        return (*_linear_cat_bwd(ctx, dyc), None)
+
+
+def _linear_cat_fwd(ctx, x, w1, w2, b1, b2, out_dtype):
+    n1 = w1.shape[0]
+    wq = PACK.get((w1.reshape(n1, -1), w2.reshape(w2.shape[0], -1)), PK_CAST, x.dtype)
+    if wq is None:
+        wq = torch.cat([w1.reshape(n1, -1), w2.reshape(w2.shape[0], -1)], 0).to(x.dtype)
+    bq = None
+    if b1 is not None:
+        bq = PACK.get((b1, b2), PK_CAST, torch.float32)
+        if bq is None:
+            bq = torch.cat([b1, b2], 0).float()
+    y = mm(x, wq, bias=bq, out_dtype=out_dtype)
+    # [w1; w2]^T from the weight pack: the data gradient becomes a contraction-contiguous product (see _Linear)
+    ctx.wT = None
+    if _DGRAD_NT and w1.dtype != x.dtype and (n1 + w2.shape[0]) % 64 == 0:
+        ctx.wT = PACK.get((w1.reshape(n1, -1), w2.reshape(w2.shape[0], -1)), PK_TRANSPOSE, x.dtype)
+    ctx.lc_saved = (x, wq)
+    ctx.conf = (n1, tuple(w1.shape), tuple(w2.shape), b1 is not None)
+    ctx.wrefs = WGRAD.note_use(*([w1, w2] if b1 is None else [w1, w2, b1, b2]))
+    return y
+
+
+def _linear_cat_bwd(ctx, dyc, x=None, wq=None):
+    """-> (dx, dw1, dw2, db1, db2) for dyc in the GEMM dtype"""
+    if x is None:
+        x, wq = ctx.saved_tensors[:2]
+    n1, s1, s2, has_bias = ctx.conf
+    dx = None
+    if ctx.needs_input_grad[0]:
+        dx = mm(dyc, ctx.wT) if ctx.wT is not None else mm_dgrad(dyc, wq)
+    db1 = db2 = None
+    grp = WGRAD.begin(ctx.wrefs)
+    if has_bias:
+        dw, db = mm_wgrad(dyc, x, with_colsum=True, defer=grp)
+        db1, db2 = db[:n1], db[n1:]
+    else:
+        dw = mm_wgrad(dyc, x, defer=grp)
+    if grp is not None and not grp["ret"]:
+        return dx, None, None, None, None
+    return dx, dw[:n1].view(s1), dw[n1:].view(s2), db1, db2
 
 
 def linear_cat(x, w1, w2, b1=None, b2=None, out_dtype=None):
@@ -1875,6 +1889,44 @@ class _MSDAPrep(torch.autograd.Function):
 
 def msda_prep(raw, ref, Lq, M, P, Hs, Ws):
     return _MSDAPrep.apply(raw, ref, Lq, M, P, Hs, Ws)
+
+
+class _OffsetsPrep(torch.autograd.Function):
+    """MSDeformAttn's sampling_offsets + attention_weights product (ms_deform_attn.py:188-189, fp32 result as the reference's
+    custom_fwd(cast_inputs=fp32), :30) and msda_prep (:190-197) as ONE autograd node: the fp32 (rows, M*P*3) matrix is an internal buffer,
+    so its gradient can be written by du_msda_prep_bwd directly in the GEMM dtype -- as two nodes autograd demands an fp32 gradient for
+    the fp32 tensor, i.e. a 33 MB fp32 write plus a cast pass per extractor and step (6 x 17 us, the `cast_kernel<float, bf16>` line of the
+    round-5 trace)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, b1, b2, ref, Lq, M, P, Hs, Ws):
+        raw = _linear_cat_fwd(ctx, x, w1, w2, b1, b2, torch.float32)
+        rows, ncol, ld = _rows2d(raw)
+        assert ncol == M * P * 3
+        loc = torch.empty((rows, M, P, 2), dtype=torch.float32, device=raw.device)
+        attn = torch.empty((rows, M, P), dtype=torch.float32, device=raw.device)
+        _lib.check(_lib.lib().du_msda_prep(_code(raw.dtype), _p(raw), ld, _p(ref), _p(loc), _p(attn), rows, Lq, M, P, Hs, Ws, _st()),
+                   "du_msda_prep")
+        xs, wq = ctx.lc_saved
+        ctx.lc_saved = None
+        ctx.save_for_backward(xs, wq, attn)
+        ctx.prep = (M, P, Hs, Ws, ncol)
+        return loc, attn
+
+    @staticmethod
+    def backward(ctx, gloc, gattn):
+        x, wq, attn = ctx.saved_tensors
+        M, P, Hs, Ws, ncol = ctx.prep
+        rows = attn.shape[0]
+        graw = torch.empty((rows, ncol), dtype=x.dtype, device=attn.device)
+        _lib.check(_lib.lib().du_msda_prep_bwd(_code(x.dtype), _p(attn), _p(gloc.contiguous()), _p(gattn.contiguous()), _p(graw), ncol, rows,
+                                               M, P, Hs, Ws, _st()), "du_msda_prep_bwd")
+        return (*_linear_cat_bwd(ctx, graw, x, wq), None, None, None, None, None, None)
+
+
+def offsets_prep(x, w1, w2, b1, b2, ref, Lq, M, P, Hs, Ws):
+    """(N, Lq, C) queries -> sampling locations (N*Lq, M, P, 2) and softmaxed attention weights (N*Lq, M, P), fp32."""
+    return _OffsetsPrep.apply(x.reshape(-1, x.shape[-1]), w1, w2, b1, b2, ref, Lq, M, P, Hs, Ws)
 
 
 # ----------------------------------------------------------------------------------------------------

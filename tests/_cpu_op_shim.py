@@ -141,6 +141,11 @@ def msda_prep(raw, ref, Lq, M, P, Hs, Ws):
     return loc, F.softmax(logit, -1)
 
 
+def offsets_prep(x, w1, w2, b1, b2, ref, Lq, M, P, Hs, Ws):
+    raw = linear_cat(x.reshape(-1, x.shape[-1]), w1, w2, b1, b2, out_dtype=torch.float32)
+    return msda_prep(raw, ref, Lq, M, P, Hs, Ws)
+
+
 def msda(value, shapes, lsi, loc, attn):
     from oracle.dinounet_oracle import msda_core
     return msda_core(value.float(), shapes.tolist(), loc.float(), attn.float()).to(value.dtype)
@@ -281,7 +286,7 @@ def sync_bn_multi(xs, bns, act, group):
                               act, group) for x, bn in zip(xs, bns)]
 
 
-_NAMES = ["mm_swiglu", "sample_gather", "sample_scatter_", "sync_bn_multi", "mm", "linear", "linear_cat", "conv1x1_cat", "fapm_project", "conv1x1", "conv2d", "conv2d_stats", "conv_transpose2x2", "norm_act", "layer_norm", "layer_norm_res", "layernorm_raw", "msda_prep", "msda",
+_NAMES = ["mm_swiglu", "sample_gather", "sample_scatter_", "sync_bn_multi", "mm", "linear", "linear_cat", "conv1x1_cat", "fapm_project", "conv1x1", "conv2d", "conv2d_stats", "conv_transpose2x2", "norm_act", "layer_norm", "layer_norm_res", "layernorm_raw", "msda_prep", "offsets_prep", "msda",
           "dwconv3x3", "dwconv_tokens", "maxpool3x3s2", "bilinear_add", "bilinear_resize", "squeeze_excite", "nchw_to_nhwc", "nhwc_to_nchw_f32", "patchify16", "cast",
           "attention", "qkv_attention"]
 

@@ -918,6 +918,35 @@ def test_msda_bf16_grad_value_skips_only_blocks_that_cannot_reach_a_tile(N, Hs, 
     assert bool((gv.float().cpu()[gvr == 0] == 0).all())
 
 
+def test_offsets_and_prep_as_one_autograd_node_match_the_two_node_form():
+    """Round 6: ops.offsets_prep (the offsets | weights product + msda_prep in ONE node, the fp32 matrix between them internal, its gradient
+    written in bf16 by du_msda_prep_bwd) against ops.linear_cat(out_dtype=fp32) + ops.msda_prep: same forward bits, gradients equal to the
+    rounding of one bf16 cast (the two-node form casts the fp32 gradient, the fused one rounds inside the kernel: the same values)."""
+    from dinounet_amd import ops
+    d = dev()
+    bf = torch.bfloat16
+    N, Lq, Cc, M, P = 2, 672, 256, 16, 4
+    x = q(gen(N, Lq, Cc, seed=1), bf).to(d, bf)
+    w1, w2 = gen(M * P * 2, Cc, seed=2, scale=0.05).to(d), gen(M * P, Cc, seed=3, scale=0.05).to(d)
+    b1, b2 = gen(M * P * 2, seed=4).to(d), gen(M * P, seed=5).to(d)
+    ref = torch.rand(Lq, 2, generator=torch.Generator().manual_seed(6)).to(d)
+    gl, ga = gen(N * Lq, M, P, 2, seed=7).to(d), gen(N * Lq, M, P, seed=8).to(d)
+    outs = []
+    for fused in (True, False):
+        xs = x.clone().requires_grad_(True)
+        ps = [t.clone().requires_grad_(True) for t in (w1, w2, b1, b2)]
+        if fused:
+            loc, at = ops.offsets_prep(xs, ps[0], ps[1], ps[2], ps[3], ref, Lq, M, P, 4, 8)
+        else:
+            raw = ops.linear_cat(xs, ps[0], ps[1], ps[2], ps[3], out_dtype=torch.float32).view(N * Lq, M * P * 3)
+            loc, at = ops.msda_prep(raw, ref, Lq, M, P, 4, 8)
+        g = torch.autograd.grad((loc * gl).sum() + (at * ga).sum(), [xs] + ps)
+        outs.append((loc.detach(), at.detach(), [t.float() for t in g]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert rel(a, b) < 1e-5, (a.shape, rel(a, b))
+
+
 def test_msda_prep_fwd_bwd():
     from dinounet_amd import ops
     d = dev()
