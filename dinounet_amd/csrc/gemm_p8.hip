@@ -391,14 +391,31 @@ constexpr int P8_LDS = 256 * P8_STG_LDB * 2;   // 135 168 B >= 2 * BUF_B and >= 
 // dispatched when the first tiles retire and overlap the stragglers; as launches of their own the 40-row tails cost ~8 us each, 72 of
 // them per dinounet_l step (profiles/r02_launch_counts_v5.txt).
 template <typename TC, int NW = 8>
-__device__ __forceinline__ void p8_tail(const GemmParams& P, unsigned char* smem) {
+__device__ __forceinline__ void p8_tail(const GemmParams& P, unsigned char* smem, int unit = -1) {
   SkinnyEpi E;
   E.C = (TC*)P.C + (long)P.M * P.ldc; E.ldc = P.ldc;
   E.residual = P.residual ? (const void*)((const TC*)P.residual + (long)P.M * P.ldr) : nullptr; E.ldr = P.ldr;
   E.bias = P.bias; E.gamma = P.gamma; E.row_scale = P.row_scale;
   E.alpha = P.alpha; E.act = P.act; E.rs_rows = P.rs_rows; E.out_bf16 = sizeof(TC) == 2; E.row0 = P.M;
   skinny_fused_body<NW>((const bf16_t*)P.a.p + (long)P.M * P.a.ld, P.a.ld, (const bf16_t*)P.b.p, P.b.ld, P.tail_rows, P.N, P.K, E, (float*)smem,
-                       (int)blockIdx.x - P.main_wgs);
+                       unit >= 0 ? unit : (int)blockIdx.x - P.main_wgs);
+}
+
+// Round 6: the ragged rows INSIDE the tile workgroups.  As extra workgroups behind the tiles (round 3) the tail units share the launch's
+// dynamic LDS size (135-149 KB), so none of them is resident beside a tile workgroup: they are dispatched when the tiles retire and the
+// launch ends with a round of its own -- 6.4-6.6 us per ViT product for ~2 us of work.  Here the workgroups that have
+// finished their tiles run the units themselves (unit = 32 output columns x the whole contraction, workgroup w takes units w, w + G, ...):
+// no dispatch, no second round.  The grid then has no extra workgroups: tail_rows > 0 and gridDim.x == main_wgs.
+template <typename TC, int NW = 8>
+__device__ __forceinline__ void p8_tail_inline(const GemmParams& P, unsigned char* smem, int w, int G) {
+  const int nunits = (P.N + SK_BN - 1) / SK_BN;
+  if (w >= nunits) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing of the tile program may still land in LDS (out-of-range ring requests write zeros)
+  __syncthreads();
+  for (int u = w; u < nunits; u += G) {
+    p8_tail<TC, NW>(P, smem, u);
+    __syncthreads();
+  }
 }
 
 // workgroup -> XCD-contiguous linear index: the hardware places workgroup b on XCD b % 8; an XCD then owns a contiguous run of indices
@@ -906,6 +923,9 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
     if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<TC>(P, smem); return; }
   }
   p8_tile_body<TC, SCHED, TN, GA>(P, smem, TN ? xcd_linear_index() : 0);
+  if constexpr (!TN && !GA) {
+    if (P.tail_rows && (int)gridDim.x == P.main_wgs && gridDim.y == 1) p8_tail_inline<TC>(P, smem, (int)blockIdx.x, P.main_wgs);
+  }
 }
 
 // ---- grouped weight gradients: several dW = dY^T X products in ONE launch (du_gemm_tn_group) ----------------------------------------
@@ -981,9 +1001,18 @@ constexpr int N_STG_LDF = NBN + 4;             // 528 B rows
 constexpr int P8N_LDS = 3 * NBUF_B;            // 147 456 B >= 256 * N_STG_LDF * 4 = 135 168
 
 template <typename TC, int SCHED>
+__device__ __forceinline__ void p8n_tile_body(const GemmParams& P, unsigned char* smem);
+
+template <typename TC, int SCHED>
 __global__ __launch_bounds__(512) void gemm_nt_p8n_kernel(GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<TC>(P, smem); return; }
+  p8n_tile_body<TC, SCHED>(P, smem);
+  if (P.tail_rows && (int)gridDim.x == P.main_wgs && gridDim.y == 1) p8_tail_inline<TC>(P, smem, (int)blockIdx.x, P.main_wgs);
+}
+
+template <typename TC, int SCHED>
+__device__ __forceinline__ void p8n_tile_body(const GemmParams& P, unsigned char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -1888,6 +1917,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   };
   last(IC<0>{}); last(IC<1>{}); last(IC<2>{}); last(IC<3>{}); last(IC<4>{}); last(IC<5>{}); last(IC<6>{}); last(IC<7>{});
   last(IC<8>{}); last(IC<9>{}); last(IC<10>{}); last(IC<11>{}); last(IC<12>{}); last(IC<13>{}); last(IC<14>{}); last(IC<15>{});
+  if (P.tail_rows && (int)gridDim.x == G) p8_tail_inline<bf16_t>(P, smem, lin, G);     // the ragged rows: units lin, lin + G, ... (round 6)
 }
 
 int g_p8_mode = -1;      // -1: heuristic, 0: off, 1: 256 x 256 wherever legal, 2: 256 x 128 wherever legal, 3: the 4-wave 256 x 128 kernel wherever legal
@@ -1897,6 +1927,8 @@ int g_p8_corun = 1;      // du_set_option key 9: independent products the caller
                          // alone is a full round beside its twin
 int g_p8_persist = 1;    // du_set_option key 10: 0 = never, 1 = the persistent 256 x 128 kernel where its epilogue / shape rules hold and a CU gets
                          // >= 2 tiles (default), 2 = wherever legal
+int g_p8_tail_inline = 1; // du_set_option key 15: the ragged rows behind the last full tile row run inside the tile workgroups (1, round 6) or as extra
+                         // workgroups behind them (0, round 3)
 int g_p8_res = 1;        // du_set_option key 14 (A-B aid): 0 = products with a bf16 residual stay on the one-shot kernels (round 5)
 int g_p8_pp_full = 0;    // du_set_option key 11 (A-B aid): 1 = the persistent kernel always launches min(tiles, 256) workgroups, co-running or not
 int g_p8_group = 4;
@@ -1912,9 +1944,10 @@ int launch_p8(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
   P.group_m = g_p8_group;
   P.dbg = g_p8_debug;
   dim3 grid(P.tiles_m * P.tiles_n, a.batch < 1 ? 1 : a.batch);
-  if (tail_rows > 0 && !GA) {       // the ragged rows behind M ride along: one extra workgroup per 32 output columns
+  if (tail_rows > 0 && !GA) {       // the ragged rows behind M ride along: inside the tile workgroups (round 6), or one extra workgroup per 32 output columns
     P.tail_rows = tail_rows; P.main_wgs = P.tiles_m * P.tiles_n;
-    grid.x += (a.N + SK_BN - 1) / SK_BN;
+    // (inline only when the tiles fill the chip: with idle CUs -- 128 tiles of 256 x 256 -- the extra workgroups run beside the tiles for free)
+    if (!(g_p8_tail_inline && grid.y == 1 && (long)grid.x * g_p8_corun >= 256)) grid.x += (a.N + SK_BN - 1) / SK_BN;
   }
   void (*kfn)(GemmParams);
   if constexpr (NARROW) kfn = gemm_nt_p8n_kernel<TC, SCHED>; else kfn = gemm_nt_p8_kernel<TC, SCHED, false, GA>;
@@ -1939,7 +1972,7 @@ int launch_pp(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
   dim3 grid(P.main_wgs, 1);
   if (tail_rows > 0) {
     P.tail_rows = tail_rows;
-    grid.x += (a.N + SK_BN - 1) / SK_BN;
+    if (!g_p8_tail_inline) grid.x += (a.N + SK_BN - 1) / SK_BN;
   }
   const bool nk4 = a.K == 256;
   const int res = a.residual ? (a.row_scale ? 2 : 1) : 0;       // the residual as two more K-steps (+ DropPath's per-sample scale)
@@ -2027,6 +2060,7 @@ extern "C" int du_set_option(int key, int value) {
     case 12: g_rk_mode = value; return DU_OK;
     case 13: g_wgrad_rows = value; return DU_OK;
     case 14: g_p8_res = value; return DU_OK;
+    case 15: g_p8_tail_inline = value; return DU_OK;
     default: return DU_ERR_BAD_ARG;
   }
 }

@@ -36,7 +36,7 @@ __device__ __forceinline__ void skinny_fused_body(const bf16_t* __restrict__ A, 
   // the launch otherwise hits the same few memory channels at the same time (32 rows at ONE column offset per load, all workgroups in step)
   const int nchunk = K / SK_CHUNK;
   const int rot = (int)((blk * 5u) % (unsigned)nchunk);
-#pragma unroll 2
+#pragma unroll 4
   for (int ci = wave; ci < nchunk; ci += NW) {
     int cc = ci + rot; if (cc >= nchunk) cc -= nchunk;
     const int k = cc * SK_CHUNK;
