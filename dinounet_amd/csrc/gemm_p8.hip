@@ -1927,8 +1927,9 @@ int g_p8_corun = 1;      // du_set_option key 9: independent products the caller
                          // alone is a full round beside its twin
 int g_p8_persist = 1;    // du_set_option key 10: 0 = never, 1 = the persistent 256 x 128 kernel where its epilogue / shape rules hold and a CU gets
                          // >= 2 tiles (default), 2 = wherever legal
-int g_p8_tail_inline = 1; // du_set_option key 15: the ragged rows behind the last full tile row run inside the tile workgroups (1, round 6) or as extra
-                         // workgroups behind them (0, round 3)
+int g_p8_tail_inline = 0; // du_set_option key 15: the ragged rows behind the last full tile row run as extra workgroups behind the tiles (0, round 3,
+                         // default) or inside the tile workgroups (1, round 6: 1-1.4 us faster per ViT product alone, but x0.998 in the replayed
+                         // step against the extra workgroups, profiles/r06_ab_tail_inline_v2.txt -- opt-in)
 int g_p8_res = 1;        // du_set_option key 14 (A-B aid): 0 = products with a bf16 residual stay on the one-shot kernels (round 5)
 int g_p8_pp_full = 0;    // du_set_option key 11 (A-B aid): 1 = the persistent kernel always launches min(tiles, 256) workgroups, co-running or not
 int g_p8_group = 4;

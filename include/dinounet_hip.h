@@ -455,8 +455,8 @@ int du_device_ok(void); /* 1 if the current device is gfx950 */
    key 12: the resident-weights streaming kernel for K <= 256 (csrc/gemm_rk.hip): 1 = K <= 192 (default), 2 = K = 256 too, 0 = never;
    key 13: 3 x 3 weight gradients (du_conv3x3_wgrad_halo): 1 = the round-5 kernel for 32 / 64 output channels (default), 2 = for 128 too,
            0 = the round-3 one;
-   key 15: the <= 64 ragged rows behind the last full 256-row tile of a tall NT product (the ViT: M = 8 x 1029): 1 = computed by the tile
-           workgroups themselves once their tiles are done (default), 0 = by extra workgroups behind the tile grid (round 3);
+   key 15: the <= 64 ragged rows behind the last full 256-row tile of a tall NT product (the ViT: M = 8 x 1029): 0 = by extra workgroups
+           behind the tile grid (default), 1 = by the tile workgroups themselves once their tiles are done;
    key 14: bf16 products with a bf16 residual on the persistent kernel (the residual as two more K-steps): 1 (default), 0 = one-shot kernels;
    key 9: number of independent products the caller keeps in flight on DIFFERENT streams (default 1; dinounet_amd runs the frozen ViT as
           two half-batch chains): du_gemm's tile choice then counts workgroup rounds on 256 / value CUs. */

@@ -161,8 +161,9 @@ def test_gemm_multiphase_nt(mode, M, N, K, f32out, epi):
         assert torch.equal(outs[0], ref2)
 
 
+@pytest.mark.parametrize("inline", [0, 1])
 @pytest.mark.parametrize("N,K", [(1024, 1024), (3072, 1024), (1024, 4096)])
-def test_gemm_ragged_tail_split(N, K):
+def test_gemm_ragged_tail_split(N, K, inline):
     """The ViT-L products (M = 8 * 1029 = 64 * 128 + 40): for proj / fc2 the last 40 rows leave the tile grid and run on the K-parallel
     skinny kernels (gemm_skinny.hip); every epilogue, against the fp32 product."""
     import ctypes
@@ -170,6 +171,14 @@ def test_gemm_ragged_tail_split(N, K):
     from dinounet_amd._lib import ACT_GELU
     d = dev()
     M, bf = 8232, torch.bfloat16
+    _lib.lib().du_set_option(15, inline)        # round 6: the tail units inside the tile workgroups (1) or as extra workgroups (0, default)
+    try:
+        _ragged_tail_body(N, K, M, bf, d, ops, _lib, ACT_GELU, ctypes)
+    finally:
+        _lib.lib().du_set_option(15, 0)
+
+
+def _ragged_tail_body(N, K, M, bf, d, ops, _lib, ACT_GELU, ctypes):
     x, w = q(gen(M, K, seed=1), bf).to(d, bf), q(gen(N, K, seed=2, scale=K ** -0.5), bf).to(d, bf)
     b, gam, res = gen(N, seed=3).to(d), gen(N, seed=4).to(d), gen(M, N, seed=5).to(d)
     rs = (torch.arange(1029, device=d) % 3 != 0).float() * 1.5          # one scale per 8 rows: the split keeps the row blocks aligned
