@@ -27,7 +27,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: dense
 HBM_PEAK_GBS = 8000.0
 MFMA_BF16_MEASURED_TFLOPS = 2382.0   # same guide: micro-benchmark ceiling of v_mfma_f32_32x32x16_bf16
 HBM_MEASURED_GBS = 6290.0            # same guide: float4 copy
-PMC_ROUNDS = ("r05", "r04", "r03", "r02")           # profiles/<round>_pmc_*: counter summaries, newest first; only one measured on the built kernel sources is used
+PMC_ROUNDS = ("r06", "r05", "r04", "r03", "r02")           # profiles/<round>_pmc_*: counter summaries, newest first; only one measured on the built kernel sources is used
 
 
 def _pmc_file(stem):

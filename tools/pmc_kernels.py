@@ -9,7 +9,7 @@ MI355X_MICROARCH.md "rocprofv3 PMC slots") over `bench.py --graph off --steps 2 
 
 Counters the installed rocprofv3 does not list (`rocprofv3 -L`) are dropped from a pass instead of failing it.  Derived columns (see render()): the wave view -- parked / stalled / issuing shares of the waves' lifetime -- and the SIMD view -- duty of
 the matrix pipe, the VALU, LDS and VMEM issue ports over the launch -- plus LDS bank-conflict cycles per LDS-array cycle.
-Run ON THE GPU BOX:  python tools/pmc_kernels.py   -> gpurun_out/r05_pmc_sq_cycles_eager.txt (copy into profiles/);
+Run ON THE GPU BOX:  python tools/pmc_kernels.py   -> gpurun_out/r06_pmc_sq_cycles_eager.txt (copy into profiles/);
 re-render an earlier output without a GPU:  python tools/pmc_kernels.py --from-raw <file>."""
 import glob
 import os
@@ -139,7 +139,7 @@ def from_raw(path):
 def main():
     outdir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(outdir, exist_ok=True)
-    path = os.path.join(outdir, "r05_pmc_sq_cycles_eager.txt")
+    path = os.path.join(outdir, "r06_pmc_sq_cycles_eager.txt")
     if len(sys.argv) > 2 and sys.argv[1] == "--from-raw":
         data, used = from_raw(sys.argv[2])
         render(data, used, 32, path)

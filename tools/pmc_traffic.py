@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Measure roofline.traffic for bench.py: two rocprofv3 PMC passes (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass) of
-`bench.py --graph off --steps 2 --warmup 1`, summarised per kernel into profiles/r05_pmc_{fetch,write}_size_eager.txt with the digest of
+`bench.py --graph off --steps 2 --warmup 1`, summarised per kernel into profiles/r06_pmc_{fetch,write}_size_eager.txt with the digest of
 the kernel sources they were measured on (bench.py ignores a summary whose digest differs from the library it runs).
 Run ON THE GPU BOX:  python tools/pmc_traffic.py   (writes under gpurun_out/, copy the two summaries into profiles/)."""
 import glob
@@ -40,8 +40,8 @@ def main():
         header = (f"# csrc-digest {digest}\n# git {sha}\n# rocprofv3 --pmc {counter} --kernel-trace -- python bench.py --graph off --steps 2 "
                   f"--warmup 1 --no-cpu-baseline --no-roofline   (mean counter value per launch, KB; FETCH_SIZE counts 128-B requests at "
                   f"64 B on gfx950: x2)\n")
-        summarise(db, counter, os.path.join(outdir, f"r05_pmc_{name}_size_eager.txt"), header)
-        print(open(os.path.join(outdir, f"r05_pmc_{name}_size_eager.txt")).read()[:1500])
+        summarise(db, counter, os.path.join(outdir, f"r06_pmc_{name}_size_eager.txt"), header)
+        print(open(os.path.join(outdir, f"r06_pmc_{name}_size_eager.txt")).read()[:1500])
 
 
 if __name__ == "__main__":
