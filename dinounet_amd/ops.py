@@ -228,11 +228,16 @@ def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat,
         kin = K if geom is None else K // max(geom.KH * geom.KW, 1) if a_mode == IM2COL_ROW else K
         # the library names the kernel family it ran for this product (du_gemm_route): no mirror of the C-side dispatch here
         kname = _ROUTE_NAMES[int(_lib.lib().du_gemm_route(C.byref(a)))]
-        tag = f"{kname}<{'bf16' if dtype == DU_BF16 else 'f32'},{_MODE_NAMES.get((a_mode, b_mode), 'other')}>"
+        mode = _MODE_NAMES.get((a_mode, b_mode), 'other')
+        if residual is not None and out_dtype == DU_BF16:
+            # products that add a bf16 residual (the adapter's output projection / ConvFFN fc2 / `up` + c1) are a family of their own: with
+            # the residual read they are HBM-bound (K = 256: 198 MB for 22.5 GFLOP), a different roofline than the plain NT products
+            mode += "+res"
+        tag = f"{kname}<{'bf16' if dtype == DU_BF16 else 'f32'},{mode}>"
         if PROFILE.detail:
             tag += f" M{M} N{N} K{K} b{batch} sk{split_k}" + (f" k{geom.KH}s{geom.stride}t{geom.transposed}" if geom is not None else "")
         PROFILE.stop(tag, e0,
-                     2.0 * M * N * K * batch, float(batch) * (M * kin * es + N * K * es + M * N * eo))
+                     2.0 * M * N * K * batch, float(batch) * (M * kin * es + N * K * es + M * N * eo * (2 if residual is not None else 1)))
         return
     _lib.check(_lib.lib().du_gemm(C.byref(a), _st()), "du_gemm")
 
