@@ -1516,11 +1516,26 @@ __device__ const PpIdent g_pp_ident{};
 // PS: the pixel-shuffle store of ConvTranspose2d k2 s2 (column n = (tap, co) of input pixel m = (b, y, x) -> output pixel (b, 2y + tap / 2,
 // 2x + tap % 2), channel co; ps_C % 128 == 0: a tile's 128 columns lie in one tap; ps_H, ps_W powers of two), with the residual read through
 // the same mapping -- the adapter's `up` + c1 (dinov3_adapter.py:360,467), 32768 x 4096 x 1024: 428 us on the one-shot 256 x 256 kernel.
-template <int ACT, bool NK4, int RES = 0, bool PS = false>
+// ROPE (round 6): the ViT's qkv projection stored head-major with RoPE applied in the drain (DU_STORE_QKV_ROPE, layers/attention.py:66-85):
+// a wave's 64 columns are one (q | k | v, head); the rotate-half partners d and d + 32 are the SAME accumulator register of column blocks
+// c = 0 and c = 1, so a drain phase takes group g of BOTH blocks, rotates in fp32 and packs; the sin / cos of (token, d) come from a
+// FACTORISED table in LDS -- the angle of dimension d is (row coordinate) / period_j for d % 32 < 16 and (column coordinate) / period_j
+// above (rope_position_encoding.py:98-104, tiled twice), so 2 x (H_t + 1) x 16 (cos, sin) pairs = 8.4 KB replace the (H_t W_t) x 64 tables;
+// the extra row is the identity rotation (prefix tokens, v).  The quads are fetched one phase ahead beside the bias quads.  q is scaled
+// by rope_qscale.  With this the 50 MB qkv matrix and the pass that re-read it (qkv_rope_split_kernel, 21 us per block) do not exist.
+constexpr int PP_ROPE_OFF = PP_BIAS_OFF + 2048;           // the factorised table behind the bias slots: [axis][33 positions][cos 16 | sin 16] fp32
+constexpr int PP_ROPE_ROWS = 33;
+constexpr int PP_LDS_ROPE = PP_ROPE_OFF + 2 * PP_ROPE_ROWS * 128;
+__device__ __forceinline__ void pp_wait_lds4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+}
+
+template <int ACT, bool NK4, int RES = 0, bool PS = false, bool ROPE = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<bf16_t>(P, smem); return; }
   static_assert(RES == 0 || ACT == DU_ACT_NONE, "the residual form has no activation");
+  static_assert(!ROPE || (ACT == DU_ACT_NONE && !NK4 && RES == 0 && !PS), "the RoPE drain: plain bias epilogue, K >= 384");
   constexpr bool FOUR = NK4 && RES == 0;          // the four-K-step tile form (K = 256 without a residual); with one the tile is six K-steps
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1552,7 +1567,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)P.b.p, 0, (int)((((long)P.N - 1) * P.b.ld + P.K) * 2), 0x00020000);
   const long out_rows = PS ? 4L * P.M : (long)P.M;           // rows (pixels) of C and of the residual
   const int out_cols = PS ? P.ps_C : P.N;
-  const auto rc = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, (int)(((out_rows - 1) * P.ldc + out_cols) * 2), 0x00020000);
+  const auto rc = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, ROPE ? (int)(3 * P.ldc * 2) : (int)(((out_rows - 1) * P.ldc + out_cols) * 2), 0x00020000);
   const int ps_lw = PS ? __builtin_ctz(P.ps_W) : 0, ps_lh = PS ? __builtin_ctz(P.ps_H) : 0;
   // PS: output pixel (before the tap's shift) of input pixel m, as a row index of C / the residual
   auto ps_pixel = [&](unsigned m) -> unsigned {
@@ -1579,6 +1594,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   unsigned va_s[2][2], vb_s[2];   // ... of the tile being STAGED, out of range for rows past M / N and past the last tile
   unsigned sa_base = 0, sb_base = 0, sr_base = 0;
   unsigned sm0 = 0;               // PS: first row of the staged tile (the residual's lane offsets are absolute output pixels)
+  unsigned sn0 = 0;               // ROPE: (sm0, sn0) = first row / column of the staged tile, 0x7fffffff behind the last tile
   // the tile whose K-tiles are requested from now on; its bias slice -> LDS slot `slot` (waves 0 / 1, one 4-byte LDS-DMA each)
   auto set_stage_tile = [&](int tile, int slot) {
     if (tile < ntiles) {
@@ -1586,9 +1602,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
       coords(tile, m0, n0);
 #pragma unroll
       for (int r = 0; r < 2; r++) {
-        va_s[0][r] = m0 + srow[r] < P.M ? va0[0][r] : PP_OOR;
-        va_s[1][r] = m0 + 128 + srow[r] < P.M ? va0[1][r] : PP_OOR;
-        vb_s[r] = n0 + srow[r] < P.N ? vb0[r] : PP_OOR;
+        if constexpr (ROPE) {      // (this form has no registers for the six lane offsets: `stage` recomputes them from the tile's scalars)
+          sm0 = (unsigned)m0; sn0 = (unsigned)n0;
+        } else {
+          va_s[0][r] = m0 + srow[r] < P.M ? va0[0][r] : PP_OOR;
+          va_s[1][r] = m0 + 128 + srow[r] < P.M ? va0[1][r] : PP_OOR;
+          vb_s[r] = n0 + srow[r] < P.N ? vb0[r] : PP_OOR;
+        }
       }
       sa_base = (unsigned)m0 * (unsigned)(P.a.ld * 2);
       sb_base = (unsigned)n0 * (unsigned)(P.b.ld * 2);
@@ -1611,6 +1631,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
     } else {
 #pragma unroll
       for (int r = 0; r < 2; r++) { va_s[0][r] = PP_OOR; va_s[1][r] = PP_OOR; vb_s[r] = PP_OOR; }
+      if constexpr (ROPE) { sm0 = 0x7fffffffu; sn0 = 0x7fffffffu; }
     }
   };
   // which: 0 = A-half0, 1 = A-half1, 2 = B of the staged tile's K-tile at byte offset kofs, into the buffer at byte offset bo.
@@ -1635,6 +1656,17 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_void*)dst, 16, vext, sr_base + kofs, 0, 0);
         } else {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (lds_void*)dst, 16, sr * 256u + (unsigned)lc * 16u, kofs, 0, 0);
+        }
+      } else if constexpr (ROPE) {
+        unsigned sr = (unsigned)srow[r];
+        asm volatile("" : "+v"(sr));
+        if constexpr (which < 2) {
+          const unsigned row = which * 128u + sr;
+          const unsigned vo = sm0 + row < (unsigned)P.M ? row * (unsigned)(P.a.ld * 2) + (unsigned)lc * 16u : PP_OOR;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, vo, sa_base + kofs, 0, 0);
+        } else {
+          const unsigned vo = sn0 + sr < (unsigned)P.N ? sr * (unsigned)(P.b.ld * 2) + (unsigned)lc * 16u : PP_OOR;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)dst, 16, vo, sb_base + kofs, 0, 0);
         }
       } else {
         if constexpr (which < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, va_s[which][r], sa_base + kofs, 0, 0);
@@ -1711,10 +1743,26 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   unsigned crow[2] = {PP_OOR, PP_OOR};   // byte offset of this lane's row of A half i, at its first column (wave's 64 + 8 hi), in C
   int pcol = 0;                   // that first column
   float rs_cur = 1.0f, rs_prev = 1.0f;   // RES == 2: DropPath scale of the tile being computed / drained (uniform: a tile lies inside one sample)
+  unsigned trow[2] = {0u, 0u};    // ROPE: this lane's rows' table positions, (row position) | (column position) << 8; 32 = the identity rotation
+  float qs_prev = 1.0f;           // ROPE: rope_qscale for a q tile, else 1
+  const unsigned rope_tbl = lds_base + PP_ROPE_OFF + (unsigned)(4 * hi * 4);     // this lane's corner (+ 4 hi entries) of a table row
   auto set_prev_tile = [&](int tile) {
     int m0, n0;
     coords(tile, m0, n0);
     pcol = n0 + wn * 64 + hi * 8;
+    if constexpr (ROPE) {
+      const int hd = P.ps_C * 64, which = n0 / hd, head = ((n0 - which * hd) >> 6) + wn;     // this wave's (q | k | v, head)
+      qs_prev = which == 0 ? P.rope_qscale : 1.0f;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int m = m0 + i * 128 + wm * 32 + (lane & 31);
+        const int b = m / P.ps_H, t = m - b * P.ps_H;
+        crow[i] = m < P.M ? (unsigned)(((long)which * P.ldc + (((long)b * P.ps_C + head) * P.ps_W + t) * 64 + hi * 4) * 2) : PP_OOR;
+        const int tt = t - P.rope_prefix, ty = tt / P.b.Wi, tx = tt - ty * P.b.Wi;
+        trow[i] = (which < 2 && tt >= 0 && m < P.M) ? (unsigned)ty | ((unsigned)tx << 8) : (32u | (32u << 8));
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int m = m0 + i * 128 + wm * 32 + (lane & 31);
@@ -1732,11 +1780,55 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   // ring once per phase.  The phase-end wait (lgkmcnt(0), naming the destinations so they stay opaque until then) retires the reads.
   f32x4 bqa = {0.f, 0.f, 0.f, 0.f}, bqb = {0.f, 0.f, 0.f, 0.f};     // bias of the next phase's first / second half
   unsigned keep0 = 0u, keep1 = 0u;                                  // packed group of the unit in progress (part 0)
+  f32x4 cq = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};       // ROPE: cos / sin of the next phase's group
   auto fetch = [&](auto h_c, f32x4& bq, unsigned base) {            // columns c*32 + 8 g + 4 hi + e of the image at `base`
     constexpr int h = decltype(h_c)::value;
     if constexpr (h >= 0) {
-      constexpr int u = h >> 1, c = (u >> 1) & 1, g = 2 * (u & 1) + (h & 1);
-      pp_lds_read1(bq, base + (unsigned)((c * 32 + 8 * g) * 4));
+      if constexpr (ROPE) {
+        // ROPE: half h = 2 ph + c: phase ph takes group g = ph & 3 of row block i = ph >> 2 for BOTH column blocks; with the c = 0 half the
+        // cos / sin quads of (row, dimensions 8 g + 4 hi .. + 3): axis = g >> 1, 16-entry table rows, j = (8 g) % 16 + 4 hi
+        constexpr int ph = h >> 1, c = h & 1, i = ph >> 2, g = ph & 3, axis = g >> 1;
+        pp_lds_read1(bq, base + (unsigned)((c * 32 + 8 * g) * 4));
+        if constexpr (c == 0) {
+          const unsigned pos = axis ? (trow[i] >> 8) : (trow[i] & 0xffu);
+          const unsigned ta = rope_tbl + (unsigned)(axis * PP_ROPE_ROWS * 128 + ((8 * g) & 15) * 4) + pos * 128u;
+          pp_lds_read1(cq, ta);
+          pp_lds_read1(sq, ta + 64u);
+        }
+      } else {
+        constexpr int u = h >> 1, c = (u >> 1) & 1, g = 2 * (u & 1) + (h & 1);
+        pp_lds_read1(bq, base + (unsigned)((c * 32 + 8 * g) * 4));
+      }
+    }
+  };
+  // ROPE: one phase = group g of both column blocks of row block i (bqa / bqb: their bias quads, cq / sq: the rotation, fp32 throughout)
+  auto rope_pair = [&](auto h_c) {
+    constexpr int h = decltype(h_c)::value;
+    if constexpr (h >= 0) {
+      constexpr int ph = h >> 1, i = ph >> 2, g = ph & 3, h2 = g >> 1;
+      const f32x16& a0 = prev[i][0];
+      const f32x16& a1 = prev[i][1];
+      unsigned pk[4];
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        const float ca = cq[e], sa = sq[e], cb = cq[e + 1], sb = sq[e + 1];
+        const float x1a = a0[4 * g + e] + bqa[e], x1b = a0[4 * g + e + 1] + bqa[e + 1];
+        const float x2a = a1[4 * g + e] + bqb[e], x2b = a1[4 * g + e + 1] + bqb[e + 1];
+        // layers/attention.py:16-27: x cos + rotate_half(x) sin, rotate_half = [-x2, x1]
+        const float o1a = (x1a * ca - x2a * sa) * qs_prev, o1b = (x1b * cb - x2b * sb) * qs_prev;
+        const float o2a = (x2a * ca + x1a * sa) * qs_prev, o2b = (x2b * cb + x1b * sb) * qs_prev;
+        const bf16x2 t1 = {(bf16_t)o1a, (bf16_t)o1b}, t2 = {(bf16_t)o2a, (bf16_t)o2b};
+        pk[e >> 1] = __builtin_bit_cast(unsigned, t1);
+        pk[2 + (e >> 1)] = __builtin_bit_cast(unsigned, t2);
+      }
+      // 8 bytes per lane (dimensions 8 g + 4 hi .. + 3 of this lane's row, a row's two lanes adjacent).  The 16-byte form of the plain
+      // drain (pairs kept across a phase + v_permlane32_swap) needs four more registers than this kernel has: it spills (104 B / lane)
+      (void)h2;
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+      const u32x2_t v0 = {pk[0], pk[1]}, v1 = {pk[2], pk[3]};
+      const unsigned off = nlim ? crow[i] + (unsigned)(8 * g * 2) : PP_OOR;
+      __builtin_amdgcn_raw_buffer_store_b64(v0, rc, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(v1, rc, off == PP_OOR ? PP_OOR : off + 64u, 0, 0);
     }
   };
   auto half = [&](auto h_c, const f32x4& bq) {
@@ -1773,7 +1865,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   auto finish6 = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    pp_wait_lds(bqa, bqb);
+    if constexpr (ROPE) pp_wait_lds4(bqa, bqb, cq, sq); else pp_wait_lds(bqa, bqb);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -1801,7 +1893,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
     if constexpr (decltype(cp1_c)::value) { prev[1][0] = acc[1][0]; prev[1][1] = acc[1][1]; }
     if constexpr (SC == 2) scale_acc(IC<1>{});
     mma(IC<0>{}, IC<p>{}, first_c);
-    half(ha0, bqa); half(hb0, bqb);
+    if constexpr (ROPE) rope_pair(ha0); else { half(ha0, bqa); half(hb0, bqb); }
     pin(IC<4>{}, IC<4>{});
     __builtin_amdgcn_sched_barrier(0);
     fetch(ha1, bqa, fbase); fetch(hb1, bqb, fbase);
@@ -1812,7 +1904,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
     if constexpr (decltype(cp0_c)::value) { prev[0][0] = acc[0][0]; prev[0][1] = acc[0][1]; }
     if constexpr (SC == 1) scale_acc(IC<0>{});
     mma(IC<1>{}, IC<p>{}, first_c);
-    half(ha1, bqa); half(hb1, bqb);
+    if constexpr (ROPE) rope_pair(ha1); else { half(ha1, bqa); half(hb1, bqb); }
     pin(IC<12>{}, IC<2>{});
     __builtin_amdgcn_sched_barrier(0);
     fetch(na, bqa, fbase2); fetch(nb, bqb, fbase2);      // (fbase2: the image the FOLLOWING K-step's halves belong to)
@@ -1834,6 +1926,22 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   // ---- this workgroup's first tile: the only prologue (K-tiles 0 and 1) ----
   int tile = lin;
   if (tile >= ntiles) return;
+  if constexpr (ROPE) {
+    // the factorised rotation table: row `pos` of axis 0 = dimensions 0..15 of token (pos, 0), of axis 1 = dimensions 16..31 of token
+    // (0, pos) -- the tables are separable by construction (rope_position_encoding.py:98-104) --, row 32 of either = the identity
+    float* tb = (float*)(smem + PP_ROPE_OFF);
+    for (int v = tid; v < 2 * PP_ROPE_ROWS * 32; v += 512) {
+      const int axis = v / (PP_ROPE_ROWS * 32), r = v - axis * (PP_ROPE_ROWS * 32), pos = r >> 5, e = r & 31, j = e & 15, is_sin = e >> 4;
+      float val = is_sin ? 0.f : 1.f;
+      const bool live = axis ? pos < P.b.Wi : pos < P.b.Hi;
+      if (live) {
+        const long tok = axis ? pos : (long)pos * P.b.Wi;
+        val = (is_sin ? P.rope_sin : P.rope_cos)[tok * 64 + axis * 16 + j];
+      }
+      tb[v] = val;
+    }
+    __syncthreads();
+  }
   set_stage_tile(tile, 0);
   stage(IC<0>{}, 0, 0u, F_{}); stage(IC<2>{}, 0, 0u, F_{}); stage(IC<1>{}, 0, 0u, F_{});
   stage(IC<0>{}, NBUF_B, 128u, F_{}); stage(IC<2>{}, NBUF_B, 128u, F_{}); stage(IC<1>{}, NBUF_B, 128u, F_{});
@@ -1894,10 +2002,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
       // bias of the first unit of THIS tile (its image: slot `slot`)
       set_stage_tile(next, slot ^ 1);
       pbias = bias_at(slot);
+      // (ROPE: the last phase below fetches the first rotation of THIS tile, which needs its rows' table positions -- the drain of the
+      //  previous tile ended with K-step 3, so its store offsets may be replaced here already)
+      if constexpr (ROPE) set_prev_tile(tile);
       kstep(IC<0>{}, F_{}, N_{}, N_{}, N_{}, N_{}, N_{}, N_{}, F_{}, F_{}, bc, bn, bnn, 0u, 0u, 0u, IC<2>{}, IC<0>{});
       kstep(IC<1>{}, F_{}, N_{}, N_{}, N_{}, N_{}, IC<0>{}, IC<1>{}, F_{}, T_{}, bn, bnn, bc, 128u, 0u, pbias, IC<0>{}, IC<0>{});
       rot2();
-      set_prev_tile(tile);
+      if constexpr (!ROPE) set_prev_tile(tile);
       rs_prev = rs_cur;
       slot ^= 1;
     }
@@ -1915,8 +2026,21 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (h & 1) { fetch(IC<(h + 1 < 16 ? h + 1 : -1)>{}, bqa, pbias); fetch(IC<(h + 2 < 16 ? h + 2 : -1)>{}, bqb, pbias); }
   };
-  last(IC<0>{}); last(IC<1>{}); last(IC<2>{}); last(IC<3>{}); last(IC<4>{}); last(IC<5>{}); last(IC<6>{}); last(IC<7>{});
-  last(IC<8>{}); last(IC<9>{}); last(IC<10>{}); last(IC<11>{}); last(IC<12>{}); last(IC<13>{}); last(IC<14>{}); last(IC<15>{});
+  auto last_pair = [&](auto ph_c) {    // ROPE: phase ph of the drain in the open, then the fetch of the next phase's quads
+    constexpr int ph = decltype(ph_c)::value;
+    pp_wait_lds4(bqa, bqb, cq, sq);
+    __builtin_amdgcn_sched_barrier(0);
+    rope_pair(IC<2 * ph>{});
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(IC<(ph + 1 < 8 ? 2 * ph + 2 : -1)>{}, bqa, pbias); fetch(IC<(ph + 1 < 8 ? 2 * ph + 3 : -1)>{}, bqb, pbias);
+  };
+  if constexpr (ROPE) {
+    last_pair(IC<0>{}); last_pair(IC<1>{}); last_pair(IC<2>{}); last_pair(IC<3>{});
+    last_pair(IC<4>{}); last_pair(IC<5>{}); last_pair(IC<6>{}); last_pair(IC<7>{});
+  } else {
+    last(IC<0>{}); last(IC<1>{}); last(IC<2>{}); last(IC<3>{}); last(IC<4>{}); last(IC<5>{}); last(IC<6>{}); last(IC<7>{});
+    last(IC<8>{}); last(IC<9>{}); last(IC<10>{}); last(IC<11>{}); last(IC<12>{}); last(IC<13>{}); last(IC<14>{}); last(IC<15>{});
+  }
   if (P.tail_rows && (int)gridDim.x == G) p8_tail_inline<bf16_t>(P, smem, lin, G);     // the ragged rows: units lin, lin + G, ... (round 6)
 }
 
@@ -1978,19 +2102,23 @@ int launch_pp(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
   const bool nk4 = a.K == 256;
   const int res = a.residual ? (a.row_scale ? 2 : 1) : 0;       // the residual as two more K-steps (+ DropPath's per-sample scale)
   const bool ps = a.store_mode == DU_STORE_PIXEL_SHUFFLE2;     // (pp_legal: with a residual, K >= 384)
+  const bool rope = a.store_mode == DU_STORE_QKV_ROPE;         // (pp_legal: token grid <= 32 x 32, K >= 384)
+  if (rope) { P.b.Hi = a.geom.Hi; P.b.Wi = a.geom.Wi; }
   void (*kfn)(GemmParams);
-  if (ps) kfn = gemm_nt_pp_kernel<DU_ACT_NONE, false, 1, true>;
+  if (rope) kfn = gemm_nt_pp_kernel<DU_ACT_NONE, false, 0, false, true>;
+  else if (ps) kfn = gemm_nt_pp_kernel<DU_ACT_NONE, false, 1, true>;
   else if (res == 2) kfn = nk4 ? gemm_nt_pp_kernel<DU_ACT_NONE, true, 2> : gemm_nt_pp_kernel<DU_ACT_NONE, false, 2>;
   else if (res == 1) kfn = nk4 ? gemm_nt_pp_kernel<DU_ACT_NONE, true, 1> : gemm_nt_pp_kernel<DU_ACT_NONE, false, 1>;
   else if (nk4) kfn = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, true> : gemm_nt_pp_kernel<DU_ACT_NONE, true>;
   else kfn = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, false> : gemm_nt_pp_kernel<DU_ACT_NONE, false>;
-  static bool attr_set[9] = {false, false, false, false, false, false, false, false, false};
-  const int ai = ps ? 8 : (res ? 2 + 2 * res + (nk4 ? 1 : 0) : (a.act == DU_ACT_GELU ? 1 : 0) + (nk4 ? 2 : 0));
+  static bool attr_set[10] = {false, false, false, false, false, false, false, false, false, false};
+  const int lds_bytes = rope ? PP_LDS_ROPE : PP_LDS;
+  const int ai = rope ? 9 : ps ? 8 : (res ? 2 + 2 * res + (nk4 ? 1 : 0) : (a.act == DU_ACT_GELU ? 1 : 0) + (nk4 ? 2 : 0));
   if (!attr_set[ai]) {
-    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS) != hipSuccess) return DU_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return DU_ERR_LAUNCH;
     attr_set[ai] = true;
   }
-  hipLaunchKernelGGL(kfn, grid, dim3(512), PP_LDS, st, P);
+  hipLaunchKernelGGL(kfn, grid, dim3(512), lds_bytes, st, P);
   return du_check_launch();
 }
 
@@ -2107,6 +2235,13 @@ static bool p8_legal(const du_gemm_args& a) {
 // the persistent 256 x 128 kernel: bf16 result with a bias (+ GELU) epilogue, plain store, K >= 512, every extent below 2^31 bytes
 static bool pp_legal(const du_gemm_args& a) {
   if (!p8_legal(a) || a.out_dtype != DU_BF16 || a.batch > 1) return false;
+  if (a.store_mode == DU_STORE_QKV_ROPE) {      // (p8_legal checked the bias-only bf16 epilogue, the planes and the tables)
+    // RoPE in the drain: the factorised table holds a token grid of <= 32 x 32 (du_gemm_args.geom.Hi x Wi, Hi * Wi = tokens behind the prefix)
+    const du_conv_geom& g = a.geom;
+    if (g.Hi <= 0 || g.Wi <= 0 || g.Hi > 32 || g.Wi > 32 || g.Hi * g.Wi != a.ps_H - a.rope_prefix || a.rope_prefix < 0) return false;
+    if (a.K < 384 || a.N % 128 || a.M % 256 || 3L * a.ldc * 2 >= 0x7fffffffL) return false;
+    return ((long)a.M * a.lda + a.K) * 2 < 0x7fffffffL && ((long)a.N * a.ldb + a.K) * 2 < 0x7fffffffL;
+  }
   const bool ps = a.store_mode == DU_STORE_PIXEL_SHUFFLE2;
   if (ps) {     // ConvTranspose2d k2 s2 forward + residual: a 128-column tile inside one tap, power-of-two pixel grid
     if (!a.residual || a.row_scale || a.K < 384 || a.ps_C % 128 || a.N != 4 * a.ps_C || a.ps_H <= 0 || a.ps_W <= 0) return false;
@@ -2132,7 +2267,10 @@ int du_gemm_p8_choice(const du_gemm_args& a) {
   if (g_p8_mode != 0 && g_p8_tn && p8_gather_legal(a))      // ConvT data gradient: 256 x 256 tiles once they fill most of the CUs
     return (g_p8_mode > 0 || (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 192) ? 1 : 0;
   if (g_p8_mode == 0 || !p8_legal(a)) return 0;
-  if (a.store_mode == DU_STORE_QKV_ROPE) return 2;
+  if (a.store_mode == DU_STORE_QKV_ROPE) {     // round 6: on the persistent kernel (RoPE in the drain) where a CU gets >= 2 tiles, else 256 x 128
+    const long t = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+    return (g_p8_persist && g_p8_mode != 2 && pp_legal(a) && (g_p8_persist > 1 || g_p8_mode == 4 || t >= 2 * (256 / g_p8_corun))) ? 4 : 2;
+  }
   if (g_p8_mode == 3) return a.act == DU_ACT_SWIGLU ? 2 : 3;
   if (g_p8_mode == 4) return pp_legal(a) ? 4 : 2;
   if (g_p8_mode > 0) return g_p8_mode == 2 ? 2 : 1;

@@ -271,6 +271,7 @@ class DinoVisionTransformer(nn.Module):
         xs[:, npre:] = tok.view(B, hp * wp, D)
         take = list(n)
         sin_all, cos_all = self.rope_embed.sincos_all(hp, wp, x.device, self.training, len(pk["blocks"]))   # vision_transformer.py:271-272
+        rope_grid = (hp, wp)       # the tables are those of an hp x wp token grid: ops.qkv_attention may apply them from a factorised table
         sd = self.training and self.drop_path_rate > 0.0
         k_sub = max(int(B * (1 - self.drop_path_rate)), 1)                                 # layers/block.py:92-93
         if sd:
@@ -279,7 +280,7 @@ class DinoVisionTransformer(nn.Module):
         def attn_branch(xr, Bs, i, d, scale, ws):
             """xr (Bs*N, D) fp32 += [scale *] ls1(attn(norm1(xr)))   in place (layers/block.py:189-193)"""
             h, _, _ = ops.layernorm_raw(xr, d["n1w"], d["n1b"], 1e-5, dtype)
-            a = ops.qkv_attention(h, d["qkv_w"], d["qkv_b"], sin_all[i], cos_all[i], Bs, N, nh, dh, npre, ws)
+            a = ops.qkv_attention(h, d["qkv_w"], d["qkv_b"], sin_all[i], cos_all[i], Bs, N, nh, dh, npre, ws, grid=rope_grid)
             ops.mm(a, d["proj_w"], bias=d["proj_b"], gamma=d["g1"], residual=xr, out=xr, row_scale=scale, rs_rows=xr.shape[0] if scale is not None else 0)
 
         def ffn_branch(xr, d, scale):

@@ -2337,16 +2337,23 @@ def cast(x, dt):
 # 33.71 ms fused vs 33.56 ms with the separate du_qkv_rope_split pass: the epilogue's table loads, the per-row division and the 128-byte
 # head-major store segments cost what the 100 MB pass saved), so it stays opt-in.
 _QKV_FUSED = _ab_env("DINOUNET_QKV_FUSED", "0") == "1"
+# round 6: RoPE + head split in the persistent kernel's drain (gemm_nt_pp_kernel<.., ROPE>, needs `grid`).  Built, parity-tested, and measured
+# SLOWER than the plain persistent product + du_qkv_rope_split: x0.995 in the step (profiles/r06_ab_rope_drain_v1.txt) -- the drain has no
+# registers for the 16-byte store form (it spills), and sixteen 8-byte stores per lane and tile cost more than the 21 us pass saves.  Opt-in.
+_QKV_ROPE_DRAIN = _ab_env("DINOUNET_QKV_ROPE_DRAIN", "0") == "1"
 
 
-def qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, workspace):
+def qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, workspace, grid=None):
     """attention(h w^T + bias) of one ViT block (layers/attention.py:88-118): h (B*N, D) normalised tokens -> (B*N, H*Dh).
     bf16, d_head 64: the qkv product's epilogue applies RoPE and the q scale and stores q / k / v head-major (DU_STORE_QKV_ROPE), so the
     (B*N, 3*H*Dh) matrix and the pass that re-read it (du_qkv_rope_split) do not exist; the few rows past the last full 256-row tile
-    (M = 8 * 1029 = 32 * 256 + 40) go through a small plain product + du_qkv_rope_split_rows.  Otherwise: mm + attention()."""
+    (M = 8 * 1029 = 32 * 256 + 40) go through a small plain product + du_qkv_rope_split_rows.  Otherwise: mm + attention().
+    grid = (H_t, W_t): the caller states that sin / cos are RoPE tables of an H_t x W_t token grid (separable: dimensions 0..15 of a head
+    depend on the token's row, 16..31 on its column, 32..63 repeat them, rope_position_encoding.py:98-104) -- round 6: the persistent
+    kernel then applies the rotation in its drain from an 8 KB factorised table (gemm_nt_pp_kernel<.., ROPE>)."""
     dt = h.dtype
     M, D = h.shape
-    if _QKV_FUSED and dt == torch.bfloat16 and Dh == 64 and M == B * N and M >= 256:
+    if (_QKV_FUSED or (_QKV_ROPE_DRAIN and grid is not None)) and dt == torch.bfloat16 and Dh == 64 and M == B * N and M >= 256:
         Npad = (N + 7) // 8 * 8
         key = ("qkv", dt, B, H, Npad, Dh)
         if key not in workspace:
@@ -2361,7 +2368,12 @@ def qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, workspace):
         kw = dict(dtype=DU_BF16, out_dtype=DU_BF16, a_mode=PLAIN_ROW, b_mode=PLAIN_ROW, M=M0, N=Nw, K=D, A=h.data_ptr(), lda=lda,
                   B=w.data_ptr(), ldb=ldb, Cmat=qkv3.data_ptr(), ldc=B * H * Npad * Dh, bias=_dp(bias), store_mode=STORE_QKV_ROPE,
                   ps=(N, Npad, H), rope=(sin.data_ptr(), cos.data_ptr(), prefix, qscale))
-        if Nw == 3 * H * Dh and gemm_route(**kw) == 4:
+        if grid is not None and _QKV_ROPE_DRAIN:
+            g = ConvGeom()
+            g.Hi, g.Wi = int(grid[0]), int(grid[1])
+            kw["geom"] = g
+        route = gemm_route(**kw) if Nw == 3 * H * Dh else 0
+        if route == 6 or (route == 4 and _QKV_FUSED):
             gemm_raw(**kw)
             L = _lib.lib()
             if r:

@@ -218,7 +218,7 @@ def attention(qkv, sin, cos, B, N, H, Dh, prefix, workspace):
     return o.transpose(1, 2).reshape(B * N, H * Dh).to(qkv.dtype)
 
 
-def qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, workspace):
+def qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, workspace, grid=None):
     return attention(mm(h, w, bias=bias), sin, cos, B, N, H, Dh, prefix, workspace)
 
 

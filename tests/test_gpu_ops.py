@@ -1227,6 +1227,67 @@ def test_vit_qkv_rope_in_gemm_epilogue(B, H, N, D):
     assert rel(out_u, ref) < 3e-2
 
 
+@pytest.mark.parametrize("B,H,hp,wp,D", [(8, 16, 32, 32, 1024), (2, 6, 32, 32, 384), (3, 12, 16, 24, 768), (9, 16, 32, 32, 1024)])
+def test_vit_qkv_rope_in_the_persistent_kernels_drain(B, H, hp, wp, D):
+    """Round 6: RoPE + q scale + head-major store in the DRAIN of the persistent kernel (gemm_nt_pp_kernel<.., ROPE>): the rotation of
+    (token, d) comes from a factorised table in LDS -- dimensions 0..15 of a head follow the token's row, 16..31 its column, 32..63 repeat
+    them (rope_position_encoding.py:98-104) -- so the tables here are built the reference's way (coords / periods, tiled twice, with
+    per-axis jitter so that the two axes differ).  Against the separate product + du_qkv_rope_split (planes equal to one bf16 ulp: the
+    unfused path rounds the projection first) and torch SDPA on the fp32 projection; prefix tokens unrotated; v untouched; rows behind
+    the last full 256-row tile through du_qkv_rope_split_rows; B = 9: tiles that straddle samples."""
+    import math
+    from dinounet_amd import ops
+    d = dev()
+    bf = torch.bfloat16
+    Dh, prefix = 64, 5
+    N = prefix + hp * wp
+    h = q(gen(B * N, D, seed=1), bf)
+    w = q(gen(3 * H * Dh, D, seed=2, scale=D ** -0.5), bf)
+    bias = gen(3 * H * Dh, seed=3, scale=0.1)
+    periods = 100.0 ** (2 * torch.arange(Dh // 4, dtype=torch.float32) / (Dh // 2))
+    ch = (torch.arange(0.5, hp) / hp * 2 - 1) * 1.37 + 0.11           # (a jitter / shift per axis, as in training)
+    cw = (torch.arange(0.5, wp) / wp * 2 - 1) * 0.71 - 0.23
+    coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij"), -1).flatten(0, 1)          # [HW, 2]
+    ang = (2 * math.pi * coords[:, :, None] / periods[None, None, :]).flatten(1, 2).tile(2)   # [HW, 64]
+    sin, cos = torch.sin(ang), torch.cos(ang)
+    hd, wd, bd, sd, cd = h.to(d, bf), w.to(d, bf), bias.to(d), sin.to(d).contiguous(), cos.to(d).contiguous()
+    ws1, ws2 = {}, {}
+    from dinounet_amd import _lib
+    ops.TRACK_ROUTE, ops.ROUTES[:] = True, []
+    drain_default = ops._QKV_ROPE_DRAIN
+    try:
+        ops._QKV_ROPE_DRAIN = True           # opt-in path (measured x0.995 in the step, see ops.py)
+        _lib.lib().du_set_option(0, 4)       # (the small shapes have fewer than two tiles per CU: the cost model would keep them off the persistent kernel)
+        out_f = ops.qkv_attention(hd, wd, bd, sd, cd, B, N, H, Dh, prefix, ws1, grid=(hp, wp))
+        ops.TRACK_ROUTE = False
+        out_f2 = ops.qkv_attention(hd, wd, bd, sd, cd, B, N, H, Dh, prefix, {}, grid=(hp, wp))
+    finally:
+        ops.TRACK_ROUTE = False
+        ops._QKV_ROPE_DRAIN = drain_default
+        _lib.lib().du_set_option(0, -1)
+    assert 6 in [r for _, _, r in ops.ROUTES], ops.ROUTES                 # the persistent kernel took the fused store
+    assert torch.equal(out_f, out_f2), "run-to-run difference"
+    out_u = ops.attention(ops.mm(hd, wd, bias=bd), sd, cd, B, N, H, Dh, prefix, ws2)
+    (k1,), (k2,) = ws1.keys(), ws2.keys()
+    for name, a, b in zip("qkv", ws1[k1], ws2[k2]):
+        assert rel(a[:, :, :N], b[:, :, :N]) < 1.2e-2, name          # <= 1 bf16 ulp apart
+    assert rel(out_f, out_u) < 2e-2
+    qkv = h @ w.t() + bias
+    qq, kk, vv = [t.transpose(1, 2) for t in qkv.view(B, N, 3, H, Dh).unbind(2)]
+
+    def rope(t):
+        a = t[:, :, prefix:]
+        x1, x2 = a.chunk(2, -1)
+        return torch.cat([t[:, :, :prefix], a * cos + torch.cat([-x2, x1], -1) * sin], 2)
+
+    ref = F.scaled_dot_product_attention(rope(qq), rope(kk), vv).transpose(1, 2).reshape(B * N, H * Dh)
+    assert rel(out_f, ref) < 3e-2
+    # the planes themselves against the fp32 rotation (q carries the softmax scale in log2 units, ops.qkv_attention)
+    qs = Dh ** -0.5 * math.log2(math.e)
+    for name, plane, want in (("q", ws1[k1][0], rope(qq) * qs), ("k", ws1[k1][1], rope(kk)), ("v", ws1[k1][2], vv)):
+        assert rel(plane[:, :, :N].float().cpu(), want) < 6e-3, name
+
+
 @pytest.mark.parametrize("B,H,W,K,ld", [(2, 24, 40, 2, 32), (1, 17, 13, 1, 32), (3, 8, 16, 3, 32), (2, 33, 9, 4, 32), (2, 16, 16, 2, 64)])
 def test_seg_head_streaming_kernels_match_conv1x1(B, H, W, K, ld):
     """The decoder's last layer (32 channels -> K classes, dinounet_training.py:603-629) as one streaming pass: fp32 NCHW logits, and dx /
