@@ -13,7 +13,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "dinounet_hip.h")
 DU_F32, DU_BF16 = 0, 1
 PLAIN_ROW, PLAIN_COL, IM2COL_ROW, IM2COL_COL = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY, ACT_SWIGLU = 0, 1, 2, 3, 4
-STORE_PLAIN, STORE_PIXEL_SHUFFLE2, STORE_QKV_ROPE, STORE_SLABS = 0, 1, 2, 4
+STORE_PLAIN, STORE_PIXEL_SHUFFLE2, STORE_QKV_ROPE, STORE_SLABS, STORE_QKV_HEADS = 0, 1, 2, 4, 5
 ERRORS = {-1: "DU_ERR_BAD_ARG", -2: "DU_ERR_UNSUPPORTED", -3: "DU_ERR_LAUNCH"}
 
 

@@ -1242,6 +1242,65 @@ __global__ __launch_bounds__(256) void qkv_rope_split_rows_kernel(const T* __res
   }
 }
 
+// RoPE + q scale applied IN PLACE to head-major q / k planes that the qkv product stored unrotated (DU_STORE_QKV_HEADS, round 6): a thread
+// owns dimensions d0 .. d0 + 7 AND their rotate-half partners d0 + 32 .. of one (which, b, h, token) row, so every element is read once
+// and written once -- 67 MB for ViT-L at batch 8 against the 101 MB of qkv_rope_split_kernel (v is already where it belongs).  Rows whose
+// global index b * N + n is >= m_limit belong to the product's ragged tail (du_qkv_rope_split_rows writes them rotated): skipped.
+// Same arithmetic as qkv_rope_split_kernel, term by term (layers/attention.py:16-27,66-85).
+template <typename T>
+__global__ __launch_bounds__(256) void qkv_rope_inplace_kernel(T* __restrict__ q, T* __restrict__ k, const float* __restrict__ sin_t,
+                                                               const float* __restrict__ cos_t, int B, int N, int Npad, int H, int Dh,
+                                                               int prefix, float qscale, long m_limit, long total) {
+  constexpr int V = Elem<T>::VEC;
+  const int half = Dh / 2, dv = half / V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int d0 = (int)(i % dv) * V;
+    long t = i / dv;
+    const int n = (int)(t % N); t /= N;
+    const int h = (int)(t % H); t /= H;
+    const int b = (int)(t % B);
+    const int which = (int)(t / B);
+    if ((long)b * N + n >= m_limit) continue;
+    if (which == 1 && n < prefix) continue;                      // k prefix rows: nothing to do
+    T* row = (which == 0 ? q : k) + (((long)b * H + h) * Npad + n) * Dh;
+    Vec16<T> x1 = as_vec<T>(*(const uint4*)(row + d0)), x2 = as_vec<T>(*(const uint4*)(row + d0 + half));
+    float o1[V], o2[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) { o1[j] = to_f32(x1.v[j]); o2[j] = to_f32(x2.v[j]); }
+    if (n >= prefix) {
+      const float* sp = sin_t + (long)(n - prefix) * Dh + d0;
+      const float* cp = cos_t + (long)(n - prefix) * Dh + d0;
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        const float a = o1[j], c = o2[j];
+        o1[j] = a * cp[j] + -1.f * c * sp[j];
+        o2[j] = c * cp[half + j] + 1.f * a * sp[half + j];
+      }
+    }
+    if (which == 0) {
+#pragma unroll
+      for (int j = 0; j < V; j++) { o1[j] *= qscale; o2[j] *= qscale; }
+    }
+    Vec16<T> r1, r2;
+#pragma unroll
+    for (int j = 0; j < V; j++) { r1.v[j] = from_f32<T>(o1[j]); r2.v[j] = from_f32<T>(o2[j]); }
+    *(uint4*)(row + d0) = as_u4(r1);
+    *(uint4*)(row + d0 + half) = as_u4(r2);
+  }
+}
+
+extern "C" int du_qkv_rope_inplace(int dtype, void* q, void* k, const float* sin_t, const float* cos_t, int B, int N, int Npad, int H, int Dh,
+                                   int prefix, float qscale, int64_t m_limit, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!q || !k || !sin_t || !cos_t || B <= 0 || N <= 0 || Npad < N || H <= 0 || prefix < 0 || prefix > N) return DU_ERR_BAD_ARG;
+  if (dtype != DU_BF16 || Dh % 16 || Dh <= 0) return DU_ERR_UNSUPPORTED;
+  const long total = 2L * B * H * N * (Dh / 2 / 8);
+  long g = (total + 255) / 256; if (g > 65535 * 4) g = 65535 * 4;
+  hipLaunchKernelGGL(qkv_rope_inplace_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, st, (bf16_t*)q, (bf16_t*)k, sin_t, cos_t, B, N, Npad, H,
+                     Dh, prefix, qscale, (long)m_limit, total);
+  return du_check_launch();
+}
+
 int g_attn_impl = 0;     // du_set_option key 6: 0 = attn_fwd_w64_kernel (one wave per SIMD, 64 queries per wave), 1 = attn_fwd_kernel (round 2/3)
 int g_attn_var = 0;      // du_set_option key 8: experimental variants of the w64 kernel (tools only)
 int g_attn_thresh_log2 = 60;   // du_set_option key 7: log2 of the row-sum threshold of the w64 kernel's cold rescale path (<= -1000: every tile takes it)

@@ -1530,12 +1530,15 @@ __device__ __forceinline__ void pp_wait_lds4(f32x4& a, f32x4& b, f32x4& c, f32x4
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
 }
 
-template <int ACT, bool NK4, int RES = 0, bool PS = false, bool ROPE = false>
+// QKV == 2 (DU_STORE_QKV_HEADS): the same head-major store WITHOUT the rotation -- the plain drain with another row offset, no extra
+// registers, 16-byte stores; du_qkv_rope_inplace then rotates q and k where they lie (67 MB instead of the 101 MB of qkv_rope_split).
+template <int ACT, bool NK4, int RES = 0, bool PS = false, int QKV = 0>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
+  constexpr bool ROPE = QKV == 1, HEADS = QKV == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<bf16_t>(P, smem); return; }
   static_assert(RES == 0 || ACT == DU_ACT_NONE, "the residual form has no activation");
-  static_assert(!ROPE || (ACT == DU_ACT_NONE && !NK4 && RES == 0 && !PS), "the RoPE drain: plain bias epilogue, K >= 384");
+  static_assert(QKV == 0 || (ACT == DU_ACT_NONE && !NK4 && RES == 0 && !PS), "the qkv stores: plain bias epilogue, K >= 384");
   constexpr bool FOUR = NK4 && RES == 0;          // the four-K-step tile form (K = 256 without a residual); with one the tile is six K-steps
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1567,7 +1570,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
   const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)P.b.p, 0, (int)((((long)P.N - 1) * P.b.ld + P.K) * 2), 0x00020000);
   const long out_rows = PS ? 4L * P.M : (long)P.M;           // rows (pixels) of C and of the residual
   const int out_cols = PS ? P.ps_C : P.N;
-  const auto rc = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, ROPE ? (int)(3 * P.ldc * 2) : (int)(((out_rows - 1) * P.ldc + out_cols) * 2), 0x00020000);
+  const auto rc = __builtin_amdgcn_make_buffer_rsrc(P.C, 0, QKV ? (int)(3 * P.ldc * 2) : (int)(((out_rows - 1) * P.ldc + out_cols) * 2), 0x00020000);
   const int ps_lw = PS ? __builtin_ctz(P.ps_W) : 0, ps_lh = PS ? __builtin_ctz(P.ps_H) : 0;
   // PS: output pixel (before the tap's shift) of input pixel m, as a row index of C / the residual
   auto ps_pixel = [&](unsigned m) -> unsigned {
@@ -1750,16 +1753,19 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmParams P) {
     int m0, n0;
     coords(tile, m0, n0);
     pcol = n0 + wn * 64 + hi * 8;
-    if constexpr (ROPE) {
+    if constexpr (QKV != 0) {
       const int hd = P.ps_C * 64, which = n0 / hd, head = ((n0 - which * hd) >> 6) + wn;     // this wave's (q | k | v, head)
-      qs_prev = which == 0 ? P.rope_qscale : 1.0f;
+      if constexpr (ROPE) qs_prev = which == 0 ? P.rope_qscale : 1.0f;
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         const int m = m0 + i * 128 + wm * 32 + (lane & 31);
         const int b = m / P.ps_H, t = m - b * P.ps_H;
-        crow[i] = m < P.M ? (unsigned)(((long)which * P.ldc + (((long)b * P.ps_C + head) * P.ps_W + t) * 64 + hi * 4) * 2) : PP_OOR;
-        const int tt = t - P.rope_prefix, ty = tt / P.b.Wi, tx = tt - ty * P.b.Wi;
-        trow[i] = (which < 2 && tt >= 0 && m < P.M) ? (unsigned)ty | ((unsigned)tx << 8) : (32u | (32u << 8));
+        // (ROPE stores 8 bytes per lane: + 4 hi elements; HEADS the plain drain's 16 bytes: + 8 hi, and its column offsets c * 32 + 16 h2 stay)
+        crow[i] = m < P.M ? (unsigned)(((long)which * P.ldc + (((long)b * P.ps_C + head) * P.ps_W + t) * 64 + hi * (ROPE ? 4 : 8)) * 2) : PP_OOR;
+        if constexpr (ROPE) {
+          const int tt = t - P.rope_prefix, ty = tt / P.b.Wi, tx = tt - ty * P.b.Wi;
+          trow[i] = (which < 2 && tt >= 0 && m < P.M) ? (unsigned)ty | ((unsigned)tx << 8) : (32u | (32u << 8));
+        }
       }
       return;
     }
@@ -2103,17 +2109,19 @@ int launch_pp(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
   const int res = a.residual ? (a.row_scale ? 2 : 1) : 0;       // the residual as two more K-steps (+ DropPath's per-sample scale)
   const bool ps = a.store_mode == DU_STORE_PIXEL_SHUFFLE2;     // (pp_legal: with a residual, K >= 384)
   const bool rope = a.store_mode == DU_STORE_QKV_ROPE;         // (pp_legal: token grid <= 32 x 32, K >= 384)
+  const bool heads = a.store_mode == DU_STORE_QKV_HEADS;
   if (rope) { P.b.Hi = a.geom.Hi; P.b.Wi = a.geom.Wi; }
   void (*kfn)(GemmParams);
-  if (rope) kfn = gemm_nt_pp_kernel<DU_ACT_NONE, false, 0, false, true>;
+  if (rope) kfn = gemm_nt_pp_kernel<DU_ACT_NONE, false, 0, false, 1>;
+  else if (heads) kfn = gemm_nt_pp_kernel<DU_ACT_NONE, false, 0, false, 2>;
   else if (ps) kfn = gemm_nt_pp_kernel<DU_ACT_NONE, false, 1, true>;
   else if (res == 2) kfn = nk4 ? gemm_nt_pp_kernel<DU_ACT_NONE, true, 2> : gemm_nt_pp_kernel<DU_ACT_NONE, false, 2>;
   else if (res == 1) kfn = nk4 ? gemm_nt_pp_kernel<DU_ACT_NONE, true, 1> : gemm_nt_pp_kernel<DU_ACT_NONE, false, 1>;
   else if (nk4) kfn = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, true> : gemm_nt_pp_kernel<DU_ACT_NONE, true>;
   else kfn = a.act == DU_ACT_GELU ? gemm_nt_pp_kernel<DU_ACT_GELU, false> : gemm_nt_pp_kernel<DU_ACT_NONE, false>;
-  static bool attr_set[10] = {false, false, false, false, false, false, false, false, false, false};
+  static bool attr_set[11] = {false, false, false, false, false, false, false, false, false, false, false};
   const int lds_bytes = rope ? PP_LDS_ROPE : PP_LDS;
-  const int ai = rope ? 9 : ps ? 8 : (res ? 2 + 2 * res + (nk4 ? 1 : 0) : (a.act == DU_ACT_GELU ? 1 : 0) + (nk4 ? 2 : 0));
+  const int ai = heads ? 10 : rope ? 9 : ps ? 8 : (res ? 2 + 2 * res + (nk4 ? 1 : 0) : (a.act == DU_ACT_GELU ? 1 : 0) + (nk4 ? 2 : 0));
   if (!attr_set[ai]) {
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return DU_ERR_LAUNCH;
     attr_set[ai] = true;
@@ -2217,10 +2225,10 @@ static bool p8_gather_legal(const du_gemm_args& a) {
 static bool p8_legal(const du_gemm_args& a) {
   if (a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.dtype != DU_BF16) return false;
   if (a.split_k > 1) return false;
-  if (a.store_mode == DU_STORE_QKV_ROPE) {       // 256 x 128 kernel only (du_gemm_p8_choice), bias-only bf16 epilogue, d_head 64
+  if (a.store_mode == DU_STORE_QKV_ROPE || a.store_mode == DU_STORE_QKV_HEADS) {       // bias-only bf16 epilogue, d_head 64
     if (a.out_dtype != DU_BF16 || a.residual || a.gamma || a.row_scale || a.alpha != 1.0f || a.act != DU_ACT_NONE || a.batch > 1) return false;
-    if (a.ps_H <= 0 || a.ps_W < a.ps_H || a.ps_C <= 0 || a.N != 3 * a.ps_C * 64 || a.ldc % 8 || !a.rope_sin || !a.rope_cos) return false;
-    if ((((uintptr_t)a.rope_sin) | ((uintptr_t)a.rope_cos) | ((uintptr_t)a.C)) & 15) return false;
+    if (a.ps_H <= 0 || a.ps_W < a.ps_H || a.ps_C <= 0 || a.N != 3 * a.ps_C * 64 || a.ldc % 8 || (((uintptr_t)a.C) & 15)) return false;
+    if (a.store_mode == DU_STORE_QKV_ROPE && (!a.rope_sin || !a.rope_cos || ((((uintptr_t)a.rope_sin) | ((uintptr_t)a.rope_cos)) & 15))) return false;
   } else
   if (a.store_mode != DU_STORE_PLAIN && (a.store_mode != DU_STORE_PIXEL_SHUFFLE2 || a.ps_C % 4 || a.act == DU_ACT_SWIGLU)) return false;
   if (a.K % 128 || a.K < 256 || a.M < 256 || a.N < 128 || a.N % 4) return false;
@@ -2235,6 +2243,10 @@ static bool p8_legal(const du_gemm_args& a) {
 // the persistent 256 x 128 kernel: bf16 result with a bias (+ GELU) epilogue, plain store, K >= 512, every extent below 2^31 bytes
 static bool pp_legal(const du_gemm_args& a) {
   if (!p8_legal(a) || a.out_dtype != DU_BF16 || a.batch > 1) return false;
+  if (a.store_mode == DU_STORE_QKV_HEADS) {     // the head-major store alone (p8_legal: bias-only bf16 epilogue, the planes)
+    if (a.K < 384 || a.N % 128 || a.M % 256 || 3L * a.ldc * 2 >= 0x7fffffffL) return false;
+    return ((long)a.M * a.lda + a.K) * 2 < 0x7fffffffL && ((long)a.N * a.ldb + a.K) * 2 < 0x7fffffffL;
+  }
   if (a.store_mode == DU_STORE_QKV_ROPE) {      // (p8_legal checked the bias-only bf16 epilogue, the planes and the tables)
     // RoPE in the drain: the factorised table holds a token grid of <= 32 x 32 (du_gemm_args.geom.Hi x Wi, Hi * Wi = tokens behind the prefix)
     const du_conv_geom& g = a.geom;
@@ -2267,6 +2279,7 @@ int du_gemm_p8_choice(const du_gemm_args& a) {
   if (g_p8_mode != 0 && g_p8_tn && p8_gather_legal(a))      // ConvT data gradient: 256 x 256 tiles once they fill most of the CUs
     return (g_p8_mode > 0 || (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 192) ? 1 : 0;
   if (g_p8_mode == 0 || !p8_legal(a)) return 0;
+  if (a.store_mode == DU_STORE_QKV_HEADS) return (g_p8_mode != 0 && pp_legal(a)) ? 4 : 0;      // the persistent kernel or nothing
   if (a.store_mode == DU_STORE_QKV_ROPE) {     // round 6: on the persistent kernel (RoPE in the drain) where a CU gets >= 2 tiles, else 256 x 128
     const long t = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
     return (g_p8_persist && g_p8_mode != 2 && pp_legal(a) && (g_p8_persist > 1 || g_p8_mode == 4 || t >= 2 * (256 / g_p8_corun))) ? 4 : 2;

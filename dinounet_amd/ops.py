@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SWIGLU, DU_BF16, DU_F32, IM2COL_COL, IM2COL_ROW, PLAIN_COL,
-                   PLAIN_ROW, STORE_PIXEL_SHUFFLE2, STORE_QKV_ROPE, STORE_SLABS, ConvGeom, GemmArgs)
+                   PLAIN_ROW, STORE_PIXEL_SHUFFLE2, STORE_QKV_HEADS, STORE_QKV_ROPE, STORE_SLABS, ConvGeom, GemmArgs)
 
 __all__ = ["mm", "linear", "conv2d", "conv_transpose2x2", "norm_act", "layer_norm", "msda", "dwconv3x3",
            "maxpool3x3s2", "bilinear_add", "bilinear_resize", "squeeze_excite", "dice_ce_loss"]
@@ -2341,6 +2341,9 @@ _QKV_FUSED = _ab_env("DINOUNET_QKV_FUSED", "0") == "1"
 # SLOWER than the plain persistent product + du_qkv_rope_split: x0.995 in the step (profiles/r06_ab_rope_drain_v1.txt) -- the drain has no
 # registers for the 16-byte store form (it spills), and sixteen 8-byte stores per lane and tile cost more than the 21 us pass saves.  Opt-in.
 _QKV_ROPE_DRAIN = _ab_env("DINOUNET_QKV_ROPE_DRAIN", "0") == "1"
+# round 6: head-major store from the persistent kernel's drain (DU_STORE_QKV_HEADS) + du_qkv_rope_inplace: 67 MB of RoPE traffic instead of
+# 101 MB -- and x0.993 in the step (profiles/r06_ab_qkv_heads_v1.txt; alone 140 vs 127-140 us per qkv + rope + attention).  Opt-in.
+_QKV_HEADS = _ab_env("DINOUNET_QKV_HEADS", "0") == "1"
 
 
 def qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, workspace, grid=None):
@@ -2353,6 +2356,38 @@ def qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, workspace, grid=Non
     kernel then applies the rotation in its drain from an 8 KB factorised table (gemm_nt_pp_kernel<.., ROPE>)."""
     dt = h.dtype
     M, D = h.shape
+    if _QKV_HEADS and dt == torch.bfloat16 and Dh == 64 and M == B * N and M >= 256 and not _QKV_FUSED and not (_QKV_ROPE_DRAIN and grid is not None):
+        # round 6: the persistent kernel's drain stores q / k / v head-major (DU_STORE_QKV_HEADS: the plain drain with another row offset),
+        # du_qkv_rope_inplace rotates q and k where they lie: 67 MB instead of the 101 MB pass of du_qkv_rope_split; the same bits
+        Npad = (N + 7) // 8 * 8
+        key = ("qkv", dt, B, H, Npad, Dh)
+        if key not in workspace:
+            workspace[key] = torch.zeros((3, B, H, Npad, Dh), dtype=dt, device=h.device)
+        qkv3 = workspace[key]
+        q, k, v = qkv3
+        r = M % 256
+        M0 = M - r
+        qscale = Dh ** -0.5 * math.log2(math.e)
+        _, _, lda = _rows2d(h)
+        Nw, _, ldb = _rows2d(w)
+        kw = dict(dtype=DU_BF16, out_dtype=DU_BF16, a_mode=PLAIN_ROW, b_mode=PLAIN_ROW, M=M0, N=Nw, K=D, A=h.data_ptr(), lda=lda,
+                  B=w.data_ptr(), ldb=ldb, Cmat=qkv3.data_ptr(), ldc=B * H * Npad * Dh, bias=_dp(bias), store_mode=STORE_QKV_HEADS,
+                  ps=(N, Npad, H))
+        if Nw == 3 * H * Dh and M0 > 0 and gemm_route(**kw) == 6:
+            gemm_raw(**kw)
+            L = _lib.lib()
+            _lib.check(L.du_qkv_rope_inplace(DU_BF16, _p(q), _p(k), _p(sin), _p(cos), B, N, Npad, H, Dh, prefix, qscale, M0, _st()),
+                       "du_qkv_rope_inplace")
+            if r:
+                tail = mm(h[M0:], w, bias=bias)
+                _lib.check(L.du_qkv_rope_split_rows(DU_BF16, _p(tail), _p(q), _p(k), _p(v), _p(sin), _p(cos), B, N, Npad, H, Dh, prefix,
+                                                    qscale, M0, r, _st()), "du_qkv_rope_split_rows")
+            out = torch.empty((M, H * Dh), dtype=dt, device=h.device)
+            e0 = PROFILE.start() if PROFILE is not None else None
+            _lib.check(L.du_attention_fwd(_p(q), _p(k), _p(v), _p(out), B, H, N, Npad, Dh, _st()), "du_attention_fwd")
+            if PROFILE is not None:
+                PROFILE.stop("attn_fwd_w64_kernel<bf16>", e0, 4.0 * B * H * N * N * Dh, 4.0 * B * H * N * Dh * 2)
+            return out
     if (_QKV_FUSED or (_QKV_ROPE_DRAIN and grid is not None)) and dt == torch.bfloat16 and Dh == 64 and M == B * N and M >= 256:
         Npad = (N + 7) // 8 * 8
         key = ("qkv", dt, B, H, Npad, Dh)

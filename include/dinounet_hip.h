@@ -71,6 +71,9 @@ extern "C" {
 #define DU_STORE_SLABS 4 /* split_k > 1, fp32 result, generic bf16 engine only: split s writes its partial product with plain stores to
                             C + s * M * ldc (split_k slabs of M x ldc floats, no zero fill needed) instead of adding into C atomically --
                             the caller reduces the slabs in a fixed order (du_splitk_reduce_bf16): bit-reproducible results */
+#define DU_STORE_QKV_HEADS 5 /* as DU_STORE_QKV_ROPE without the rotation and the q scale: the projection (+ bias) stored head-major in the
+                               three planes (ps_H / ps_W / ps_C as there), rotated afterwards where it lies by du_qkv_rope_inplace.  Served by the
+                               persistent multi-phase kernel only (M % 256 == 0, K >= 384; DU_ERR_UNSUPPORTED otherwise) */
 #define DU_STORE_TAPS 3 /* grouped convolution weight gradients only (du_gemm_tn_group: du_tn_job.taps): column n = (tap, c) of the product is
                            element (m, c, tap) of a torch-layout weight gradient */
 #define DU_STORE_QKV_ROPE 2 /* the ViT's qkv projection stored head-major with RoPE: row m = (b, token t) of M = B * ps_H tokens, column
@@ -210,6 +213,11 @@ int du_qkv_rope_split(int dtype, const void* qkv, void* q, void* k, void* v, con
    rows a tile kernel left to the skinny tail when it wrote the rest through DU_STORE_QKV_ROPE). */
 int du_qkv_rope_split_rows(int dtype, const void* qkv_rows, void* q, void* k, void* v, const float* sin_t, const float* cos_t, int B, int N,
                            int Npad, int H, int Dh, int prefix, float qscale, int64_t m_begin, int m_count, void* stream);
+/* RoPE + q scale IN PLACE on head-major q / k planes (B, H, Npad, Dh) that du_gemm stored unrotated (DU_STORE_QKV_HEADS): the arithmetic of
+   du_qkv_rope_split on rows b * N + n < m_limit (rows at and behind m_limit were written, rotated, by du_qkv_rope_split_rows); bf16.
+   Replaces layers/attention.py:66-85 like du_qkv_rope_split. */
+int du_qkv_rope_inplace(int dtype, void* q, void* k, const float* sin_t, const float* cos_t, int B, int N, int Npad, int H, int Dh,
+                        int prefix, float qscale, int64_t m_limit, void* stream);
 /* Non-causal softmax2(q k^T) v per (b, head) with base-2 exponentials: q must be pre-scaled by
    Dh^-0.5 * log2(e).  q,k,v: (B, H, Npad, Dh) bf16; out: (B, N, H*Dh) bf16.  Dh in {64, 128}. */
 int du_attention_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int N, int Npad, int Dh,

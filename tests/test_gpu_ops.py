@@ -1227,6 +1227,43 @@ def test_vit_qkv_rope_in_gemm_epilogue(B, H, N, D):
     assert rel(out_u, ref) < 3e-2
 
 
+@pytest.mark.parametrize("B,H,N,D", [(8, 16, 1029, 1024), (2, 6, 1029, 384), (3, 12, 261, 768), (9, 16, 1029, 1024), (1, 16, 1024, 1024)])
+def test_vit_qkv_head_major_store_and_in_place_rope(B, H, N, D):
+    """Round 6 (opt-in, measured x0.993 in the step): the persistent kernel's drain stores q / k / v head-major (DU_STORE_QKV_HEADS: the
+    plain drain with another row offset) and du_qkv_rope_inplace rotates q and k where they lie -- against the plain product +
+    du_qkv_rope_split: v bit-identical (no arithmetic), q / k equal to the contraction order of one fused multiply-add (same bf16 rounding
+    of the projection, the same fp32 rotation), prefix rows, the rows behind the last full 256-row tile (du_qkv_rope_split_rows), tiles that
+    straddle samples (B = 9), no ragged rows at all (N = 1024)."""
+    from dinounet_amd import ops, _lib
+    d = dev()
+    bf = torch.bfloat16
+    Dh, prefix = 64, 5
+    h = q(gen(B * N, D, seed=1), bf)
+    w = q(gen(3 * H * Dh, D, seed=2, scale=D ** -0.5), bf)
+    bias = gen(3 * H * Dh, seed=3, scale=0.1)
+    ang = gen(N - prefix, Dh, seed=4)
+    sin, cos = torch.sin(ang), torch.cos(ang)
+    hd, wd, bd, sd, cd = h.to(d, bf), w.to(d, bf), bias.to(d), sin.to(d).contiguous(), cos.to(d).contiguous()
+    ws1, ws2 = {}, {}
+    heads_default = ops._QKV_HEADS
+    ops.TRACK_ROUTE, ops.ROUTES[:] = True, []
+    try:
+        ops._QKV_HEADS = True
+        _lib.lib().du_set_option(0, 4)       # (small shapes: the cost model is not asked -- the store mode exists on the persistent kernel only)
+        out_f = ops.qkv_attention(hd, wd, bd, sd, cd, B, N, H, Dh, prefix, ws1)
+    finally:
+        ops.TRACK_ROUTE = False
+        ops._QKV_HEADS = heads_default
+        _lib.lib().du_set_option(0, -1)
+    assert 6 in [r for _, _, r in ops.ROUTES], ops.ROUTES
+    out_u = ops.attention(ops.mm(hd, wd, bias=bd), sd, cd, B, N, H, Dh, prefix, ws2)
+    (k1,), (k2,) = ws1.keys(), ws2.keys()
+    assert torch.equal(ws1[k1][2][:, :, :N], ws2[k2][2][:, :, :N])          # v: stored, not computed
+    for name, a, b in zip("qk", ws1[k1], ws2[k2]):
+        assert rel(a[:, :, :N], b[:, :, :N]) < 4e-3, name                    # <= 1 bf16 ulp on a few elements (fma contraction)
+    assert rel(out_f, out_u) < 1e-2
+
+
 @pytest.mark.parametrize("B,H,hp,wp,D", [(8, 16, 32, 32, 1024), (2, 6, 32, 32, 384), (3, 12, 16, 24, 768), (9, 16, 32, 32, 1024)])
 def test_vit_qkv_rope_in_the_persistent_kernels_drain(B, H, hp, wp, D):
     """Round 6: RoPE + q scale + head-major store in the DRAIN of the persistent kernel (gemm_nt_pp_kernel<.., ROPE>): the rotation of

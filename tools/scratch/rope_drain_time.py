@@ -15,10 +15,16 @@ coords = torch.stack(torch.meshgrid(ch, cw, indexing="ij"), -1).flatten(0, 1)
 ang = (2 * math.pi * coords[:, :, None] / periods[None, None, :]).flatten(1, 2).tile(2)
 sin, cos = torch.sin(ang).to(dev).contiguous(), torch.cos(ang).to(dev).contiguous()
 ws = {}
-def fused(): return ops.qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, ws, grid=(hp, wp))
+def heads(): return ops.qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, ws)
+def drain():
+    ops._QKV_ROPE_DRAIN = True
+    try:
+        return ops.qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, ws, grid=(hp, wp))
+    finally:
+        ops._QKV_ROPE_DRAIN = False
 def unfused(): return ops.attention(ops.mm(h, w, bias=bias), sin, cos, B, N, H, Dh, prefix, ws)
 res = {}
-for name, fn in (("fused", fused), ("unfused", unfused)):
+for name, fn in (("heads+inplace", heads), ("rope in drain", drain), ("unfused", unfused)):
     fn(); torch.cuda.synchronize()
     gr = torch.cuda.CUDAGraph()
     with torch.cuda.graph(gr):
