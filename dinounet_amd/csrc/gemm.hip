@@ -361,9 +361,15 @@ extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
     const int route = a.dtype == DU_BF16 && a.a_mode == DU_PLAIN_COL && !DU_GETENV("DU_GEMM_GENERIC") ? du_gemm_route_bf16(a) : 0;
     if (route != 1 && route != 5) return DU_ERR_UNSUPPORTED;
   }
-  if (a.store_mode == DU_STORE_QKV_HEADS) {      // head-major qkv planes from the persistent kernel's drain, or nothing
+  if (a.store_mode == DU_STORE_QKV_HEADS) {      // head-major qkv planes from the persistent kernel's drain (ragged rows in the same launch), or nothing
     if (a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.split_k > 1) return DU_ERR_UNSUPPORTED;
-    return du_gemm_nt_p8(a, st);
+    const int r = du_gemm_ragged_rows(a);
+    if (r > 0) {
+      du_gemm_args head = a;
+      head.M = a.M - r;
+      return du_gemm_nt_p8(head, st, r);
+    }
+    return a.M % 256 ? DU_ERR_UNSUPPORTED : du_gemm_nt_p8(a, st);
   }
   if (a.store_mode == DU_STORE_QKV_ROPE) {       // fused RoPE + head split: the 256 x 128 multi-phase kernel or nothing
     if (a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.split_k > 1) return DU_ERR_UNSUPPORTED;

@@ -471,7 +471,15 @@ int du_gemm_tn_p8_splits(const du_gemm_args& a);
 // 0 = leave the product alone.
 int du_gemm_ragged_rows(const du_gemm_args& a) {
   static const bool off = DU_GETENV("DU_GEMM_NO_RAGGED_SPLIT") != nullptr;      // debugging / A-B aid
-  if (off || a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.store_mode != DU_STORE_PLAIN) return 0;
+  if (off || a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW) return 0;
+  if (a.store_mode == DU_STORE_QKV_HEADS) {      // head-major qkv planes: the ragged rows ride in the persistent kernel's launch or the product is declined
+    const int r = a.M % 256;
+    if (r < 1 || r > 64 || a.batch > 1 || a.split_k > 1) return 0;
+    du_gemm_args head = a;
+    head.M = a.M - r;
+    return du_gemm_p8_wants(head) && du_gemm_p8_tail_ok(a, r) ? r : 0;
+  }
+  if (a.store_mode != DU_STORE_PLAIN) return 0;
   if (a.act == DU_ACT_SWIGLU) return 0;      // the skinny kernels have no gate epilogue: the multi-phase kernel keeps the ragged rows
   if (a.batch > 1 || a.split_k > 1 || a.K % 64 || a.N < 96 || a.N % 4 || a.M < 1024 || a.lda % 8 || a.ldb % 8) return 0;
   {

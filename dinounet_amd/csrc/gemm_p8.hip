@@ -393,7 +393,9 @@ constexpr int P8_LDS = 256 * P8_STG_LDB * 2;   // 135 168 B >= 2 * BUF_B and >= 
 template <typename TC, int NW = 8>
 __device__ __forceinline__ void p8_tail(const GemmParams& P, unsigned char* smem, int unit = -1) {
   SkinnyEpi E;
+  E.qkv_H = 0; E.qkv_N = 0; E.qkv_Npad = 0;
   E.C = (TC*)P.C + (long)P.M * P.ldc; E.ldc = P.ldc;
+  if (P.store_mode == DU_STORE_QKV_HEADS) { E.C = P.C; E.qkv_H = P.ps_C; E.qkv_N = P.ps_H; E.qkv_Npad = P.ps_W; }
   E.residual = P.residual ? (const void*)((const TC*)P.residual + (long)P.M * P.ldr) : nullptr; E.ldr = P.ldr;
   E.bias = P.bias; E.gamma = P.gamma; E.row_scale = P.row_scale;
   E.alpha = P.alpha; E.act = P.act; E.rs_rows = P.rs_rows; E.out_bf16 = sizeof(TC) == 2; E.row0 = P.M;
@@ -2351,7 +2353,8 @@ bool du_gemm_p8_tail_ok(const du_gemm_args& whole, int r) {
   //  runs beside the stragglers of the tile grid and two ~5 us launch slots per block go away)
   static const int kmax = DU_GETENV("DU_SKINNY_FUSE_KMAX") ? atoi(DU_GETENV("DU_SKINNY_FUSE_KMAX")) : 4096;
   if (off || r < 1 || r > 64 || whole.K > kmax || whole.K % SK_CHUNK || whole.N % 4 || whole.batch > 1) return false;
-  if (whole.store_mode != DU_STORE_PLAIN || whole.act == DU_ACT_SWIGLU || whole.a_mode != DU_PLAIN_ROW || whole.b_mode != DU_PLAIN_ROW) return false;
+  if ((whole.store_mode != DU_STORE_PLAIN && whole.store_mode != DU_STORE_QKV_HEADS) || whole.act == DU_ACT_SWIGLU ||
+      whole.a_mode != DU_PLAIN_ROW || whole.b_mode != DU_PLAIN_ROW) return false;
   return 8 * 64 * (SK_BN + 1) * 4 <= P8_LDS;
 }
 

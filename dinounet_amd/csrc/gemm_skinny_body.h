@@ -12,6 +12,8 @@ struct SkinnyEpi {
   const float* bias; const float* gamma; const float* row_scale;
   float alpha; int act, rs_rows, out_bf16;
   int row0;        // first output row's index for row_scale (the tail sits behind the head's rows)
+  int qkv_H;       // > 0: DU_STORE_QKV_HEADS -- C is the base of the three head-major planes (ldc elements apart), row row0 + m = (b, token) of
+  int qkv_N, qkv_Npad;   //   qkv_N tokens per sample, column n = (which, head, d): element [which][b][head][token][d] (bf16, no residual)
 };
 
 constexpr int SK_BN = 32;          // output columns per workgroup
@@ -95,7 +97,14 @@ __device__ __forceinline__ void skinny_fused_body(const bf16_t* __restrict__ A, 
 #pragma unroll
       for (int e = 0; e < 4; e++) o[e] *= rs;
     }
-    if (P.out_bf16) {
+    if (P.qkv_H > 0) {
+      const int gm = P.row0 + m, b = gm / P.qkv_N, tk = gm - b * P.qkv_N;
+      const int hd = P.qkv_H * 64, which = nn / hd, rem = nn - which * hd;
+      bf16x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; e++) t[e] = (bf16_t)o[e];
+      *(uint2*)((bf16_t*)P.C + (long)which * P.ldc + (((long)b * P.qkv_H + (rem >> 6)) * P.qkv_Npad + tk) * 64 + (rem & 63)) = __builtin_bit_cast(uint2, t);
+    } else if (P.out_bf16) {
       if (P.residual) {
         const bf16_t* rp = (const bf16_t*)P.residual + (long)m * P.ldr + nn;
 #pragma unroll

@@ -2341,9 +2341,10 @@ _QKV_FUSED = _ab_env("DINOUNET_QKV_FUSED", "0") == "1"
 # SLOWER than the plain persistent product + du_qkv_rope_split: x0.995 in the step (profiles/r06_ab_rope_drain_v1.txt) -- the drain has no
 # registers for the 16-byte store form (it spills), and sixteen 8-byte stores per lane and tile cost more than the 21 us pass saves.  Opt-in.
 _QKV_ROPE_DRAIN = _ab_env("DINOUNET_QKV_ROPE_DRAIN", "0") == "1"
-# round 6: head-major store from the persistent kernel's drain (DU_STORE_QKV_HEADS) + du_qkv_rope_inplace: 67 MB of RoPE traffic instead of
-# 101 MB -- and x0.993 in the step (profiles/r06_ab_qkv_heads_v1.txt; alone 140 vs 127-140 us per qkv + rope + attention).  Opt-in.
-_QKV_HEADS = _ab_env("DINOUNET_QKV_HEADS", "0") == "1"
+# round 6: head-major store from the persistent kernel's drain (DU_STORE_QKV_HEADS, the ragged rows in the same launch) + du_qkv_rope_inplace:
+# 67 MB of RoPE traffic instead of 101 MB.  x1.0041 in the step (profiles/r06_ab_qkv_heads_v2.txt); a first form that ran the 40 ragged
+# rows as a product of their own + du_qkv_rope_split_rows measured x0.993 (r06_ab_qkv_heads_v1.txt: two more launches per block).
+_QKV_HEADS = _ab_env("DINOUNET_QKV_HEADS", "1") == "1"
 
 
 def qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, workspace, grid=None):
@@ -2365,23 +2366,18 @@ def qkv_attention(h, w, bias, sin, cos, B, N, H, Dh, prefix, workspace, grid=Non
             workspace[key] = torch.zeros((3, B, H, Npad, Dh), dtype=dt, device=h.device)
         qkv3 = workspace[key]
         q, k, v = qkv3
-        r = M % 256
-        M0 = M - r
         qscale = Dh ** -0.5 * math.log2(math.e)
         _, _, lda = _rows2d(h)
         Nw, _, ldb = _rows2d(w)
-        kw = dict(dtype=DU_BF16, out_dtype=DU_BF16, a_mode=PLAIN_ROW, b_mode=PLAIN_ROW, M=M0, N=Nw, K=D, A=h.data_ptr(), lda=lda,
+        # (the <= 64 rows behind the last full 256-row tile ride in the same launch: du_gemm's tail units store head-major too)
+        kw = dict(dtype=DU_BF16, out_dtype=DU_BF16, a_mode=PLAIN_ROW, b_mode=PLAIN_ROW, M=M, N=Nw, K=D, A=h.data_ptr(), lda=lda,
                   B=w.data_ptr(), ldb=ldb, Cmat=qkv3.data_ptr(), ldc=B * H * Npad * Dh, bias=_dp(bias), store_mode=STORE_QKV_HEADS,
                   ps=(N, Npad, H))
-        if Nw == 3 * H * Dh and M0 > 0 and gemm_route(**kw) == 6:
+        if Nw == 3 * H * Dh and gemm_route(**kw) == 6:
             gemm_raw(**kw)
             L = _lib.lib()
-            _lib.check(L.du_qkv_rope_inplace(DU_BF16, _p(q), _p(k), _p(sin), _p(cos), B, N, Npad, H, Dh, prefix, qscale, M0, _st()),
+            _lib.check(L.du_qkv_rope_inplace(DU_BF16, _p(q), _p(k), _p(sin), _p(cos), B, N, Npad, H, Dh, prefix, qscale, M, _st()),
                        "du_qkv_rope_inplace")
-            if r:
-                tail = mm(h[M0:], w, bias=bias)
-                _lib.check(L.du_qkv_rope_split_rows(DU_BF16, _p(tail), _p(q), _p(k), _p(v), _p(sin), _p(cos), B, N, Npad, H, Dh, prefix,
-                                                    qscale, M0, r, _st()), "du_qkv_rope_split_rows")
             out = torch.empty((M, H * Dh), dtype=dt, device=h.device)
             e0 = PROFILE.start() if PROFILE is not None else None
             _lib.check(L.du_attention_fwd(_p(q), _p(k), _p(v), _p(out), B, H, N, Npad, Dh, _st()), "du_attention_fwd")
