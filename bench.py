@@ -292,6 +292,21 @@ def north_star_targets(prof, steps=1):
     return out
 
 
+def _pmc_match(tag, trace_name):
+    """does a rocprofv3 kernel name belong to the profile family `tag` (ops.KernelProfile)?  The persistent kernel's instantiations with a
+    residual (template argument RES != 0, incl. the ConvTranspose + skip form) are the `+res` family: HBM-bound products that must not be
+    averaged into the plain family's traffic."""
+    import re
+    key = tag.split("<")[0]
+    if key not in trace_name:
+        return False
+    if key == "gemm_nt_pp_kernel":
+        m = re.search(r"gemm_nt_pp_kernel<\s*(\d+),\s*(true|false),\s*(\d+)", trace_name)
+        if m:
+            return (m.group(3) != "0") == ("+res" in tag)
+    return True
+
+
 def pmc_traffic(roof):
     """roofline.traffic = memory-side bytes per launch of the dominant kernel, from rocprofv3 PMC passes of this same command
     (tools/pmc_traffic.py: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate runs of `bench.py --graph off`; counters cannot be
@@ -315,7 +330,7 @@ def pmc_traffic(roof):
         calls, kb = 0, 0.0
         for line in lines:
             f = line.split(None, 2)
-            if len(f) == 3 and f[0].isdigit() and key in f[2]:
+            if len(f) == 3 and f[0].isdigit() and _pmc_match(roof.get("kernel", ""), f[2]):
                 calls += int(f[0]); kb += int(f[0]) * float(f[1])
         if not calls:
             return
@@ -345,7 +360,7 @@ def pmc_cycles(roof):
                 break
             continue
         f = line.replace("|", " ").split()
-        if len(f) >= 12 and f[0].isdigit() and key in line:
+        if len(f) >= 12 and f[0].isdigit() and _pmc_match(roof.get("kernel", ""), line):
             try:
                 vals = [float(f[i]) for i in (2, 3, 5, 6, 7)]          # parked, stall, issue, mfma, valu
             except ValueError:
