@@ -286,3 +286,36 @@ def test_dinounet_two_ranks_syncbn_through_the_adapter_matches_full_batch():
     for k, v in full[3].items():
         for r in range(2):
             assert torch.allclose(ranks[r][3][k], v, rtol=1e-4, atol=1e-6), (k, r)
+
+
+def _mode_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from dinounet_amd.training import TrainStep
+        ts = TrainStep(nn.Linear(2, 2), None, [], (1, 3, 8, 8), (1, 1, 8, 8), torch.device("cpu"), reducer=object(), graph=False)
+        # rank 1's capture "fails" in the first round, both succeed in the second, both fail in the third
+        res = [ts._all_ranks(rank == 0), ts._all_ranks(True), ts._all_ranks(False)]
+        q.put((rank, res))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "ERR " + traceback.format_exc()))
+
+
+def test_capture_mode_is_a_collective_decision_world2():
+    """a rank whose whole-step capture failed must not fall back alone -- segmented replays issue the bucket all-reduces
+    in bucket-index order, whole-step / eager steps in hook-ready order, so mixed modes hang or sum the wrong buckets.  TrainStep._all_ranks
+    is MIN over the ranks of 'my capture worked': a rank that succeeded where another failed gets False too."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_mode_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+    for r in range(2):
+        assert got[r] == [False, True, False], got

@@ -162,6 +162,29 @@ def test_gemm_multiphase_nt(mode, M, N, K, f32out, epi):
 
 
 @pytest.mark.parametrize("inline", [0, 1])
+def test_gemm_persistent_residual_in_place():
+    """The residual of the persistent kernel's residual form may BE the output buffer (y = y + f(x), in place): a tile reads its residual
+    rows through the staging ring during its own K-steps and stores them in the drain of the NEXT tile, other tiles touch other rows /
+    columns.  Same result as the out-of-place call, bit for bit."""
+    from dinounet_amd import ops, _lib
+    d = dev()
+    bf = torch.bfloat16
+    M, N, K = 43008, 1024, 256
+    x, w = q(gen(M, K, seed=1), bf).to(d, bf), q(gen(N, K, seed=2, scale=K ** -0.5), bf).to(d, bf)
+    b = gen(N, seed=3).to(d)
+    res = q(gen(M, N, seed=5), bf).to(d, bf)
+    rs = (torch.arange(M // 5376, device=d) % 3 != 0).float() / 0.7
+    ops.TRACK_ROUTE = True
+    try:
+        want = ops.mm(x, w, bias=b, residual=res, row_scale=rs, rs_rows=5376)
+        assert ops.LAST_GEMM_ROUTE == 6, ops.LAST_GEMM_ROUTE
+        buf = res.clone()
+        got = ops.mm(x, w, bias=b, residual=buf, out=buf, row_scale=rs, rs_rows=5376)
+    finally:
+        ops.TRACK_ROUTE = False
+    assert got.data_ptr() == buf.data_ptr() and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("N,K", [(1024, 1024), (3072, 1024), (1024, 4096)])
 def test_gemm_ragged_tail_split(N, K, inline):
     """The ViT-L products (M = 8 * 1029 = 64 * 128 + 40): for proj / fc2 the last 40 rows leave the tile grid and run on the K-parallel
