@@ -161,7 +161,6 @@ def test_gemm_multiphase_nt(mode, M, N, K, f32out, epi):
         assert torch.equal(outs[0], ref2)
 
 
-@pytest.mark.parametrize("inline", [0, 1])
 def test_gemm_persistent_residual_in_place():
     """The residual of the persistent kernel's residual form may BE the output buffer (y = y + f(x), in place): a tile reads its residual
     rows through the staging ring during its own K-steps and stores them in the drain of the NEXT tile, other tiles touch other rows /
@@ -185,6 +184,7 @@ def test_gemm_persistent_residual_in_place():
     assert got.data_ptr() == buf.data_ptr() and torch.equal(got, want)
 
 
+@pytest.mark.parametrize("inline", [0, 1])
 @pytest.mark.parametrize("N,K", [(1024, 1024), (3072, 1024), (1024, 4096)])
 def test_gemm_ragged_tail_split(N, K, inline):
     """The ViT-L products (M = 8 * 1029 = 64 * 128 + 40): for proj / fc2 the last 40 rows leave the tile grid and run on the K-parallel
