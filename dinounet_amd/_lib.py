@@ -13,7 +13,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "dinounet_hip.h")
 DU_F32, DU_BF16 = 0, 1
 PLAIN_ROW, PLAIN_COL, IM2COL_ROW, IM2COL_COL = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LEAKY, ACT_SWIGLU = 0, 1, 2, 3, 4
-STORE_PLAIN, STORE_PIXEL_SHUFFLE2, STORE_QKV_ROPE, STORE_SLABS, STORE_QKV_HEADS = 0, 1, 2, 4, 5
+STORE_PLAIN, STORE_PIXEL_SHUFFLE2, STORE_QKV_ROPE, STORE_SLABS, STORE_QKV_HEADS, STORE_MSDA_PREP = 0, 1, 2, 4, 5, 6
 ERRORS = {-1: "DU_ERR_BAD_ARG", -2: "DU_ERR_UNSUPPORTED", -3: "DU_ERR_LAUNCH"}
 
 
@@ -36,7 +36,7 @@ class GemmArgs(C.Structure):
                 ("store_mode", C.c_int32), ("ps_H", C.c_int32), ("ps_W", C.c_int32), ("ps_C", C.c_int32),
                 ("geom", ConvGeom), ("ws", C.c_void_p), ("ws_elems", C.c_int64),
                 ("rope_sin", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_prefix", C.c_int32), ("rope_qscale", C.c_float),
-                ("a_colsum", C.c_void_p), ("b_colsum", C.c_void_p)]
+                ("a_colsum", C.c_void_p), ("b_colsum", C.c_void_p), ("C2", C.c_void_p)]
 
 
 class TnJob(C.Structure):

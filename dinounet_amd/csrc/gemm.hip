@@ -361,6 +361,10 @@ extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
     const int route = a.dtype == DU_BF16 && a.a_mode == DU_PLAIN_COL && !DU_GETENV("DU_GEMM_GENERIC") ? du_gemm_route_bf16(a) : 0;
     if (route != 1 && route != 5) return DU_ERR_UNSUPPORTED;
   }
+  if (a.store_mode == DU_STORE_MSDA_PREP) {      // sampling locations + attention weights from the 256 x 256 kernel's epilogue, or nothing
+    if (a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.split_k > 1) return DU_ERR_UNSUPPORTED;
+    return du_gemm_nt_p8(a, st);
+  }
   if (a.store_mode == DU_STORE_QKV_HEADS) {      // head-major qkv planes from the persistent kernel's drain (ragged rows in the same launch), or nothing
     if (a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.split_k > 1) return DU_ERR_UNSUPPORTED;
     const int r = du_gemm_ragged_rows(a);

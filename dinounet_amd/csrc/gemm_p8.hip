@@ -375,6 +375,38 @@ __device__ __forceinline__ void readout_f32_any(const GemmParams& P, const float
   else if (P.act == DU_ACT_GELU) readout_f32<TC, TBN, DU_ACT_GELU, 4, NTHR>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
   else readout_f32<TC, TBN, -1, 4, NTHR>(P, stg, ldf, nrows, mrow0, n0, Cb, Rb, tid);
 }
+// DU_STORE_MSDA_PREP: rows of the fp32 staging tile = [heads x 8 offsets | heads x 4 logits] of MSDeformAttn's offsets | weights product
+// (ms_deform_attn.py:188-197): + bias, loc = ref[m % Lq] + offset / (W, H), attn = softmax over the 4 points -- the arithmetic of
+// msda_prep_kernel (elementwise.hip), one (row, head) per thread and trip; the matrix itself is never written
+template <int NTHR = 512>
+__device__ __forceinline__ void readout_msda_prep(const GemmParams& P, const float* stg, int ldf, int nrows, int mrow0, int tid) {
+  const int Mh = P.N / 12, Lq = P.ps_C;
+  const float invW = 1.0f / (float)P.ps_W, invH = 1.0f / (float)P.ps_H;
+  float* loc = (float*)P.C;
+  for (int v = tid; v < nrows * Mh; v += NTHR) {
+    const int row = v / Mh, h = v - row * Mh;
+    const int m = mrow0 + row;
+    if (m >= P.M) continue;
+    const int q = m % Lq;
+    const float rx = P.rope_sin[q * 2], ry = P.rope_sin[q * 2 + 1];
+    const float* so = stg + row * ldf + h * 8;
+    const float* sl = stg + row * ldf + Mh * 8 + h * 4;
+    float off[8], lg[4];
+#pragma unroll
+    for (int e = 0; e < 8; e++) off[e] = so[e] + (P.bias ? P.bias[h * 8 + e] : 0.f);
+#pragma unroll
+    for (int e = 0; e < 4; e++) lg[e] = sl[e] + (P.bias ? P.bias[Mh * 8 + h * 4 + e] : 0.f);
+    const float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+    float ex[4], sm = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { ex[e] = expf(lg[e] - mx); sm += ex[e]; }
+    const float inv = 1.f / sm;
+    float* lo = loc + ((long)m * Mh + h) * 8;
+    *(float4*)lo = make_float4(rx + off[0] * invW, ry + off[1] * invH, rx + off[2] * invW, ry + off[3] * invH);
+    *(float4*)(lo + 4) = make_float4(rx + off[4] * invW, ry + off[5] * invH, rx + off[6] * invW, ry + off[7] * invH);
+    *(float4*)(P.C2 + ((long)m * Mh + h) * 4) = make_float4(ex[0] * inv, ex[1] * inv, ex[2] * inv, ex[3] * inv);
+  }
+}
 // bf16 result whose epilogue is bias (+ GELU) only: staged as bf16 (the ViT's qkv and fc1)
 __device__ __forceinline__ bool bf16_simple(const GemmParams& P, const void* Rb) {
   return !Rb && !P.gamma && !P.row_scale && P.alpha == 1.0f && (P.act == DU_ACT_NONE || P.act == DU_ACT_GELU || P.act == DU_ACT_SWIGLU);
@@ -913,6 +945,9 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
         for (int b = 0; b < 2; b++)
           stage_block_f32(acc[i][j][b], stg, P8_STG_LDF, wm * 64 + b * 32 + (lane & 31), j * 128 + wn * 32, lane);
       __syncthreads();
+      if constexpr (sizeof(TC) == 4 && !TN && !GA) {
+        if (P.store_mode == DU_STORE_MSDA_PREP) { readout_msda_prep(P, stg, P8_STG_LDF, 128, m0 + i * 128, tid); continue; }
+      }
       readout_f32_any<TC, PBN>(P, stg, P8_STG_LDF, 128, m0 + i * 128, n0, Cb, Rb, tid);
     }
   }
@@ -2227,6 +2262,11 @@ static bool p8_gather_legal(const du_gemm_args& a) {
 static bool p8_legal(const du_gemm_args& a) {
   if (a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW || a.dtype != DU_BF16) return false;
   if (a.split_k > 1) return false;
+  if (a.store_mode == DU_STORE_MSDA_PREP) {       // offsets | weights product with the sampling-location / softmax epilogue: one tile column
+    if (a.out_dtype != DU_F32 || a.residual || a.gamma || a.row_scale || a.alpha != 1.0f || a.act != DU_ACT_NONE || a.batch > 1) return false;
+    if (a.N % 12 || a.N > 256 || a.ps_H <= 0 || a.ps_W <= 0 || a.ps_C <= 0 || !a.rope_sin || !a.C2) return false;
+    if ((((uintptr_t)a.C) | ((uintptr_t)a.C2)) & 15) return false;
+  } else
   if (a.store_mode == DU_STORE_QKV_ROPE || a.store_mode == DU_STORE_QKV_HEADS) {       // bias-only bf16 epilogue, d_head 64
     if (a.out_dtype != DU_BF16 || a.residual || a.gamma || a.row_scale || a.alpha != 1.0f || a.act != DU_ACT_NONE || a.batch > 1) return false;
     if (a.ps_H <= 0 || a.ps_W < a.ps_H || a.ps_C <= 0 || a.N != 3 * a.ps_C * 64 || a.ldc % 8 || (((uintptr_t)a.C) & 15)) return false;
@@ -2281,6 +2321,7 @@ int du_gemm_p8_choice(const du_gemm_args& a) {
   if (g_p8_mode != 0 && g_p8_tn && p8_gather_legal(a))      // ConvT data gradient: 256 x 256 tiles once they fill most of the CUs
     return (g_p8_mode > 0 || (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 192) ? 1 : 0;
   if (g_p8_mode == 0 || !p8_legal(a)) return 0;
+  if (a.store_mode == DU_STORE_MSDA_PREP) return 1;                                            // the 256 x 256 kernel's fp32 staging epilogue or nothing
   if (a.store_mode == DU_STORE_QKV_HEADS) return (g_p8_mode != 0 && pp_legal(a)) ? 4 : 0;      // the persistent kernel or nothing
   if (a.store_mode == DU_STORE_QKV_ROPE) {     // round 6: on the persistent kernel (RoPE in the drain) where a CU gets >= 2 tiles, else 256 x 128
     const long t = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);

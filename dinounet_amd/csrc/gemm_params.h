@@ -30,6 +30,7 @@ struct GemmParams {
   int k_scale;            // weight-gradient form (A contraction-major): row_scale[k / rs_rows] scales the CONTRACTION rows of A, not output rows
   int tail_rows;          // gemm_p8.hip NT kernels: rows [M, M + tail_rows) (<= 64) are computed by the workgroups behind the first main_wgs
   int main_wgs;           //   ones (skinny_fused_body, gemm_skinny_body.h); 0 = no tail in this launch
+  float* C2;              // DU_STORE_MSDA_PREP: the attention weights (C = the sampling locations)
 };
 
 // element offset of C / residual element (m, n) for row stride ld: plain rows, or the pixel-shuffle store of ConvTranspose2d k2 s2
@@ -120,6 +121,7 @@ inline GemmParams make_params(const du_gemm_args& a, int amode, int bmode, int B
   P.store_mode = a.store_mode; P.ps_H = a.ps_H; P.ps_W = a.ps_W; P.ps_C = a.ps_C;
   P.a_colsum = a.a_colsum; P.b_colsum = a.b_colsum;
   P.rope_sin = a.rope_sin; P.rope_cos = a.rope_cos; P.rope_prefix = a.rope_prefix; P.rope_qscale = a.rope_qscale;
+  P.C2 = a.C2;
   P.k_scale = (amode == DU_PLAIN_COL && a.row_scale) ? 1 : 0;
   P.tiles_n = (a.N + BN - 1) / BN;
   (void)BM;

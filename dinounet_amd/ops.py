@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SWIGLU, DU_BF16, DU_F32, IM2COL_COL, IM2COL_ROW, PLAIN_COL,
-                   PLAIN_ROW, STORE_PIXEL_SHUFFLE2, STORE_QKV_HEADS, STORE_QKV_ROPE, STORE_SLABS, ConvGeom, GemmArgs)
+                   PLAIN_ROW, STORE_MSDA_PREP, STORE_PIXEL_SHUFFLE2, STORE_QKV_HEADS, STORE_QKV_ROPE, STORE_SLABS, ConvGeom, GemmArgs)
 
 __all__ = ["mm", "linear", "conv2d", "conv_transpose2x2", "norm_act", "layer_norm", "msda", "dwconv3x3",
            "maxpool3x3s2", "bilinear_add", "bilinear_resize", "squeeze_excite", "dice_ce_loss"]
@@ -186,7 +186,7 @@ ROUTES = []                  # (a_mode, b_mode, route) of every product since TR
 
 def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat, ldc, batch=1, abs_=0, bbs=0, cbs=0,
              split_k=1, alpha=1.0, bias=None, act=ACT_NONE, gamma=None, row_scale=None, rs_rows=0, residual=None, ldr=0,
-             store_mode=0, ps=(0, 0, 0), geom=None, a_colsum=None, b_colsum=None, rope=None, route_only=False):
+             store_mode=0, ps=(0, 0, 0), geom=None, a_colsum=None, b_colsum=None, rope=None, c2=None, route_only=False):
     a = GemmArgs()
     a.dtype, a.out_dtype, a.a_mode, a.b_mode = dtype, out_dtype, a_mode, b_mode
     a.M, a.N, a.K = M, N, K
@@ -205,6 +205,7 @@ def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat,
         a.geom = geom
     a.a_colsum = a_colsum
     a.b_colsum = b_colsum
+    a.C2 = c2
     if rope is not None:
         a.rope_sin, a.rope_cos, a.rope_prefix, a.rope_qscale = rope
     if route_only:
@@ -1296,7 +1297,8 @@ class _LinearCat(torch.autograd.Function):
         return (*_linear_cat_bwd(ctx, dyc), None)
 
 
-def _linear_cat_fwd(ctx, x, w1, w2, b1, b2, out_dtype):
+def _linear_cat_fwd(ctx, x, w1, w2, b1, b2, out_dtype, product=None):
+    """product: callable(x, wq, bq) -> result instead of the plain mm (ops._OffsetsPrep: the product with the msda_prep epilogue)"""
     n1 = w1.shape[0]
     wq = PACK.get((w1.reshape(n1, -1), w2.reshape(w2.shape[0], -1)), PK_CAST, x.dtype)
     if wq is None:
@@ -1306,7 +1308,7 @@ def _linear_cat_fwd(ctx, x, w1, w2, b1, b2, out_dtype):
         bq = PACK.get((b1, b2), PK_CAST, torch.float32)
         if bq is None:
             bq = torch.cat([b1, b2], 0).float()
-    y = mm(x, wq, bias=bq, out_dtype=out_dtype)
+    y = mm(x, wq, bias=bq, out_dtype=out_dtype) if product is None else product(x, wq, bq)
     # [w1; w2]^T from the weight pack: the data gradient becomes a contraction-contiguous product (see _Linear)
     ctx.wT = None
     if _DGRAD_NT and w1.dtype != x.dtype and (n1 + w2.shape[0]) % 64 == 0:
@@ -1896,6 +1898,9 @@ def msda_prep(raw, ref, Lq, M, P, Hs, Ws):
     return _MSDAPrep.apply(raw, ref, Lq, M, P, Hs, Ws)
 
 
+_MSDA_PREP_FUSED = _ab_env("DINOUNET_MSDA_PREP_FUSED", "1") == "1"
+
+
 class _OffsetsPrep(torch.autograd.Function):
     """MSDeformAttn's sampling_offsets + attention_weights product (ms_deform_attn.py:188-189, fp32 result as the reference's
     custom_fwd(cast_inputs=fp32), :30) and msda_prep (:190-197) as ONE autograd node: the fp32 (rows, M*P*3) matrix is an internal buffer,
@@ -1905,13 +1910,31 @@ class _OffsetsPrep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, w2, b1, b2, ref, Lq, M, P, Hs, Ws):
-        raw = _linear_cat_fwd(ctx, x, w1, w2, b1, b2, torch.float32)
-        rows, ncol, ld = _rows2d(raw)
-        assert ncol == M * P * 3
-        loc = torch.empty((rows, M, P, 2), dtype=torch.float32, device=raw.device)
-        attn = torch.empty((rows, M, P), dtype=torch.float32, device=raw.device)
-        _lib.check(_lib.lib().du_msda_prep(_code(raw.dtype), _p(raw), ld, _p(ref), _p(loc), _p(attn), rows, Lq, M, P, Hs, Ws, _st()),
-                   "du_msda_prep")
+        rows = x.shape[0]
+        ncol = M * P * 3
+        loc = torch.empty((rows, M, P, 2), dtype=torch.float32, device=x.device)
+        attn = torch.empty((rows, M, P), dtype=torch.float32, device=x.device)
+
+        def product(xm, wq, bq):
+            # round 6: the reference-point / softmax step in the product's epilogue (DU_STORE_MSDA_PREP): the (rows, M*P*3) fp32 matrix is
+            # never written; where the library declines (another kernel family for this shape), the plain product + du_msda_prep
+            _, K, lda = _rows2d(xm)
+            Nw, _, ldb = _rows2d(wq)
+            if _MSDA_PREP_FUSED and P == 4 and xm.dtype == torch.bfloat16 and Nw == ncol:
+                kw = dict(dtype=DU_BF16, out_dtype=DU_F32, a_mode=PLAIN_ROW, b_mode=PLAIN_ROW, M=rows, N=Nw, K=K, A=xm.data_ptr(), lda=lda,
+                          B=wq.data_ptr(), ldb=ldb, Cmat=loc.data_ptr(), ldc=Nw, bias=_dp(bq), store_mode=STORE_MSDA_PREP, ps=(Hs, Ws, Lq),
+                          rope=(ref.data_ptr(), None, 0, 1.0), c2=attn.data_ptr())
+                if gemm_route(**kw) == 3:
+                    gemm_raw(**kw)
+                    return None
+            raw = mm(xm, wq, bias=bq, out_dtype=torch.float32)
+            _, _, ld = _rows2d(raw)
+            _lib.check(_lib.lib().du_msda_prep(_code(raw.dtype), _p(raw), ld, _p(ref), _p(loc), _p(attn), rows, Lq, M, P, Hs, Ws, _st()),
+                       "du_msda_prep")
+            return None
+
+        assert w1.shape[0] + w2.shape[0] == ncol
+        _linear_cat_fwd(ctx, x, w1, w2, b1, b2, torch.float32, product=product)
         xs, wq = ctx.lc_saved
         ctx.lc_saved = None
         ctx.save_for_backward(xs, wq, attn)

@@ -74,6 +74,11 @@ extern "C" {
 #define DU_STORE_QKV_HEADS 5 /* as DU_STORE_QKV_ROPE without the rotation and the q scale: the projection (+ bias) stored head-major in the
                                three planes (ps_H / ps_W / ps_C as there), rotated afterwards where it lies by du_qkv_rope_inplace.  Served by the
                                persistent multi-phase kernel only (M % 256 == 0, K >= 384; DU_ERR_UNSUPPORTED otherwise) */
+#define DU_STORE_MSDA_PREP 6 /* MSDeformAttn's sampling_offsets | attention_weights product (ms_deform_attn.py:188-197) with the reference-point /
+                               softmax step in the epilogue: N = heads * 12 columns = [heads x 4 points x (x, y) offsets | heads x 4 logits] (+ bias),
+                               fp32; instead of the matrix, C receives the sampling locations (M, heads, 4, 2) = ref[m % ps_C] + offset / (ps_W,
+                               ps_H) and C2 the softmax over the 4 points (M, heads, 4); rope_sin = ref (ps_C, 2) fp32.  Served by the 256 x 256
+                               multi-phase kernel only (N <= 256, K % 128 == 0; DU_ERR_UNSUPPORTED otherwise: du_msda_prep on the plain result) */
 #define DU_STORE_TAPS 3 /* grouped convolution weight gradients only (du_gemm_tn_group: du_tn_job.taps): column n = (tap, c) of the product is
                            element (m, c, tap) of a torch-layout weight gradient */
 #define DU_STORE_QKV_ROPE 2 /* the ViT's qkv projection stored head-major with RoPE: row m = (b, token t) of M = B * ps_H tokens, column
@@ -130,6 +135,7 @@ typedef struct {
                          b_colsum[n % geom.C] += sum_k B(n, k) -- every dY pixel appears exactly once among the (input pixel, tap) pairs, so
                          this is the bias gradient sum_pixels dY[.., co]; same contract as a_colsum (zero-initialised, atomics,
                          DU_ERR_UNSUPPORTED unless du_gemm_route is 1 or 5) */
+  float* C2;          /* DU_STORE_MSDA_PREP only: the second result (attention weights) */
 } du_gemm_args;
 
 int du_gemm(const du_gemm_args* args, void* stream);
