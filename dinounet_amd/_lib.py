@@ -36,7 +36,7 @@ class GemmArgs(C.Structure):
                 ("store_mode", C.c_int32), ("ps_H", C.c_int32), ("ps_W", C.c_int32), ("ps_C", C.c_int32),
                 ("geom", ConvGeom), ("ws", C.c_void_p), ("ws_elems", C.c_int64),
                 ("rope_sin", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_prefix", C.c_int32), ("rope_qscale", C.c_float),
-                ("a_colsum", C.c_void_p), ("b_colsum", C.c_void_p), ("C2", C.c_void_p)]
+                ("a_colsum", C.c_void_p), ("b_colsum", C.c_void_p), ("C2", C.c_void_p), ("ks_ws", C.c_void_p), ("ks_ws_bytes", C.c_int64)]
 
 
 class TnJob(C.Structure):

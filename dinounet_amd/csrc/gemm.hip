@@ -313,6 +313,13 @@ extern "C" int64_t du_gemm_ws_elems(const du_gemm_args* pa) {
   return du_gemm_ragged_rows(*pa) > 0 ? du_gemm_skinny_ws_elems(pa->N, pa->K) : 0;
 }
 
+long du_gemm_ks_bytes_bf16(const du_gemm_args& a);              // gemm_bf16.hip
+extern "C" int64_t du_gemm_ks_ws_bytes(const du_gemm_args* pa) {
+  if (!pa) return 0;
+  static const bool generic = DU_GETENV("DU_GEMM_GENERIC") != nullptr;
+  return generic ? 0 : du_gemm_ks_bytes_bf16(*pa);
+}
+
 extern "C" int du_gemm(const du_gemm_args* pa, void* stream) {
   if (!pa) return DU_ERR_BAD_ARG;
   const du_gemm_args& a = *pa;

@@ -504,6 +504,22 @@ int du_gemm_ragged_rows(const du_gemm_args& a) {
   return r;
 }
 
+long du_gemm_p8_ks_bytes(const du_gemm_args& a);               // gemm_p8.hip
+long du_gemm_p8_tail_bytes(const du_gemm_args& whole);
+long du_gemm_ks_bytes_bf16(const du_gemm_args& a) {
+  if (a.dtype != DU_BF16 || a.a_mode != DU_PLAIN_ROW || a.b_mode != DU_PLAIN_ROW) return 0;
+  du_gemm_args head = a;
+  head.ks_ws = nullptr; head.ks_ws_bytes = 0;      // (the ragged-row rule must not depend on the scratch being asked about)
+  int r = a.M % 256;
+  if (r < 1 || r > 64 || !du_gemm_p8_tail_ok(a, r)) r = 0;
+  head.M = a.M - r;
+  const long pair = du_gemm_p8_ks_bytes(head);
+  // (the sliced units exist in the one-shot tile kernels' launches: choice 1 / 2)
+  const int c = r > 0 ? du_gemm_p8_choice(head) : 0;
+  const long tail = (c == 1 || c == 2) ? du_gemm_p8_tail_bytes(a) : 0;
+  return pair > tail ? pair : tail;
+}
+
 // large contraction-contiguous products: the 256 x 256 multi-phase kernel where it pays, else the 128 x 128 direct-to-LDS kernel
 static int nt_tiles(const du_gemm_args& a, hipStream_t st) {
   if (du_gemm_p8_wants(a)) {
@@ -582,6 +598,7 @@ int du_gemm_route_bf16(const du_gemm_args& a) {
   const int r = du_gemm_ragged_rows(a);
   if (r > 0) head.M = a.M - r;
   const int c = du_gemm_p8_choice(head);
+  if (c == 5) return 8;      // (2 + c = 7 is the resident-weights kernel)
   if (c) return 2 + c;
   return du_gemm_glds_serves(head) ? 2 : 1;
 }

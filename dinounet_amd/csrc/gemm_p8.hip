@@ -70,6 +70,7 @@ template <> struct Out4p<bf16_t> {
   }
 };
 
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int N> struct IC { static constexpr int value = N; };
 
 __device__ __forceinline__ void wait_vm_count(int n) {      // n = LDS-DMA instructions that may stay in flight (even, <= 12)
@@ -86,8 +87,11 @@ __device__ __forceinline__ void wait_vm_count(int n) {      // n = LDS-DMA instr
 
 // XCD-aware tile order shared by both kernels: an XCD owns a run of tiles; inside it bands of group_m tile rows are walked column
 // by column so the ~32 resident tiles of an XCD share few A / B panels through its L2.
+__device__ __forceinline__ void tile_coords_of(const GemmParams& P, int nwg, int bid, int& tm, int& tn);
 __device__ __forceinline__ void tile_coords(const GemmParams& P, int& tm, int& tn) {
-  const int nwg = P.main_wgs ? P.main_wgs : (int)gridDim.x, bid = blockIdx.x;
+  tile_coords_of(P, P.main_wgs ? P.main_wgs : (int)gridDim.x, blockIdx.x, tm, tn);
+}
+__device__ __forceinline__ void tile_coords_of(const GemmParams& P, int nwg, int bid, int& tm, int& tn) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;     // bijective
   if (P.group_m > 1) {
@@ -422,7 +426,7 @@ constexpr int P8_LDS = 256 * P8_STG_LDB * 2;   // 135 168 B >= 2 * BUF_B and >= 
 // 32 x 256 + 40 rows): workgroups behind the main tiles run the K-parallel skinny program on rows [P.M, P.M + tail_rows).  They are
 // dispatched when the first tiles retire and overlap the stragglers; as launches of their own the 40-row tails cost ~8 us each, 72 of
 // them per dinounet_l step (profiles/r02_launch_counts_v5.txt).
-template <typename TC, int NW = 8>
+template <typename TC, int NW = 8, bool SL = false>
 __device__ __forceinline__ void p8_tail(const GemmParams& P, unsigned char* smem, int unit = -1) {
   SkinnyEpi E;
   E.qkv_H = 0; E.qkv_N = 0; E.qkv_Npad = 0;
@@ -431,8 +435,19 @@ __device__ __forceinline__ void p8_tail(const GemmParams& P, unsigned char* smem
   E.residual = P.residual ? (const void*)((const TC*)P.residual + (long)P.M * P.ldr) : nullptr; E.ldr = P.ldr;
   E.bias = P.bias; E.gamma = P.gamma; E.row_scale = P.row_scale;
   E.alpha = P.alpha; E.act = P.act; E.rs_rows = P.rs_rows; E.out_bf16 = sizeof(TC) == 2; E.row0 = P.M;
-  skinny_fused_body<NW>((const bf16_t*)P.a.p + (long)P.M * P.a.ld, P.a.ld, (const bf16_t*)P.b.p, P.b.ld, P.tail_rows, P.N, P.K, E, (float*)smem,
-                       unit >= 0 ? unit : (int)blockIdx.x - P.main_wgs);
+  E.slices = 1; E.slice = 0; E.slab = nullptr; E.cnt = nullptr;
+  int u = unit >= 0 ? unit : (int)blockIdx.x - P.main_wgs;
+  int k0 = 0, klen = P.K;
+  if (SL && P.tail_slices > 1) {       // (column block, K slice): a long contraction on 32 CUs is a chain of TA-bound fragment loads (fc2: 18 us for 40 rows)
+    const int cb = u / P.tail_slices;
+    E.slices = P.tail_slices; E.slice = u - cb * P.tail_slices;
+    klen = P.K / P.tail_slices; k0 = E.slice * klen;
+    E.cnt = (int*)((char*)P.ks_ws + 65536) + cb;
+    E.slab = (float*)((char*)P.ks_ws + 131072) + (long)cb * P.tail_slices * (64 * SK_BN);
+    u = cb;
+  }
+  skinny_fused_body<NW, 2, SL>((const bf16_t*)P.a.p + (long)P.M * P.a.ld + k0, P.a.ld, (const bf16_t*)P.b.p + k0, P.b.ld, P.tail_rows, P.N, klen, E,
+                       (float*)smem, u);
 }
 
 // Round 6: the ragged rows INSIDE the tile workgroups.  As extra workgroups behind the tiles (round 3) the tail units share the launch's
@@ -465,9 +480,12 @@ __device__ __forceinline__ int xcd_linear_index() {
 // of ANY channel count (B(k = input pixel, n = (tap, co)) = dy[output pixel (2y + tap / 2, 2x + tap % 2)][co]) and 3 x 3 / stride 1 / pad 1
 // convolution weight gradients (B(k = pixel, n = (tap, ci)) = x[pixel + tap shift][ci], zero outside the image; two concatenated sources).
 // GG = 2: the ConvTranspose form, GG = 3: the 3 x 3 convolution form (compile-time: the kernel is at its register limit, scalar ones included).
-template <typename TC, int SCHED, bool TN, bool GA, int GG = 0>
+// KS (NT, fp32 result): the tile's contraction is cut in two halves run by the workgroups (16 g + x, 16 g + 8 + x) -- the same XCD -- so that
+// a product with <= 128 tiles still occupies 256 CUs; the halves meet through fp32 slabs in P.ks_ws (ks_exchange below).
+template <typename TC, int SCHED, bool TN, bool GA, int GG = 0, bool KS = false>
 __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char* smem, const int lin) {
   static_assert(GG == 0 || ((GG == 2 || GG == 3) && TN && !GA), "general gather: weight-gradient form only");
+  static_assert(!KS || (!TN && !GA && sizeof(TC) == 4), "K-split pairs: plain NT products with an fp32 result");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -475,6 +493,7 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
   int nk = P.K / PBK;
   long kbeg = 0;                      // TN: first contraction row of this workgroup's split
   int my_split = 0;
+  int ks_split = 0, ks_tile = 0, ks_kt0 = 0;
   if constexpr (TN) {
     // (split, tile): the linear index walks the tiles of one split before the next split, so the workgroups that share a K range (and
     // with it the A / B panels) sit on one XCD's L2
@@ -487,6 +506,13 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
     kbeg = (long)first * (2 * PBK);
     nk = 2 * (base + (split < extra ? 1 : 0));
     my_split = split;
+  } else if constexpr (KS) {
+    const int bid = blockIdx.x;
+    ks_split = (bid >> 3) & 1;
+    ks_tile = ((bid >> 4) << 3) | (bid & 7);
+    tile_coords_of(P, P.main_wgs >> 1, ks_tile, tm, tn);
+    nk >>= 1;
+    ks_kt0 = ks_split * nk;
   } else {
     tile_coords(P, tm, tn);
   }
@@ -616,7 +642,7 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
     // buffer soffset of K-tile kt.  NT gather: K runs over (tap, co); a K-tile lies inside one tap (C % 64 == 0, C a power of two).
     // (plain statements, not a helper lambda: a lambda call inside the LDS-DMA builtin's argument list makes the HOST pass drop the
     // kernel's stub without a diagnostic -- the library then fails to load with an undefined symbol)
-    unsigned soff = kt * (which < 2 ? kstep_a : kstep_b);
+    unsigned soff = (KS ? kt + ks_kt0 : kt) * (which < 2 ? kstep_a : kstep_b);
     if constexpr (GA && !TN && which < 2) {
       const int k = kt * PBK, tap = k >> P.a.logC, within = k - (tap << P.a.logC);
       soff = (unsigned)((((tap >> 1) * P.a.Wi + (tap & 1)) * (int)P.a.ld + within) * 2);
@@ -827,6 +853,11 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
     finish(3);
   };
 
+  int* ks_st = nullptr;          // KS: {alive, flag of split 0, flag of split 1, done} of this tile (all zero between launches)
+  if constexpr (KS) {
+    ks_st = (int*)P.ks_ws + ks_tile * 4;
+    if (tid == 0) __hip_atomic_fetch_add(ks_st, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // "resident": the peer may wait for this workgroup from here on
+  }
   // ---- prologue: K-tiles 0 and 1 entirely, then A0(2) once A-half0[0] has been read ----
   stage(IC<0>{}, IC<0>{}, 0); stage(IC<2>{}, IC<0>{}, 0); stage(IC<3>{}, IC<0>{}, 0); stage(IC<1>{}, IC<0>{}, 0);
   stage(IC<0>{}, IC<1>{}, 1); stage(IC<2>{}, IC<1>{}, 1); stage(IC<3>{}, IC<1>{}, 1); stage(IC<1>{}, IC<1>{}, 1);
@@ -853,6 +884,109 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
   TC* Cb = (TC*)P.C + (long)batch * P.cbs;
   const TC* Rb = (const TC*)P.residual;
   if (Rb) Rb += (long)batch * P.cbs;
+  // ---- KS: the two K halves of the tile meet.  Slab of (tile, split): 32 chunks of 512 lanes x 16 bytes = the 128 accumulator registers in
+  // register order (chunk ((i*2+j)*2+b)*4+q, lane tid): private layout, both sides use the same lane <-> element map.  Stores and loads are
+  // sc1 (write-through / L2-bypassing: the per-XCD L2s are not coherent and a pair may sit anywhere), flags relaxed agent-scope atomics
+  // behind a vmcnt(0) drain + barrier.  Three ways through, decided per tile at run time so that NO workgroup ever waits for one that is
+  // not resident (any occupancy, any dispatch order):
+  //   both resident (alive == 2): each publishes the quadrant row the OTHER finishes (128 KB), raises its flag (1), waits for the peer's
+  //     flag (the peer is running: bounded), adds the peer's half to its own quadrant row and runs the epilogue on those 128 rows;
+  //   peer not started yet (alive == 1): publish everything (256 KB), flag = 2, leave; the peer finds the flag whenever it gets there,
+  //     adds the whole slab and finishes both quadrant rows;
+  //   (a peer that already left with flag 2 is found by the first look, or by the wait loop if the two decisions raced.)
+  // a + b == b + a in fp32: the result does not depend on which way a tile went (bit-reproducible run to run).
+  // The second of the pair to leave restores the four words to zero.
+  int ks_rows = 3;                  // bit i: this workgroup finishes quadrant row i
+  if constexpr (KS) {
+    volatile int* bc = (volatile int*)smem;
+    const int peer = 1 - ks_split;
+    const auto rmine = __builtin_amdgcn_make_buffer_rsrc((void*)((float*)((char*)P.ks_ws + 131072) + ((long)ks_tile * 2 + ks_split) * (PBM * PBN)), 0,
+                                                         PBM * PBN * 4, 0x00020000);
+    const auto rpeer = __builtin_amdgcn_make_buffer_rsrc((void*)((float*)((char*)P.ks_ws + 131072) + ((long)ks_tile * 2 + peer) * (PBM * PBN)), 0,
+                                                         PBM * PBN * 4, 0x00020000);
+    auto leave = [&]() {
+      if (tid == 0) {
+        const int d = __hip_atomic_fetch_add(ks_st + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == 1) {
+#pragma unroll
+          for (int w = 0; w < 4; w++) __hip_atomic_store(ks_st + w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    };
+    auto publish = [&](auto i_c) {
+      constexpr int i = decltype(i_c)::value;
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = acc[i][j][b][4 * q + e];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rmine, (((((i * 2 + j) * 2 + b) * 4 + q) * 512) + tid) * 16, 0, 16);
+          }
+    };
+    auto take = [&](auto i_c) {
+      constexpr int i = decltype(i_c)::value;
+#pragma unroll
+      for (int g = 0; g < 2; g++) {       // eight 16-byte loads in flight per lane
+        u32x4_t v[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = __builtin_amdgcn_raw_buffer_load_b128(rpeer, (((i * 16 + g * 8 + c) * 512) + tid) * 16, 0, 16);
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const f32x4 f = __builtin_bit_cast(f32x4, v[c]);
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[i][g][(c >> 2) & 1][4 * (c & 3) + e] += f[e];
+        }
+      }
+    };
+    if (tid == 0) {
+      if ((P.dbg & 16) && ks_split == 1) {       // test aid: this half looks late (finds a peer that left)
+        for (int w = 0; w < 2000; w++) __builtin_amdgcn_s_sleep(32);
+      }
+      const int f = __hip_atomic_load(ks_st + 1 + peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int a = __hip_atomic_load(ks_st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bc[0] = f == 2 ? 2 : (a >= 2 ? 1 : 0);
+    }
+    __syncthreads();
+    int mode = bc[0];
+    __syncthreads();
+    if (P.dbg & 2) mode = 0;        // measurement aid: publish and leave
+    if ((P.dbg & 8) && ks_split == 0 && mode == 1) mode = 0;      // test aid: this half behaves as if its peer had not started
+    if (mode == 0) {                // the peer has not started: hand everything over
+      publish(IC<0>{}); publish(IC<1>{});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(ks_st + 1 + ks_split, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      leave();
+      return;
+    }
+    if (mode == 1) {
+      if (ks_split == 0) publish(IC<1>{}); else publish(IC<0>{});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_store(ks_st + 1 + ks_split, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int f = 0;
+        for (long spin = 0; spin < (1L << 24); spin++) {      // the peer is resident: it raises its flag after at most its main loop + publish
+          f = __hip_atomic_load(ks_st + 1 + peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (f) break;
+          __builtin_amdgcn_s_sleep(4);
+        }
+        if (!f) __hip_atomic_store((int*)P.ks_ws + 16380, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // never seen; tests read this word
+        bc[0] = f;
+      }
+      __syncthreads();
+      mode = bc[0] == 2 ? 2 : (bc[0] == 1 ? 1 : 3);
+      __syncthreads();
+    }
+    // (one site per quadrant row: two copies of take<i> on different paths made the allocator give the sums new registers and spill at the merge)
+    if (mode != 2) ks_rows = 1 << ks_split;      // (mode 3, the error path -- the flag never came: the own rows without the peer's half)
+    if (mode == 2 || (mode == 1 && ks_split == 0)) take(IC<0>{});
+    if (mode == 2 || (mode == 1 && ks_split == 1)) take(IC<1>{});
+  }
   if (P.dbg & 2) return;            // measurement aid (du_set_option key 3): no epilogue at all
   if constexpr (TN) {
     if (colsum_on) {
@@ -938,6 +1072,7 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
     float* stg = (float*)smem;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
+      if constexpr (KS) { if (!((ks_rows >> i) & 1)) continue; }
       if (i > 0) __syncthreads();
 #pragma unroll
       for (int j = 0; j < 2; j++)
@@ -951,18 +1086,35 @@ __device__ __forceinline__ void p8_tile_body(const GemmParams& P, unsigned char*
       readout_f32_any<TC, PBN>(P, stg, P8_STG_LDF, 128, m0 + i * 128, n0, Cb, Rb, tid);
     }
   }
+  if constexpr (KS) {              // the second of the pair to get here restores the tile's four words
+    if (tid == 0) {
+      const int d = __hip_atomic_fetch_add(ks_st + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d == 1) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) __hip_atomic_store(ks_st + w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 template <typename TC, int SCHED, bool TN, bool GA>
 __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if constexpr (!TN && !GA) {
-    if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<TC>(P, smem); return; }
+    if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<TC, 8, true>(P, smem); return; }
   }
   p8_tile_body<TC, SCHED, TN, GA>(P, smem, TN ? xcd_linear_index() : 0);
   if constexpr (!TN && !GA) {
     if (P.tail_rows && (int)gridDim.x == P.main_wgs && gridDim.y == 1) p8_tail_inline<TC>(P, smem, (int)blockIdx.x, P.main_wgs);
   }
+}
+
+// the K-split pair form (fp32 result, <= 128 tiles): see KS in p8_tile_body
+template <int SCHED>
+__global__ __launch_bounds__(512) void gemm_nt_p8ks_kernel(GemmParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<float>(P, smem); return; }
+  p8_tile_body<float, SCHED, false, false, 0, true>(P, smem, 0);
 }
 
 // ---- grouped weight gradients: several dW = dY^T X products in ONE launch (du_gemm_tn_group) ----------------------------------------
@@ -1043,7 +1195,7 @@ __device__ __forceinline__ void p8n_tile_body(const GemmParams& P, unsigned char
 template <typename TC, int SCHED>
 __global__ __launch_bounds__(512) void gemm_nt_p8n_kernel(GemmParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<TC>(P, smem); return; }
+  if (P.tail_rows && (int)blockIdx.x >= P.main_wgs) { p8_tail<TC, 8, true>(P, smem); return; }
   p8n_tile_body<TC, SCHED>(P, smem);
   if (P.tail_rows && (int)gridDim.x == P.main_wgs && gridDim.y == 1) p8_tail_inline<TC>(P, smem, (int)blockIdx.x, P.main_wgs);
 }
@@ -1530,7 +1682,6 @@ constexpr unsigned PP_OOR = 0x80000000u;          // a voffset past every descri
 __device__ __forceinline__ void pp_swap_halves(unsigned& a, unsigned& b) {      // a's lanes 32-63 <-> b's lanes 0-31
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // (free functions: an asm operand that is a local captured by a generic lambda does not compile)
 __device__ __forceinline__ void pp_lds_read1(f32x4& a, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=&v"(a) : "v"(addr)); }
 __device__ __forceinline__ void pp_wait_lds(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
@@ -2102,6 +2253,21 @@ int g_p8_pp_full = 0;    // du_set_option key 11 (A-B aid): 1 = the persistent k
 int g_p8_group = 4;
 int g_p8_debug = 0;      // bit 0: skip the bf16 global stores, bit 1: skip the whole epilogue (timing ablations only)
 
+constexpr long KS_STATE_BYTES = 131072;       // [0, 64 KB): 4 words per tile (<= 4095 tiles) + the error word at int index 16380; [64 KB, 128 KB): tail tickets
+int g_p8_tail_slices = 1;      // du_set_option key 17: 1 = ragged-row units of a long contraction (K >= 2048) are cut into K slices that meet through ks_ws
+// slices per 32-column block of the ragged-row units (1 = whole contraction per unit): <= 8, >= 512 contraction elements each, at most one
+// round of 256 workgroups; needs the persistent scratch
+static int tail_slices_for(const du_gemm_args& a, bool have_ws) {
+  if (!g_p8_tail_slices || a.K < (g_p8_tail_slices >= 2 ? 1024 : 2048) || g_p8_tail_inline) return 1;      // (key 17 = 2: A-B aid, K = 1024 too)
+  const int units = (a.N + SK_BN - 1) / SK_BN;
+  int s = a.K / 512;
+  if (s > 8) s = 8;
+  while (s > 1 && (a.K % (s * SK_CHUNK) || units * s > 256)) s--;
+  if (s < 2 || units > 16384) return 1;
+  if (have_ws && (!a.ks_ws || a.ks_ws_bytes < KS_STATE_BYTES + (long)units * s * 64 * SK_BN * 4)) return 1;
+  return s;
+}
+
 template <typename TC, int SCHED, bool NARROW, bool GA = false>
 int launch_p8(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
   static_assert(!(NARROW && GA), "the gather form exists for the 256 x 256 kernel only");
@@ -2115,7 +2281,10 @@ int launch_p8(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
   if (tail_rows > 0 && !GA) {       // the ragged rows behind M ride along: inside the tile workgroups (round 6), or one extra workgroup per 32 output columns
     P.tail_rows = tail_rows; P.main_wgs = P.tiles_m * P.tiles_n;
     // (inline only when the tiles fill the chip: with idle CUs -- 128 tiles of 256 x 256 -- the extra workgroups run beside the tiles for free)
-    if (!(g_p8_tail_inline && grid.y == 1 && (long)grid.x * g_p8_corun >= 256)) grid.x += (a.N + SK_BN - 1) / SK_BN;
+    if (!(g_p8_tail_inline && grid.y == 1 && (long)grid.x * g_p8_corun >= 256)) {
+      P.tail_slices = tail_slices_for(a, true); P.ks_ws = a.ks_ws;
+      grid.x += (a.N + SK_BN - 1) / SK_BN * P.tail_slices;
+    }
   }
   void (*kfn)(GemmParams);
   if constexpr (NARROW) kfn = gemm_nt_p8n_kernel<TC, SCHED>; else kfn = gemm_nt_p8_kernel<TC, SCHED, false, GA>;
@@ -2189,6 +2358,28 @@ int launch_p4(const du_gemm_args& a, hipStream_t st, int tail_rows = 0) {
 }
 
 // weight-gradient form: C[m][n] += alpha * sum_k A[k][m] * B[k][n] (both operands contraction-major, fp32 atomics into a zeroed C)
+int g_p8_ks = 0;         // du_set_option key 16: 1 = fp32-result products with <= 128 tiles of 256 x 256 run as K-split pairs (gemm_nt_p8ks_kernel)
+inline long ks_ws_need(long tiles) { return KS_STATE_BYTES + tiles * 2 * PBM * PBN * 4; }
+
+int launch_p8ks(const du_gemm_args& a, hipStream_t st, int tail_rows) {
+  GemmParams P = make_params(a, DU_PLAIN_ROW, DU_PLAIN_ROW, PBM, PBN, PBK);
+  P.tiles_m = (a.M + PBM - 1) / PBM;
+  P.group_m = g_p8_group;
+  P.dbg = g_p8_debug;
+  P.ks_ws = a.ks_ws;
+  P.main_wgs = 2 * P.tiles_m * P.tiles_n;
+  dim3 grid(P.main_wgs, 1);
+  if (tail_rows > 0) { P.tail_rows = tail_rows; grid.x += (a.N + SK_BN - 1) / SK_BN; }
+  void (*kfn)(GemmParams) = g_p8_sched ? gemm_nt_p8ks_kernel<1> : gemm_nt_p8ks_kernel<0>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[g_p8_sched ? 1 : 0]) {
+    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS) != hipSuccess) return DU_ERR_LAUNCH;
+    attr_set[g_p8_sched ? 1 : 0] = true;
+  }
+  hipLaunchKernelGGL(kfn, grid, dim3(512), P8_LDS, st, P);
+  return du_check_launch();
+}
+
 int g_p8_tn = 1;         // du_set_option key 5: 0 = keep these products on the 128 x 128 register-staged kernel, 1 = where it pays, 2 = wherever legal
 
 template <int SCHED, bool GA>
@@ -2235,6 +2426,8 @@ extern "C" int du_set_option(int key, int value) {
     case 13: g_wgrad_rows = value; return DU_OK;
     case 14: g_p8_res = value; return DU_OK;
     case 15: g_p8_tail_inline = value; return DU_OK;
+    case 16: g_p8_ks = value; return DU_OK;
+    case 17: g_p8_tail_slices = value; return DU_OK;
     default: return DU_ERR_BAD_ARG;
   }
 }
@@ -2315,8 +2508,21 @@ static bool pp_legal(const du_gemm_args& a) {
   return ((long)a.M * a.lda + a.K) * 2 < lim && ((long)a.N * a.ldb + a.K) * 2 < lim && ((long)a.M * a.ldc + a.N) * 2 < lim;
 }
 
+// the K-split pair form of the 256 x 256 kernel: fp32 result, plain store, whole pairs of K-tile pairs per half, tiles a multiple of 8 (a pair =
+// workgroups 16 g + x and 16 g + 8 + x), both halves of every tile resident at once on an otherwise idle chip (<= 128 tiles)
+static bool ks_shape_ok(const du_gemm_args& a) {
+  if (!p8_legal(a) || a.out_dtype != DU_F32 || a.store_mode != DU_STORE_PLAIN || a.batch > 1 || a.act == DU_ACT_SWIGLU) return false;
+  if (a.K % 256 || a.K < 1024 || g_p8_corun != 1) return false;
+  const long tiles = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  return tiles % 8 == 0 && tiles >= 64 && tiles <= 128;
+}
+static bool ks_legal(const du_gemm_args& a) {
+  if (!ks_shape_ok(a) || !a.ks_ws || (((uintptr_t)a.ks_ws) & 15)) return false;
+  return a.ks_ws_bytes >= ks_ws_need((long)((a.M + 255) / 256) * ((a.N + 255) / 256));
+}
+
 // 0: not served by gemm_p8.hip, 1: 256 x 256 tiles, 2: 256 x 128 tiles (8 waves, one workgroup per CU), 3: 256 x 128 tiles on 4 waves, two workgroups per CU,
-// 4: 256 x 128 tiles, persistent workgroups
+// 4: 256 x 128 tiles, persistent workgroups, 5: 256 x 256 tiles as K-split pairs
 int du_gemm_p8_choice(const du_gemm_args& a) {
   if (g_p8_mode != 0 && g_p8_tn && p8_gather_legal(a))      // ConvT data gradient: 256 x 256 tiles once they fill most of the CUs
     return (g_p8_mode > 0 || (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 192) ? 1 : 0;
@@ -2327,6 +2533,8 @@ int du_gemm_p8_choice(const du_gemm_args& a) {
     const long t = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
     return (g_p8_persist && g_p8_mode != 2 && pp_legal(a) && (g_p8_persist > 1 || g_p8_mode == 4 || t >= 2 * (256 / g_p8_corun))) ? 4 : 2;
   }
+  if (g_p8_ks && g_p8_mode < 0 && ks_legal(a)) return 5;
+  if (g_p8_mode == 5) return ks_legal(a) ? 5 : 2;
   if (g_p8_mode == 3) return a.act == DU_ACT_SWIGLU ? 2 : 3;
   if (g_p8_mode == 4) return pp_legal(a) ? 4 : 2;
   if (g_p8_mode > 0) return g_p8_mode == 2 ? 2 : 1;
@@ -2363,6 +2571,16 @@ int du_gemm_p8_choice(const du_gemm_args& a) {
   return 2;
 }
 bool du_gemm_p8_wants(const du_gemm_args& a) { return du_gemm_p8_choice(a) != 0; }
+// bytes of du_gemm_args.ks_ws the K-sliced ragged-row units want for `whole` (0: one unit per column block)
+long du_gemm_p8_tail_bytes(const du_gemm_args& whole) {
+  const int s = tail_slices_for(whole, false);
+  return s > 1 ? KS_STATE_BYTES + (long)((whole.N + SK_BN - 1) / SK_BN) * s * 64 * SK_BN * 4 : 0;
+}
+// bytes of du_gemm_args.ks_ws the pair kernel wants for this product (its full tile rows): 0 = it would not run there
+long du_gemm_p8_ks_bytes(const du_gemm_args& a) {
+  if (!(g_p8_ks && g_p8_mode < 0) && g_p8_mode != 5) return 0;
+  return ks_shape_ok(a) ? ks_ws_need((long)((a.M + 255) / 256) * ((a.N + 255) / 256)) : 0;
+}
 
 // returns DU_ERR_UNSUPPORTED when these kernels cannot serve the product; the caller then uses gemm_glds.hip
 // tail_rows > 0: rows [a.M, a.M + tail_rows) of the same operands / result are computed in the same launch (p8_tail); the caller has checked
@@ -2375,6 +2593,7 @@ int du_gemm_nt_p8(const du_gemm_args& a, hipStream_t st, int tail_rows) {
   if (a.a_mode == DU_IM2COL_ROW) return g_p8_sched ? launch_p8<bf16_t, 1, false, true>(a, st) : launch_p8<bf16_t, 0, false, true>(a, st);
   const bool bf = a.out_dtype == DU_BF16;
   const int tr = tail_rows;
+  if (c == 5) return launch_p8ks(a, st, tr);
   if (c == 4) return launch_pp(a, st, tr);
   if (c == 3) return bf ? launch_p4<bf16_t>(a, st, tr) : launch_p4<float>(a, st, tr);
   if (c == 1) {

@@ -31,6 +31,8 @@ struct GemmParams {
   int tail_rows;          // gemm_p8.hip NT kernels: rows [M, M + tail_rows) (<= 64) are computed by the workgroups behind the first main_wgs
   int main_wgs;           //   ones (skinny_fused_body, gemm_skinny_body.h); 0 = no tail in this launch
   float* C2;              // DU_STORE_MSDA_PREP: the attention weights (C = the sampling locations)
+  void* ks_ws;            // du_gemm_args.ks_ws: [0, 64 KB) pair state of gemm_nt_p8ks_kernel, [64 KB, 128 KB) tail-unit tickets, then slabs
+  int tail_slices;        // > 1: the tail units are (32 columns, K slice) pairs that meet through ks_ws (gemm_skinny_body.h)
 };
 
 // element offset of C / residual element (m, n) for row stride ld: plain rows, or the pixel-shuffle store of ConvTranspose2d k2 s2

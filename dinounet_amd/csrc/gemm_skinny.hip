@@ -125,7 +125,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_fused_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                                     long ldb, int M, int N, int K, SkinnyEpi P) {
   extern __shared__ __attribute__((aligned(16))) float sk_red[];      // [NW][64][SK_BN + 1]
-  skinny_fused_body<NW>(A, lda, B, ldb, M, N, K, P, sk_red, (int)blockIdx.x);
+  skinny_fused_body<NW, (NW >= 16 ? 1 : 2)>(A, lda, B, ldb, M, N, K, P, sk_red, (int)blockIdx.x);      // (16 waves: 128 registers per lane)
 }
 
 template <int NW>

@@ -156,7 +156,7 @@ _MODE_NAMES = {(0, 0): "linear", (0, 1): "linear_dgrad", (1, 1): "linear_wgrad",
 
 
 _ROUTE_NAMES = {0: "gemm_kernel", 1: "gemm_bf16_kernel", 2: "gemm_nt_glds_kernel", 3: "gemm_nt_p8_kernel", 4: "gemm_nt_p8n_kernel", 5: "gemm_tn_p8_kernel",
-                6: "gemm_nt_pp_kernel", 7: "gemm_nt_rk_kernel"}
+                6: "gemm_nt_pp_kernel", 7: "gemm_nt_rk_kernel", 8: "gemm_nt_p8ks_kernel"}
 
 
 _AB_KNOBS = os.environ.get("DINOUNET_AB_KNOBS") == "1"
@@ -182,6 +182,24 @@ def gemm_route(**kw):
 TRACK_ROUTE = False          # tests: record the kernel family of the last product (du_gemm_route) in LAST_GEMM_ROUTE
 LAST_GEMM_ROUTE = -1
 ROUTES = []                  # (a_mode, b_mode, route) of every product since TRACK_ROUTE was switched on
+
+
+_KS_PAIRS = _ab_env("DINOUNET_KS_PAIRS", "1") == "1"      # lend du_gemm the pair-exchange scratch (the library decides: du_set_option key 16)
+_KS_SCRATCH = {}
+_KS_RETIRED = []
+
+
+def _ks_scratch(nbytes):
+    """du_gemm_args.ks_ws: per (device, stream), persistent; the state words at its head are zeroed once (every launch leaves them zero)"""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    buf = _KS_SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _KS_RETIRED.append(buf)      # a captured graph may still hold its address: never handed back to the allocator
+        buf = torch.empty(max(nbytes, 4 << 20), dtype=torch.uint8, device=torch.device("cuda", key[0]))
+        buf[:131072].zero_()
+        _KS_SCRATCH[key] = buf
+    return buf
 
 
 def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat, ldc, batch=1, abs_=0, bbs=0, cbs=0,
@@ -217,6 +235,11 @@ def gemm_raw(*, dtype, out_dtype, a_mode, b_mode, M, N, K, A, lda, B, ldb, Cmat,
         if n_ws > 0:
             ws = torch.empty(n_ws, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
             a.ws, a.ws_elems = ws.data_ptr(), n_ws
+    if _KS_PAIRS and dtype == DU_BF16 and a_mode == PLAIN_ROW and b_mode == PLAIN_ROW and store_mode == 0 and M >= 1024 and K >= 1024 and (
+            out_dtype == DU_F32 or 0 < M % 256 <= 64):
+        n_ks = int(_lib.lib().du_gemm_ks_ws_bytes(C.byref(a)))
+        if n_ks > 0:
+            a.ks_ws, a.ks_ws_bytes = _ks_scratch(n_ks).data_ptr(), n_ks
     global LAST_GEMM_ROUTE
     if TRACK_ROUTE:
         LAST_GEMM_ROUTE = int(_lib.lib().du_gemm_route(C.byref(a)))

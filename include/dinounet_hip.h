@@ -136,6 +136,12 @@ typedef struct {
                          this is the bias gradient sum_pixels dY[.., co]; same contract as a_colsum (zero-initialised, atomics,
                          DU_ERR_UNSUPPORTED unless du_gemm_route is 1 or 5) */
   float* C2;          /* DU_STORE_MSDA_PREP only: the second result (attention weights) */
+  void* ks_ws;        /* optional scratch for workgroups that meet INSIDE a launch: the K-sliced ragged-row units of a tall product with a long
+                         contraction (the ViT's fc2: M = 8 x 1029, K = 4096) and the K-split pair kernel (option key 16):
+                         du_gemm_ks_ws_bytes(args) bytes that PERSIST between calls on one stream; the first 131072 bytes zeroed ONCE by
+                         the caller (every launch leaves them zero again), the rest uninitialised.  One buffer per stream that may run
+                         such products concurrently.  NULL / too small: one unit per 32 columns, one workgroup per tile */
+  int64_t ks_ws_bytes;
 } du_gemm_args;
 
 int du_gemm(const du_gemm_args* args, void* stream);
@@ -143,6 +149,9 @@ int du_gemm(const du_gemm_args* args, void* stream);
    leaves a short ragged last tile row on an otherwise exactly filled GPU (the ViT's M = 8 * 1029): those rows then go through a
    K-parallel skinny kernel pair instead of opening a nearly empty extra round of 128 x 128 tiles. */
 int64_t du_gemm_ws_elems(const du_gemm_args* args);
+/* Bytes of ks_ws du_gemm would use for `args` (0: nothing in this product meets inside the launch: shape, epilogue, du_set_option keys
+   16 / 17). */
+int64_t du_gemm_ks_ws_bytes(const du_gemm_args* args);
 /* Kernel family du_gemm runs for the bulk of `args` (for profilers: names the kernel without mirroring the dispatch): 0 generic,
    1 bf16 tile engine (gemm_bf16.hip), 2 128 x 128 direct-to-LDS NT kernel (gemm_glds.hip), 3 / 4 the 256 x 256 / 256 x 128
    multi-phase NT kernels (gemm_p8.hip). */
@@ -471,6 +480,10 @@ int du_device_ok(void); /* 1 if the current device is gfx950 */
            0 = the round-3 one;
    key 15: the <= 64 ragged rows behind the last full 256-row tile of a tall NT product (the ViT: M = 8 x 1029): 0 = by extra workgroups
            behind the tile grid (default), 1 = by the tile workgroups themselves once their tiles are done;
+   key 16: fp32-result NT products with 64-128 tiles of 256 x 256 and K >= 1024 (the ViT's proj / fc2) as K-split pairs of workgroups that
+           exchange fp32 halves inside the launch (needs du_gemm_args.ks_ws): 0 = off (default), 1 = on;
+   key 17: the ragged-row units of a product with K >= 2048 on the one-shot tile kernels (the ViT's fc2) as (32 columns, K slice) pairs that
+           meet through du_gemm_args.ks_ws: 1 (default), 0 = one unit per 32 columns walks the whole contraction;
    key 14: bf16 products with a bf16 residual on the persistent kernel (the residual as two more K-steps): 1 (default), 0 = one-shot kernels;
    key 9: number of independent products the caller keeps in flight on DIFFERENT streams (default 1; dinounet_amd runs the frozen ViT as
           two half-batch chains): du_gemm's tile choice then counts workgroup rounds on 256 / value CUs. */

@@ -184,6 +184,91 @@ def test_gemm_persistent_residual_in_place():
     assert got.data_ptr() == buf.data_ptr() and torch.equal(got, want)
 
 
+@pytest.mark.parametrize("M,N,K", [(4136, 1024, 1024), (8232, 1024, 4096), (4096, 2048, 1024)])
+def test_gemm_k_split_pairs_every_way_through_the_exchange(M, N, K):
+    """fp32-result products with 64-128 tiles of 256 x 256 (the ViT's proj / fc2: LayerScale + residual epilogue, layers/block.py:126-198) as
+    K-split pairs of workgroups (gemm_nt_p8ks_kernel, du_set_option key 16): against the fp32 product; the three ways through the exchange
+    (both halves resident; one leaves first and the other finds its flag in the wait loop / at its first look -- forced by the test aids in
+    du_set_option key 3) give the SAME bits, repeats are bit-identical, the scratch state is zero again after every launch and the
+    error word (a flag that never came) stays clear; ragged rows ride in the same launch."""
+    from dinounet_amd import ops, _lib
+    d = dev()
+    bf = torch.bfloat16
+    L = _lib.lib()
+    x, w = q(gen(M, K, seed=1), bf).to(d, bf), q(gen(N, K, seed=2, scale=K ** -0.5), bf).to(d, bf)
+    b, gam, res = gen(N, seed=3).to(d), gen(N, seed=4).to(d), gen(M, N, seed=5).to(d)
+    ref = ((x.double() @ w.double().t()) + b.double()) * gam.double() + res.double()
+    run = lambda: ops.mm(x, w, bias=b, gamma=gam, residual=res, out=torch.empty((M, N), dtype=torch.float32, device=d))
+    outs = []
+    ops.TRACK_ROUTE = True
+    try:
+        L.du_set_option(16, 1)
+        for aid in (0, 8, 24, 16):
+            L.du_set_option(3, aid)
+            y = run()
+            assert ops.LAST_GEMM_ROUTE == 8, ops.LAST_GEMM_ROUTE
+            for _ in range(10 if aid == 0 else 2):
+                assert torch.equal(run(), y)
+            torch.cuda.synchronize()
+            state = next(iter(ops._KS_SCRATCH.values()))[:131072].view(torch.int32)
+            assert int(state.abs().sum().item()) == 0, f"aid {aid}: pair state not restored (error word {int(state[16380].item())})"
+            outs.append(y)
+        L.du_set_option(16, 0)
+        L.du_set_option(3, 0)
+        plain = run()
+        assert ops.LAST_GEMM_ROUTE != 8, ops.LAST_GEMM_ROUTE
+    finally:
+        ops.TRACK_ROUTE = False
+        L.du_set_option(16, 0)
+        L.du_set_option(3, 0)
+    for y in outs[1:]:
+        assert torch.equal(y, outs[0])
+    scale = ref.abs().max().item()
+    assert (outs[0].double() - ref).abs().max().item() / scale < 2e-5
+    assert (outs[0] - plain).abs().max().item() / scale < 2e-5
+
+
+@pytest.mark.parametrize("od", ["f32", "bf16"])
+def test_gemm_ragged_rows_as_k_sliced_units(od):
+    """fc2 of the ViT (M = 8 x 1029, K = 4096): the 40 ragged rows run as (32 columns, K slice) units behind the tiles that meet through
+    du_gemm_args.ks_ws -- slabs written through, a ticket, the last arriver adds the slices in slice order (du_set_option key 17).  Same rows
+    as the one-unit-per-column-block form up to fp32 summation order, bit-identical run to run, tickets back at zero."""
+    import ctypes
+    from dinounet_amd import ops, _lib
+    d = dev()
+    bf = torch.bfloat16
+    L = _lib.lib()
+    M, N, K = 8232, 1024, 4096
+    odt = torch.float32 if od == "f32" else bf
+    x, w = q(gen(M, K, seed=1), bf).to(d, bf), q(gen(N, K, seed=2, scale=K ** -0.5), bf).to(d, bf)
+    b, gam, res = gen(N, seed=3).to(d), gen(N, seed=4).to(d), gen(M, N, seed=5).to(d).to(odt)
+    kw = dict(bias=b, residual=res) if od == "bf16" else dict(bias=b, gamma=gam, residual=res)
+    run = lambda: ops.mm(x, w, out=torch.empty((M, N), dtype=odt, device=d), **kw)
+    a = _lib.GemmArgs()
+    a.dtype, a.out_dtype, a.a_mode, a.b_mode = _lib.DU_BF16, _lib.DU_F32 if od == "f32" else _lib.DU_BF16, ops.PLAIN_ROW, ops.PLAIN_ROW
+    a.M, a.N, a.K, a.batch, a.split_k, a.alpha = M, N, K, 1, 1, 1.0
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = x.data_ptr(), K, w.data_ptr(), K, res.data_ptr(), N
+    assert int(L.du_gemm_ks_ws_bytes(ctypes.byref(a))) >= 131072 + 32 * 8 * 8192
+    try:
+        y = run()
+        for _ in range(10):
+            assert torch.equal(run(), y)
+        torch.cuda.synchronize()
+        state = next(iter(ops._KS_SCRATCH.values()))[:131072].view(torch.int32)
+        assert int(state.abs().sum().item()) == 0
+        L.du_set_option(17, 0)
+        assert int(L.du_gemm_ks_ws_bytes(ctypes.byref(a))) == 0
+        y1 = run()
+    finally:
+        L.du_set_option(17, 1)
+    assert torch.equal(y[:8192], y1[:8192])
+    ref = (x[8192:].double() @ w.double().t() + b.double()) * (gam.double() if od == "f32" else 1.0) + res[8192:].double()
+    tol = 2e-5 if od == "f32" else 1e-2
+    scale = ref.abs().max().item()
+    assert (y[8192:].double() - ref).abs().max().item() / scale < tol
+    assert (y1[8192:].double() - ref).abs().max().item() / scale < tol
+
+
 @pytest.mark.parametrize("inline", [0, 1])
 @pytest.mark.parametrize("N,K", [(1024, 1024), (3072, 1024), (1024, 4096)])
 def test_gemm_ragged_tail_split(N, K, inline):

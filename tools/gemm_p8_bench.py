@@ -84,6 +84,43 @@ def check():
     return ok
 
 
+def check_pairs():
+    """the K-split pair kernel (mode 5): against the fp32 product, 30 bit-identical repeats, every way through the exchange (test aids: bit 3 = the
+    first half leaves as if its peer had not started, bit 4 = the second half looks late), scratch state back to zero, error word clear"""
+    g = torch.Generator(device="cpu").manual_seed(2)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    ok = True
+    for M, N, K in ((8232, 1024, 4096), (8232, 1024, 1024), (8192, 1024, 2048), (4096, 2048, 1024), (4136, 1024, 1024)):
+        x, w = rnd(M, K).to(bf), (rnd(N, K) * 0.05).to(bf)
+        bias, gamma, res = rnd(N), rnd(N), rnd(M, N)
+        ref = (x.float() @ w.float().t() + bias) * gamma + res
+        scale = ref.abs().max().item()
+        opt(mode=2)
+        y2 = run(x, w, torch.float32, bias, gamma, res)
+        outs = []
+        for dbg in (0, 8, 24, 16):
+            opt(mode=5, debug=dbg)
+            ops.TRACK_ROUTE = True
+            y = run(x, w, torch.float32, bias, gamma, res)
+            ops.TRACK_ROUTE = False
+            route = ops.LAST_GEMM_ROUTE
+            same = all(torch.equal(run(x, w, torch.float32, bias, gamma, res), y) for _ in range(30 if dbg == 0 else 3))
+            torch.cuda.synchronize()
+            st = next(iter(ops._KS_SCRATCH.values()))[:131072].view(torch.int32)
+            clean = int(st.abs().sum().item()) == 0
+            e = (y - ref).abs().max().item() / scale
+            good = route == 8 and same and clean and e < 2e-3
+            ok &= good
+            outs.append(y)
+            print(f"check pair M{M} N{N} K{K} aid {dbg:2d}: route {route} err {e:.2e} vs 256x128 {(y - y2).abs().max().item() / scale:.2e} deterministic {same} "
+                  f"state clean {clean} -> {'OK' if good else 'FAIL'}", flush=True)
+        same_all = all(torch.equal(o, outs[0]) for o in outs[1:])
+        ok &= same_all
+        print(f"   every way through the exchange gives the same bits: {same_all}", flush=True)
+    opt()
+    return ok
+
+
 def time_variants(rounds):
     g = torch.Generator(device="cpu").manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g).to(dev).to(bf)
@@ -105,6 +142,11 @@ def time_variants(rounds):
         shapes = [(43008, 1024, 256, torch.float32, "ffn_fc2_res"), (43008, 1024, 512, torch.float32, "oproj_res"), (8232, 1024, 1024, torch.float32, "proj"),
                   (8232, 1024, 4096, torch.float32, "fc2"), (8192, 1024, 1024, torch.float32, "proj8192")]
         variants = [v for v in variants if v[0] in ("256x256", "256 noepi", "256x128", "128 noepi", "4wave", "4w noepi", "auto")]
+    if "--kspair" in sys.argv:       # round 6: fp32-result products with <= 128 tiles of 256 x 256 as K-split pairs (du_set_option key 16 / mode 5)
+        shapes = [(8232, 1024, 4096, torch.float32, "fc2"), (8232, 1024, 1024, torch.float32, "proj"), (8192, 1024, 4096, torch.float32, "fc2_8192"),
+                  (8192, 1024, 1024, torch.float32, "proj8192"), (4096, 2048, 2048, torch.float32, "sq_128t"), (8232, 768, 3072, torch.float32, "fc2_b")]
+        variants = [v for v in variants if v[0] in ("256x256", "256 noepi", "256x128", "128 noepi", "auto")] + [
+            ("pair", dict(mode=5)), ("pair noepi", dict(mode=5, debug=2))]
     bf16res = "--bf16res" in sys.argv
     if bf16res:      # round 6: the adapter's products into the bf16 query stream as the model issues them (bias + bf16 residual, fc2: + DropPath scale)
         shapes = [(43008, 1024, 256, bf, "ffn_fc2_res"), (43008, 1024, 512, bf, "oproj_res"), (43008, 1024, 1024, bf, "k1024_res"),
@@ -170,7 +212,7 @@ def time_variants(rounds):
 
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
-    ok = True if "--narrow" in sys.argv else check()
+    ok = check_pairs() if "--kspair" in sys.argv else (True if "--narrow" in sys.argv else check())
     if rounds > 0:
         time_variants(rounds)
     print("CHECK", "PASSED" if ok else "FAILED")
