@@ -446,7 +446,7 @@ __device__ __forceinline__ void p8_tail(const GemmParams& P, unsigned char* smem
     E.slab = (float*)((char*)P.ks_ws + 131072) + (long)cb * P.tail_slices * (64 * SK_BN);
     u = cb;
   }
-  skinny_fused_body<NW, 2, SL>((const bf16_t*)P.a.p + (long)P.M * P.a.ld + k0, P.a.ld, (const bf16_t*)P.b.p + k0, P.b.ld, P.tail_rows, P.N, klen, E,
+  skinny_fused_body<NW, 2, SL, (NW == 8)>((const bf16_t*)P.a.p + (long)P.M * P.a.ld + k0, P.a.ld, (const bf16_t*)P.b.p + k0, P.b.ld, P.tail_rows, P.N, klen, E,
                        (float*)smem, u);
 }
 

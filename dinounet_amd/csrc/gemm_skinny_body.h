@@ -23,7 +23,7 @@ struct SkinnyEpi {
 constexpr int SK_BN = 32;          // output columns per workgroup
 constexpr int SK_CHUNK = 64;       // contraction elements per wave step (4 MFMAs)
 
-template <int NW, int CB = 2, bool SL = false>
+template <int NW, int CB = 2, bool SL = false, bool STG = false>
 __device__ __forceinline__ void skinny_fused_body(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, int M, int N,
                                                   int K, const SkinnyEpi& P, float* sk_red, int blk) {
   constexpr int SLOT = 64 * (SK_BN + 1);
@@ -63,6 +63,59 @@ __device__ __forceinline__ void skinny_fused_body(const bf16_t* __restrict__ A, 
   EpiOps E0;
   const bool sliced = SL && P.slices > 1;      // (SL = false: the slice code is not compiled in -- it costs the persistent kernels registers)
   if (!sliced) fetch(tid, E0);
+  if constexpr (STG) {
+    // Operands through LDS in whole lines (round 6).  The fragment-shaped loads below fetch 32 rows x 16 bytes per instruction: 32 cache lines
+    // for 1 KB, four instructions per line -- the address path walks 4 x more lines than the data has (K = 1024: ~6100 line visits per unit,
+    // ~2.6 us of the unit's ~6).  Here a K-step is 512 contraction elements of the 32 W rows + 64 A rows = 96 rows x 1 KB: one wave reads one
+    // whole row per instruction (8 lines), 12 instructions per lane, all in flight; the rows are parked in LDS (row pitch 1 KB + 16 B: the
+    // 32 rows of a fragment read start 4 banks apart) and every wave takes the fragments of its 64-wide chunk from there.  The next
+    // K-step's loads are in flight under the MFMAs.  The staging area is the reduce slots' memory (they are written after the last step).
+    static_assert(NW == 8, "one K-step = 8 chunks, one per wave");
+    constexpr int KST = 512, PITCH = KST * 2 + 16, NPC = 96 * 64 / (NW * 64);
+    unsigned char* stg = (unsigned char*)sk_red;
+    const int nst = (K + KST - 1) / KST;
+    bf16x8 cur[NPC];
+    auto request = [&](int st) {
+#pragma unroll
+      for (int it = 0; it < NPC; it++) {
+        const int pc = it * (NW * 64) + tid, row = pc >> 6, c16 = pc & 63;
+        const int kk = st * KST + c16 * 8;
+        const bf16_t* src = row < 32 ? B + (long)min(n0 + row, N - 1) * ldb : A + (long)min(row - 32, M - 1) * lda;
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; e++) z[e] = (bf16_t)0.f;
+        cur[it] = (kk < K && (row < 64 || nrb > 1)) ? *(const bf16x8*)(src + kk) : z;
+      }
+    };
+    request(0);
+    for (int st = 0; st < nst; st++) {
+      if (st > 0) __syncthreads();               // the previous step's fragment reads
+#pragma unroll
+      for (int it = 0; it < NPC; it++) {
+        const int pc = it * (NW * 64) + tid;
+        *(bf16x8*)(stg + (pc >> 6) * PITCH + (pc & 63) * 16) = cur[it];
+      }
+      if (st + 1 < nst) request(st + 1);
+      __syncthreads();
+      if (st * KST + wave * SK_CHUNK < K) {
+        const unsigned char* fr = stg + (lane & 31) * PITCH + wave * 128 + (lane >> 5) * 64;
+        bf16x8 fb[4], fa0[4], fa1[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) fb[j] = *(const bf16x8*)(fr + j * 16);
+#pragma unroll
+        for (int j = 0; j < 4; j++) fa0[j] = *(const bf16x8*)(fr + 32 * PITCH + j * 16);
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[j], fb[j], acc0, 0, 0, 0);
+        if (nrb > 1) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) fa1[j] = *(const bf16x8*)(fr + 64 * PITCH + j * 16);
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[j], fb[j], acc1, 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                             // the slots below overwrite the staging area
+  } else {
   // workgroup j starts its walk over the K chunks at a different chunk (and wraps): with long rows (K = 4096: 8 KB pitch) every load of
   // the launch otherwise hits the same few memory channels at the same time (32 rows at ONE column offset per load, all workgroups in step)
   const int nchunk = K / SK_CHUNK;
@@ -98,6 +151,7 @@ __device__ __forceinline__ void skinny_fused_body(const bf16_t* __restrict__ A, 
         }
       }
     }
+  }
   }
   {   // D layout: column lane & 31, row (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* slot = sk_red + wave * SLOT;
