@@ -2407,6 +2407,7 @@ extern int g_attn_w;      // attention.hip
 extern int g_attn_impl, g_attn_thresh_log2, g_attn_var;
 extern int g_rk_mode;     // gemm_rk.hip
 extern int g_wgrad_rows;  // conv_halo.hip
+extern int g_ln_rows2;    // norm.hip
 
 extern "C" int du_set_option(int key, int value) {
   switch (key) {
@@ -2428,6 +2429,7 @@ extern "C" int du_set_option(int key, int value) {
     case 15: g_p8_tail_inline = value; return DU_OK;
     case 16: g_p8_ks = value; return DU_OK;
     case 17: g_p8_tail_slices = value; return DU_OK;
+    case 18: g_ln_rows2 = value; return DU_OK;
     default: return DU_ERR_BAD_ARG;
   }
 }

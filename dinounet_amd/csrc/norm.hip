@@ -2,6 +2,8 @@
 // All are HBM-bound: 16-byte vector loads, fp32 statistics, wave64 shuffle reductions, one pass per tensor.
 #include "common.h"
 
+int g_ln_rows2 = 1;      // du_set_option key 18: LayerNorm forward with two rows per wave: 0 never, 1 where one round of waves overflows by < 2x (default), 2 always
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------------
@@ -53,6 +55,71 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict
       const int c0 = vi * VI;
 #pragma unroll
       for (int j = 0; j < VI; j++) y[row * ldy + c0 + j] = from_f32<TO>((v[i][j] - mean) * rstd * w[c0 + j] + b[c0 + j]);
+    }
+  }
+}
+
+// Two rows per wave, both rows' loads in flight (round 6).  With one row per wave the ViT's 8232 rows are 8232 waves on a chip that holds
+// 8192 (32 per CU): forty waves form a round of their own behind the first -- a whole load / reduce / store latency chain for 0.5 % of
+// the rows, 52 times per step.  Half the waves, the same bytes in flight.
+template <typename TI, typename TO, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_fwd2_kernel(const TI* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                             const float* __restrict__ b, TO* __restrict__ y, long ldy,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                             long rows, int D, float eps) {
+  constexpr int VI = Elem<TI>::VEC;
+  const int lane = threadIdx.x & 63;
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+  if (row0 >= rows) return;
+  const bool two = row0 + 1 < rows;
+  const int nvec = D / VI;
+  float v[2][MAXV][VI];
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 2; u++)
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+      const int vi = lane + i * 64;
+      if (vi < nvec && (u == 0 || two)) {
+        Vec16<TI> t = as_vec<TI>(*(const uint4*)(x + (row0 + u) * ldx + (long)vi * VI));
+#pragma unroll
+        for (int j = 0; j < VI; j++) { v[u][i][j] = to_f32(t.v[j]); s[u] += v[u][i][j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < VI; j++) v[u][i][j] = 0.f;
+      }
+    }
+  float mean[2], rstd[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) mean[u] = wave_sum(s[u]) / (float)D;
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+#pragma unroll
+        for (int j = 0; j < VI; j++) { const float d = v[u][i][j] - mean[u]; s2 += d * d; }
+      }
+    }
+    rstd[u] = rsqrtf(wave_sum(s2) / (float)D + eps);
+  }
+  if (lane == 0) {
+    if (mean_out) { mean_out[row0] = mean[0]; if (two) mean_out[row0 + 1] = mean[1]; }
+    if (rstd_out) { rstd_out[row0] = rstd[0]; if (two) rstd_out[row0 + 1] = rstd[1]; }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; i++) {
+    const int vi = lane + i * 64;
+    if (vi < nvec) {
+      const int c0 = vi * VI;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (u == 1 && !two) break;
+#pragma unroll
+        for (int j = 0; j < VI; j++) y[(row0 + u) * ldy + c0 + j] = from_f32<TO>((v[u][i][j] - mean[u]) * rstd[u] * w[c0 + j] + b[c0 + j]);
+      }
     }
   }
 }
@@ -734,6 +801,19 @@ int ln_fwd_dispatch(const void* x, long ldx, const float* w, const float* b, voi
   const int nvec = D / Elem<TI>::VEC;
   const int maxv = (nvec + 63) / 64;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  // rows that overflow ONE round of waves (32 per CU) by a little: two rows per wave (see layernorm_fwd2_kernel)
+  static int wave_slots = 0;
+  if (!wave_slots) {
+    int dev = 0; hipDeviceProp_t prop;
+    wave_slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? 32 * prop.multiProcessorCount : 8192;
+  }
+  if (g_ln_rows2 && maxv <= 4 && (g_ln_rows2 > 1 || (rows > wave_slots && rows <= 2L * wave_slots))) {
+    dim3 grid2((unsigned)((rows + 7) / 8));
+#define LN2_LAUNCH(MV) hipLaunchKernelGGL((layernorm_fwd2_kernel<TI, TO, MV>), grid2, block, 0, st, (const TI*)x, ldx, w, b, (TO*)y, ldy, m, r, rows, D, eps)
+    if (maxv <= 1) LN2_LAUNCH(1); else if (maxv <= 2) LN2_LAUNCH(2); else LN2_LAUNCH(4);
+#undef LN2_LAUNCH
+    return du_check_launch();
+  }
 #define LN_LAUNCH(MV) hipLaunchKernelGGL((layernorm_fwd_kernel<TI, TO, MV>), grid, block, 0, st, (const TI*)x, ldx, w, b, (TO*)y, ldy, m, r, rows, D, eps)
   if (maxv <= 1) LN_LAUNCH(1); else if (maxv <= 2) LN_LAUNCH(2); else if (maxv <= 4) LN_LAUNCH(4);
   else if (maxv <= 8) LN_LAUNCH(8); else if (maxv <= 16) LN_LAUNCH(16); else return DU_ERR_UNSUPPORTED;

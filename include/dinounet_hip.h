@@ -484,6 +484,8 @@ int du_device_ok(void); /* 1 if the current device is gfx950 */
            exchange fp32 halves inside the launch (needs du_gemm_args.ks_ws): 0 = off (default), 1 = on;
    key 17: the ragged-row units of a product with K >= 2048 on the one-shot tile kernels (the ViT's fc2) as (32 columns, K slice) pairs that
            meet through du_gemm_args.ks_ws: 1 (default), 0 = one unit per 32 columns walks the whole contraction;
+   key 18: du_layernorm_fwd with two rows per wave: 1 = where the rows overflow one round of waves (32 per CU) by less than 2x -- the ViT's
+           8232 rows (default), 0 = never, 2 = always;
    key 14: bf16 products with a bf16 residual on the persistent kernel (the residual as two more K-steps): 1 (default), 0 = one-shot kernels;
    key 9: number of independent products the caller keeps in flight on DIFFERENT streams (default 1; dinounet_amd runs the frozen ViT as
           two half-batch chains): du_gemm's tile choice then counts workgroup rounds on 256 / value CUs. */

@@ -912,6 +912,32 @@ def test_layernorm_fwd_bwd(dt, D):
     assert rel(y2, F.layer_norm(x, (D,), w, b, 1e-5).view(-1, D)) < TOL[dt]
 
 
+@pytest.mark.parametrize("rows,D,idt,odt", [(8232, 1024, "f32", "bf16"), (8233, 768, "f32", "bf16"), (9001, 384, "bf16", "bf16"), (8200, 1024, "f32", "f32")])
+def test_layernorm_fwd_two_rows_per_wave_is_bit_identical(rows, D, idt, odt):
+    """du_layernorm_fwd with two rows per wave (the ViT's 8232 rows overflow one round of waves by forty, `du_set_option(18, .)`): the same
+    per-row arithmetic as the one-row kernel -- rows, means and rstds identical bit for bit, odd row counts included; against torch."""
+    from dinounet_amd import ops, _lib
+    d = dev()
+    L = _lib.lib()
+    it = torch.float32 if idt == "f32" else torch.bfloat16
+    ot = torch.float32 if odt == "f32" else torch.bfloat16
+    x = (gen(rows, D, seed=1) * 3.0 + 0.5).to(d).to(it)
+    w, b = gen(D, seed=2).to(d), gen(D, seed=3).to(d)
+    try:
+        L.du_set_option(18, 0)
+        y0, m0, r0 = ops.layernorm_raw(x, w, b, 1e-6, ot, want_stats=True)
+        L.du_set_option(18, 2)
+        y2, m2, r2 = ops.layernorm_raw(x, w, b, 1e-6, ot, want_stats=True)
+        L.du_set_option(18, 1)
+        y1, _, _ = ops.layernorm_raw(x, w, b, 1e-6, ot)
+    finally:
+        L.du_set_option(18, 1)
+    assert torch.equal(y0, y2) and torch.equal(m0, m2) and torch.equal(r0, r2) and torch.equal(y0, y1)
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), w, b, 1e-6)
+    tol = 2e-5 if odt == "f32" else 1.6e-2
+    assert (y2.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("rows,D,with_res", [(5376, 1024, True), (4100, 256, False), (2049, 512, True)])
 def test_layernorm_bwd_many_rows(dt, rows, D, with_res):
